@@ -1,0 +1,105 @@
+"""ctypes binding of libclibd_hip.so (C ABI declared in include/clibd_hip.h).
+
+The product path has NO CPU fallback: if the shared object is missing or a symbol cannot be bound the
+import of any compute entry point raises.  (`oracle/` is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("CLIBD_HIP_LIB", _HERE / "libclibd_hip.so"))
+
+c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class GemmEpilogue(C.Structure):
+    """Mirror of `struct clibd_gemm_epilogue` (include/clibd_hip.h)."""
+
+    _fields_ = [
+        ("bias", c_void_p),
+        ("rank_u", c_void_p),
+        ("rank_v", c_void_p),
+        ("aux_bf16", c_void_p),
+        ("residual_f32", c_void_p),
+        ("out_pre_bf16", c_void_p),
+        ("out_bf16", c_void_p),
+        ("out_f32", c_void_p),
+        ("act", C.c_int32),
+        ("ld_rank_u", C.c_int32),
+        ("ld_aux", C.c_int32),
+        ("ld_res", C.c_int32),
+        ("ld_pre", C.c_int32),
+        ("ld_out_bf16", C.c_int32),
+        ("ld_out_f32", C.c_int32),
+        ("split_k", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/clibd_hip.h declares must appear here
+SIGNATURES = {
+    "clibd_last_error": (C.c_char_p, []),
+    "clibd_abi_version": (c_int, []),
+    "clibd_gemm_bf16_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
+    "clibd_transpose_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "clibd_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "clibd_cast_transpose_f32_to_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clibd_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clibd_attention_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "clibd_attention_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "clibd_lora_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clibd_lora_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clibd_patchify": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "clibd_vit_cls_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_bert_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clibd_softmax_mean_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_softmax_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_token_mean_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_token_mean_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_gather_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_scatter_rows_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "clibd_l2norm_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "clibd_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_softce_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "clibd_softce_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "clibd_softce_rows_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "clibd_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+class ClibdHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library and bind every declared symbol. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ClibdHipError(
+            f"{LIB_PATH} not found: build it with `python -m clibd_amd.build` (hipcc, gfx950). "
+            "clibd_amd has no CPU fallback for its compute path."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ClibdHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().clibd_last_error()
+        raise ClibdHipError(f"{what} failed ({code}): {msg.decode() if msg else '?'}")

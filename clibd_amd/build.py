@@ -1,0 +1,110 @@
+"""Build libclibd_hip.so (gfx950) in-tree with hipcc.
+
+    python -m clibd_amd.build [--force] [--report]
+
+hipcc cross-compiles without a GPU, so this runs on the CPU-only authoring box; the built .so is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+INCLUDE = HERE.parent / "include"
+LIB = HERE / "libclibd_hip.so"
+OBJ = CSRC / "build"
+ARCH = "gfx950"
+SOURCES = ["capi", "gemm", "layernorm", "attention", "lora", "elementwise", "loss"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _deps() -> list[Path]:
+    return [p for p in CSRC.glob("*.h")] + [INCLUDE / "clibd_hip.h"]
+
+
+def _stale(target: Path, srcs: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(s.stat().st_mtime > t for s in srcs)
+
+
+def _compile_one(name: str, report: bool) -> tuple[str, str]:
+    src = CSRC / f"{name}.hip"
+    obj = OBJ / f"{name}.o"
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", str(src), "-o", str(obj)]
+    if report:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+    return name, r.stderr
+
+
+def _summarise(stderr: str) -> list[str]:
+    rows, cur = [], {}
+    for line in stderr.splitlines():
+        m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|SGPRs Spill|VGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]):\s*(\S+)", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if k == "Function Name":
+            if cur:
+                rows.append(cur)
+            cur = {"name": v}
+        else:
+            cur[k] = v
+    if cur:
+        rows.append(cur)
+    out = []
+    for r in rows:
+        out.append(
+            f"{r['name'][:70]:70s} vgpr={r.get('VGPRs','?'):>4} agpr={r.get('AGPRs','?'):>3} spill={r.get('VGPRs Spill','?'):>3} "
+            f"scratch={r.get('ScratchSize [bytes/lane]','?'):>4} occ={r.get('Occupancy [waves/SIMD]','?')} lds={r.get('LDS Size [bytes/block]','?')}"
+        )
+    return out
+
+
+def build(force: bool = False, report: bool = False, verbose: bool = True) -> Path:
+    OBJ.mkdir(parents=True, exist_ok=True)
+    deps = _deps()
+    todo = [n for n in SOURCES if force or report or _stale(OBJ / f"{n}.o", [CSRC / f"{n}.hip"] + deps)]
+    if todo:
+        if verbose:
+            print(f"[clibd_amd.build] hipcc --offload-arch={ARCH}: {', '.join(todo)}", flush=True)
+        with cf.ThreadPoolExecutor(max_workers=min(4, len(todo))) as ex:
+            for name, err in ex.map(lambda n: _compile_one(n, report), todo):
+                if report:
+                    print(f"== {name}")
+                    print("\n".join(_summarise(err)))
+    objs = [OBJ / f"{n}.o" for n in SOURCES]
+    if force or todo or _stale(LIB, objs):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+        if verbose:
+            print(f"[clibd_amd.build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--report", action="store_true", help="print per-kernel register/LDS usage")
+    a = ap.parse_args()
+    build(force=a.force, report=a.report)
+    sys.exit(0)

@@ -1,0 +1,413 @@
+// Multi-head attention forward / backward for short sequences (S <= 256, head dim 64) on gfx950.
+//
+// One workgroup (4 waves) per (batch, head).  The whole K/V (forward) or K,V then Q,dO (backward) of that
+// head lives in LDS as [S_pad][64] bf16 tiles (128-B rows, 16-B chunk index XOR (row&7)), filled by 16-byte
+// LDS-DMA with the swizzle applied on the per-lane source address.  Scores for one 16-query tile against
+// ALL keys fit in registers (<= 16 key tiles x 4 fp32), so softmax is an exact full-row softmax: no online
+// rescaling, no saved LSE.
+//
+// Orientation ("key on the MFMA row, query on the lane"): S^T = K·Q^T via
+// v_mfma_f32_16x16x32_bf16(A = K rows, B = Q rows) leaves each lane with ONE query (lane&15) and keys
+// 16*kt + 4*(lane>>4) + reg.  Those accumulators, packed to bf16, are directly the B operand of the next
+// product that contracts over keys (P·V, dS·K) with the k-slot -> key map
+//      kappa(g, j) = 32*s + 16*(j>>2) + 4*g + (j&3)        (g = lane>>4, j = 0..7)
+// and the other operand (V^T / K^T rows = head-dim) is fetched with ds_read_b64_tr_b16 using the same map.
+#include "common.h"
+#include "../../include/clibd_hip.h"
+#include "host_util.h"
+
+namespace clibd {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int ATT_THREADS = 256;
+constexpr int ATT_WAVES = 4;
+constexpr int DH = 64;
+constexpr int MAX_KT = 16;  // S_pad <= 256
+
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// stage rows [0,S_pad) x 64 bf16 of one head (global row stride `ld` elements) into an LDS tile
+__device__ __forceinline__ void stage_head_tile(char* lds_tile, const unsigned short* gbase, size_t ld, int S, int S_pad,
+                                                int wave, int lane) {
+    const int prow = lane >> 3;
+    const int chunk = (lane & 7) ^ prow;
+    for (int p = wave; p < (S_pad >> 3); p += ATT_WAVES) {
+        const int row = min(p * 8 + prow, S - 1);
+        glds16(gbase + (size_t)row * ld + chunk * 8, lds_tile + p * 1024);
+    }
+}
+
+__device__ __forceinline__ bf16x8 lds_row_frag(const char* tile, int row, int ks, int g) {
+    return *(const bf16x8*)(tile + tile_off(row, 4 * ks + g));
+}
+
+// transposed fragment: rows d = 16*dt + (lane&15), k-slots (g,j) -> tile rows kappa(g,j) = 32*s+16*(j>>2)+4*g+(j&3)
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* tile, int s, int dt, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int q = i >> 2, p = i & 3;
+    const int r0 = 32 * s + 4 * g + q;
+    const int ch = 2 * dt + (p >> 1);
+    const int a0 = tile_off(r0, ch) + 8 * (p & 1);
+    const int a1 = tile_off(r0 + 16, ch) + 8 * (p & 1);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + a1));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+    r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
+    r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
+    return r;
+}
+
+__device__ __forceinline__ float group4_sum(float v) {  // across the 4 lane groups (lane>>4) at fixed lane&15
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float group4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// ============================================ forward ==========================================================
+template <int NKT>  // number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32)
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int S,
+                                                                    int nheads, const int* __restrict__ key_mask,
+                                                                    unsigned short* __restrict__ out, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int S_pad = 16 * NKT;
+    char* kt_lds = smem;
+    char* vt_lds = smem + S_pad * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / nheads, h = blockIdx.x % nheads;
+    const int H = nheads * DH;
+    const size_t ld = (size_t)3 * H;
+    const unsigned short* qbase = qkv + (size_t)b * S * ld + h * DH;
+    stage_head_tile(kt_lds, qbase + H, ld, S, S_pad, wave, lane);
+    stage_head_tile(vt_lds, qbase + 2 * H, ld, S, S_pad, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int g = lane >> 4, i = lane & 15;
+    // per-lane key validity for keys 16*kt + 4*g + r
+    const int nqt = (S + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
+        const int q = qt * 16 + i;
+        const int qc = min(q, S - 1);
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (size_t)qc * ld + 32 * ks + 8 * g);
+        f32x4 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            sc[kt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(kt_lds, kt * 16 + i, ks, g), qf[ks], sc[kt], 0, 0, 0);
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                bool ok = key < S;
+                if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+                const float v = ok ? sc[kt][r] * scale : NEG_BIG;
+                sc[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = group4_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(sc[kt][r] - mx);
+                sc[kt][r] = e;
+                sum += e;
+            }
+        sum = group4_sum(sum);
+        const float inv = 1.0f / sum;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NKT / 2; ++s) {
+            f32x4 p0 = sc[2 * s], p1 = sc[2 * s + 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p0[r] *= inv; p1[r] *= inv; }
+            const bf16x8 pf = pack_frag(p0, p1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(vt_lds, s, dt, lane), pf, o[dt], 0, 0, 0);
+        }
+        if (q < S) {
+            unsigned short* orow = out + ((size_t)b * S + q) * H + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk;
+                pk.x = pack2bf(o[dt][0], o[dt][1]);
+                pk.y = pack2bf(o[dt][2], o[dt][3]);
+                *(uint2*)(orow + 16 * dt + 4 * g) = pk;
+            }
+        }
+    }
+}
+
+// ============================================ backward =========================================================
+template <int NKT>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
+                                                                    const unsigned short* __restrict__ dout, int S,
+                                                                    int nheads, const int* __restrict__ key_mask,
+                                                                    unsigned short* __restrict__ dqkv, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int S_pad = 16 * NKT;
+    char* t0 = smem;                      // phase 1: K   | phase 2: Q
+    char* t1 = smem + S_pad * 128;        // phase 1: V   | phase 2: dO
+    float* st_m = (float*)(smem + 2 * S_pad * 128);  // row max (scaled scores)
+    float* st_il = st_m + S_pad;                      // 1 / row sum
+    float* st_d = st_il + S_pad;                      // delta = sum_k P dP
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / nheads, h = blockIdx.x % nheads;
+    const int H = nheads * DH;
+    const size_t ld = (size_t)3 * H;
+    const unsigned short* qbase = qkv + (size_t)b * S * ld + h * DH;
+    const unsigned short* dobase = dout + (size_t)b * S * H + h * DH;
+    unsigned short* dqbase = dqkv + (size_t)b * S * ld + h * DH;
+    const int g = lane >> 4, i = lane & 15;
+
+    stage_head_tile(t0, qbase + H, ld, S, S_pad, wave, lane);
+    stage_head_tile(t1, qbase + 2 * H, ld, S, S_pad, wave, lane);
+    for (int r = threadIdx.x; r < S_pad; r += ATT_THREADS) { st_m[r] = 0.f; st_il[r] = 0.f; st_d[r] = 0.f; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---------------- phase 1: per 16-query tile: softmax statistics, dS, dQ ----------------
+    const int nqt = (S + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
+        const int q = qt * 16 + i;
+        const int qc = min(q, S - 1);
+        bf16x8 qf[2], dof[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = *(const bf16x8*)(qbase + (size_t)qc * ld + 32 * ks + 8 * g);
+            dof[ks] = *(const bf16x8*)(dobase + (size_t)qc * H + 32 * ks + 8 * g);
+        }
+        f32x4 sc[NKT], dp[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            sc[kt] = (f32x4){0, 0, 0, 0};
+            dp[kt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t0, kt * 16 + i, ks, g), qf[ks], sc[kt], 0, 0, 0);
+                dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t1, kt * 16 + i, ks, g), dof[ks], dp[kt], 0, 0, 0);
+            }
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                bool ok = key < S;
+                if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+                const float v = ok ? sc[kt][r] * scale : NEG_BIG;
+                sc[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = group4_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(sc[kt][r] - mx);
+                sc[kt][r] = e;
+                sum += e;
+            }
+        sum = group4_sum(sum);
+        const float inv = 1.0f / sum;
+        float dl = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sc[kt][r] * inv;  // fp32 softmax output (autograd differentiates the fp32 softmax)
+                sc[kt][r] = p;
+                dl += p * dp[kt][r];
+            }
+        dl = group4_sum(dl);
+        if (g == 0) { st_m[q] = mx; st_il[q] = inv; st_d[q] = dl; }  // q < S_pad always
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NKT / 2; ++s) {
+            f32x4 d0, d1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d0[r] = sc[2 * s][r] * (dp[2 * s][r] - dl) * scale;
+                d1[r] = sc[2 * s + 1][r] * (dp[2 * s + 1][r] - dl) * scale;
+            }
+            const bf16x8 dsf = pack_frag(d0, d1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(t0, s, dt, lane), dsf, dq[dt], 0, 0, 0);
+        }
+        if (q < S) {
+            unsigned short* orow = dqbase + (size_t)q * ld;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk;
+                pk.x = pack2bf(dq[dt][0], dq[dt][1]);
+                pk.y = pack2bf(dq[dt][2], dq[dt][3]);
+                *(uint2*)(orow + 16 * dt + 4 * g) = pk;
+            }
+        }
+    }
+    __syncthreads();  // every wave is done reading K/V tiles; statistics are visible
+
+    // ---------------- phase 2: per 16-key tile: dV, dK (query on the MFMA row, key on the lane) ----------------
+    stage_head_tile(t0, qbase, ld, S, S_pad, wave, lane);
+    stage_head_tile(t1, dobase, (size_t)H, S, S_pad, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nkt = (S + 15) >> 4;
+    for (int kt = wave; kt < nkt; kt += ATT_WAVES) {
+        const int key = kt * 16 + i;
+        const int kc = min(key, S - 1);
+        bool key_ok = key < S;
+        if (key_ok && key_mask != nullptr) key_ok = key_mask[(size_t)b * S + key] != 0;
+        bf16x8 kf[2], vf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[ks] = *(const bf16x8*)(qbase + H + (size_t)kc * ld + 32 * ks + 8 * g);
+            vf[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kc * ld + 32 * ks + 8 * g);
+        }
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll 1
+        for (int s = 0; s < NKT / 2; ++s) {
+            f32x4 pp[2], dd[2];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const int qt = 2 * s + hq;
+                f32x4 sv = (f32x4){0, 0, 0, 0}, dpv = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t0, qt * 16 + i, ks, g), kf[ks], sv, 0, 0, 0);
+                    dpv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t1, qt * 16 + i, ks, g), vf[ks], dpv, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = qt * 16 + 4 * g + r;
+                    const bool ok = key_ok && (qq < S);
+                    const float m = st_m[qq], il = st_il[qq], dl = st_d[qq];
+                    const float p = ok ? __expf(sv[r] * scale - m) * il : 0.f;  // rounded to bf16 only inside dV's operand
+                    pp[hq][r] = p;
+                    dd[hq][r] = p * (dpv[r] - dl) * scale;
+                }
+            }
+            const bf16x8 pf = pack_frag(pp[0], pp[1]);
+            const bf16x8 dsf = pack_frag(dd[0], dd[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(t1, s, dt, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(t0, s, dt, lane), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (key < S) {
+            unsigned short* krow = dqbase + H + (size_t)key * ld;
+            unsigned short* vrow = dqbase + 2 * H + (size_t)key * ld;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk;
+                pk.x = pack2bf(dk[dt][0], dk[dt][1]);
+                pk.y = pack2bf(dk[dt][2], dk[dt][3]);
+                *(uint2*)(krow + 16 * dt + 4 * g) = pk;
+                pk.x = pack2bf(dv[dt][0], dv[dt][1]);
+                pk.y = pack2bf(dv[dt][2], dv[dt][3]);
+                *(uint2*)(vrow + 16 * dt + 4 * g) = pk;
+            }
+        }
+    }
+}
+
+static int att_check(const void* qkv, int B, int S, int nheads, const char* who) {
+    if (!qkv) return set_error(CLIBD_EINVAL, "attention: null pointer");
+    if (B <= 0 || S <= 0 || nheads <= 0) return set_error(CLIBD_EINVAL, "attention: non-positive shape");
+    if (S > 16 * MAX_KT) return set_error(CLIBD_EINVAL, "attention: S must be <= 256");
+    if ((long long)B * nheads > 0x7fffffffLL) return set_error(CLIBD_EINVAL, "attention: grid too large");
+    if (!aligned16(qkv)) return set_error(CLIBD_EINVAL, "attention: alignment");
+    (void)who;
+    return 0;
+}
+
+}  // namespace clibd
+
+using namespace clibd;
+
+#define ATT_DISPATCH(NKT_EXPR, MACRO) \
+    switch (NKT_EXPR) {               \
+        case 2: MACRO(2); break;      \
+        case 4: MACRO(4); break;      \
+        case 6: MACRO(6); break;      \
+        case 8: MACRO(8); break;      \
+        case 10: MACRO(10); break;    \
+        case 12: MACRO(12); break;    \
+        case 14: MACRO(14); break;    \
+        default: MACRO(16); break;    \
+    }
+
+extern "C" int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
+                                   void* stream) {
+    if (int e = att_check(qkv, B, S, nheads, "fwd")) return e;
+    if (!out) return set_error(CLIBD_EINVAL, "attention_fwd: null out");
+    const int nkt = 2 * ((S + 31) / 32);
+    const size_t lds = (size_t)2 * nkt * 16 * 128;
+    const float scale = 0.125f;  // 1/sqrt(64)
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(N)                                                                                                 \
+    do {                                                                                                          \
+        hipFuncSetAttribute((const void*)attention_fwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(attention_fwd_kernel<N>, dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
+                           (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale); \
+    } while (0)
+    ATT_DISPATCH(nkt, LAUNCH)
+#undef LAUNCH
+    return check_launch("attention_fwd");
+}
+
+extern "C" int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
+                                   void* dqkv, void* stream) {
+    if (int e = att_check(qkv, B, S, nheads, "bwd")) return e;
+    if (!dout || !dqkv) return set_error(CLIBD_EINVAL, "attention_bwd: null pointer");
+    if (!aligned16(dout) || !aligned16(dqkv)) return set_error(CLIBD_EINVAL, "attention_bwd: alignment");
+    const int nkt = 2 * ((S + 31) / 32);
+    const size_t lds = (size_t)2 * nkt * 16 * 128 + (size_t)3 * nkt * 16 * sizeof(float);
+    const float scale = 0.125f;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(N)                                                                                                 \
+    do {                                                                                                          \
+        hipFuncSetAttribute((const void*)attention_bwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(attention_bwd_kernel<N>, dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
+                           (const unsigned short*)qkv, (const unsigned short*)dout, S, nheads, (const int*)key_mask, \
+                           (unsigned short*)dqkv, scale);                                                         \
+    } while (0)
+    ATT_DISPATCH(nkt, LAUNCH)
+#undef LAUNCH
+    return check_launch("attention_bwd");
+}

@@ -1,0 +1,63 @@
+// Shared device helpers for the CLIBD gfx950 kernels (wave64, MFMA bf16, LDS-DMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clibd {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (one MFMA A/B fragment)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+// round-to-nearest-even f32 -> bf16 (plain cast keeps NaN a NaN; lowers to v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned short f2bf(float x) {
+    __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) {
+    return __builtin_bit_cast(float, ((unsigned)h) << 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bfround(float x) { return bf2f(f2bf(x)); }
+
+// 16-byte LDS-DMA: each lane supplies its own global source; LDS dest = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_cvoid*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// erf with |abs err| <= 1.5e-7 (Abramowitz-Stegun 7.1.26); outputs are rounded to bf16 downstream
+__device__ __forceinline__ float fast_erf(float x) {
+    float ax = fabsf(x);
+    float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float y = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    float e = __expf(-ax * ax);
+    float r = 1.0f - y * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f));
+}
+// d/dx gelu(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+}  // namespace clibd

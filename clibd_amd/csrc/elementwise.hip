@@ -1,0 +1,390 @@
+// HBM/latency-bound helpers of the CLIBD step: embeddings, head tails, L2 normalisation, reductions, AdamW.
+#include "common.h"
+#include "../../include/clibd_hip.h"
+#include "host_util.h"
+
+namespace clibd {
+
+// ---- K1 front: image fp32 [B,3,224,224] -> patch matrix bf16 [B*196, 768], k = c*256 + py*16 + px ----------
+// one thread = 4 consecutive px (16 B read, 8 B write); a wave covers 4 (c,py) lines of one patch row-block.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B,
+                                                       unsigned short* __restrict__ out) {
+    const size_t total = (size_t)B * 196 * 192;  // quads
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) {
+        const int kq = (int)(q % 192);           // quad index inside the patch row: k = 4*kq
+        const size_t pr = q / 192;               // b*196 + p
+        const int p = (int)(pr % 196);
+        const int b = (int)(pr / 196);
+        const int k = kq * 4;
+        const int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
+        const int gy = (p / 14) * 16 + py, gx = (p % 14) * 16 + px;
+        const f32x4 v = *(const f32x4*)(img + (((size_t)b * 3 + c) * 224 + gy) * 224 + gx);
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2*)(out + pr * 768 + k) = o;
+    }
+}
+
+// tok[b,0,:] = cls + pos[0,:]
+__global__ __launch_bounds__(256) void vit_cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                                           int B, int S, int H, float* __restrict__ tok) {
+    const int total = B * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / H, h = i % H;
+        tok[(size_t)b * S * H + h] = cls[h] + pos[h];
+    }
+}
+
+// out[b*S+s, :] = word[id] + pos[s] + type[tt]
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tt,
+                                                         int B, int S, int H, int vocab,
+                                                         const float* __restrict__ word, const float* __restrict__ pos,
+                                                         const float* __restrict__ type, float* __restrict__ out) {
+    const int hq = H / 4;
+    const size_t total = (size_t)B * S * hq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % hq) * 4;
+        const size_t row = i / hq;
+        const int s = (int)(row % S);
+        long long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // host validates; clamp keeps a bad id from faulting
+        const long long t = tt ? (tt[row] != 0 ? 1 : 0) : 0;
+        const f32x4 w = *(const f32x4*)(word + (size_t)id * H + c);
+        const f32x4 p = *(const f32x4*)(pos + (size_t)s * H + c);
+        const f32x4 y = *(const f32x4*)(type + (size_t)t * H + c);
+        *(f32x4*)(out + row * H + c) = (f32x4){w[0] + p[0] + y[0], w[1] + p[1] + y[1], w[2] + p[2] + y[2], w[3] + p[3] + y[3]};
+    }
+}
+
+// ---- K7 tail: out[b,:] = mean_s softmax(logits[b,s,:])  (one block per b, one wave per token, LDS reduce) -------
+template <int NCH>  // NCH = C/256 rounded up; lane owns chunks of 4 columns: c = 4*(lane+64j)
+__global__ __launch_bounds__(256) void softmax_mean_fwd_kernel(const unsigned short* __restrict__ logits, int S, int C,
+                                                               float* __restrict__ out) {
+    __shared__ float part[4][1024];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) acc[j] = (f32x4){0, 0, 0, 0};
+    for (int s = wave; s < S; s += 4) {
+        const unsigned short* row = logits + ((size_t)b * S + s) * C;
+        f32x4 v[NCH];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = 4 * (lane + 64 * j);
+            if (c < C) {
+                const uint2 pk = *(const uint2*)(row + c);
+                v[j][0] = bf2f((unsigned short)(pk.x & 0xffff)); v[j][1] = bf2f((unsigned short)(pk.x >> 16));
+                v[j][2] = bf2f((unsigned short)(pk.y & 0xffff)); v[j][3] = bf2f((unsigned short)(pk.y >> 16));
+                mx = fmaxf(mx, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
+            } else {
+                v[j] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] = __expf(v[j][e] - mx);
+                sum += v[j][e];
+            }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][e] += v[j][e] * inv;
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c < C) *(f32x4*)(&part[wave][c]) = acc[j];
+    }
+    __syncthreads();
+    const float invS = 1.0f / (float)S;
+    for (int c = threadIdx.x; c < C; c += 256)
+        out[(size_t)b * C + c] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) * invS;
+}
+
+// dlogits[b,s,c] = p[s,c] * (g[c] - sum_c' p[s,c'] g[c']),  g = dout[b,:] / S
+template <int NCH>
+__global__ __launch_bounds__(256) void softmax_mean_bwd_kernel(const unsigned short* __restrict__ logits,
+                                                               const float* __restrict__ dout, int B, int S, int C,
+                                                               unsigned short* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const size_t rows = (size_t)B * S;
+    const float invS = 1.0f / (float)S;
+    for (size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * 4) {
+        const int b = (int)(r / S);
+        const unsigned short* row = logits + r * C;
+        f32x4 v[NCH], g[NCH];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = 4 * (lane + 64 * j);
+            if (c < C) {
+                const uint2 pk = *(const uint2*)(row + c);
+                v[j][0] = bf2f((unsigned short)(pk.x & 0xffff)); v[j][1] = bf2f((unsigned short)(pk.x >> 16));
+                v[j][2] = bf2f((unsigned short)(pk.y & 0xffff)); v[j][3] = bf2f((unsigned short)(pk.y >> 16));
+                g[j] = *(const f32x4*)(dout + (size_t)b * C + c);
+                mx = fmaxf(mx, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
+            } else {
+                v[j] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+                g[j] = (f32x4){0, 0, 0, 0};
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f, dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] = __expf(v[j][e] - mx);
+                sum += v[j][e];
+                dot += v[j][e] * g[j][e];
+            }
+        sum = wave_sum(sum);
+        dot = wave_sum(dot);
+        const float inv = 1.0f / sum;
+        const float pd = dot * inv;  // sum_c p_c g_c
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = 4 * (lane + 64 * j);
+            if (c < C) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = v[j][e] * inv * (g[j][e] - pd) * invS;
+                uint2 pk;
+                pk.x = pack2bf(o[0], o[1]);
+                pk.y = pack2bf(o[2], o[3]);
+                *(uint2*)(dlogits + r * C + c) = pk;
+            }
+        }
+    }
+}
+
+// out[b,:] = bf16(mean_s x[b,s,:])
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __restrict__ x, int S, int H,
+                                                             unsigned short* __restrict__ out_bf16) {
+    const int b = blockIdx.x;
+    const float invS = 1.0f / (float)S;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float s = 0.f;
+        for (int t = 0; t < S; ++t) s += x[((size_t)b * S + t) * H + h];
+        out_bf16[(size_t)b * H + h] = f2bf(s * invS);
+    }
+}
+// dx[b,s,:] = dout[b,:] / S
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, int B, int S, int H,
+                                                             float* __restrict__ dx) {
+    const size_t total = (size_t)B * S * H;
+    const float invS = 1.0f / (float)S;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % H);
+        const size_t b = i / ((size_t)S * H);
+        dx[i] = dout[b * H + h] * invS;
+    }
+}
+
+// column sums of bf16 [M,N] into fp32 out[N] (atomic accumulate): block = 256 rows chunk x 64 columns
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ x, int ld, int M, int N,
+                                                          float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * 256;
+    float s = 0.f;
+    if (c < N) {
+        const int r1 = min(r0 + 256, M);
+        for (int r = r0 + wave; r < r1; r += 4) s += bf2f(x[(size_t)r * ld + c]);
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < N) atomicAdd(out + c, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int B, int S, int H,
+                                                          float* __restrict__ out) {
+    const int total = B * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / H, h = i % H;
+        out[i] = x[(size_t)b * S * H + h];
+    }
+}
+// dx[b,0,:] = dcls[b,:], all other rows zero
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dcls, int B, int S, int H,
+                                                           unsigned short* __restrict__ dx_bf16,
+                                                           float* __restrict__ dx_f32) {
+    const size_t total = (size_t)B * S * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % H);
+        const size_t row = i / H;
+        const int s = (int)(row % S);
+        const size_t b = row / S;
+        const float v = (s == 0) ? dcls[b * H + h] : 0.f;
+        if (dx_f32) dx_f32[i] = v;
+        if (dx_bf16) dx_bf16[i] = f2bf(v);
+    }
+}
+
+// ---- K8: y = x / max(||x||, eps) -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int N, int D,
+                                                         float* __restrict__ y, float* __restrict__ inv_norm) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < N; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
+        s = wave_sum(s);
+        const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+        for (int c = lane; c < D; c += 64) y[(size_t)row * D + c] = xr[c] * inv;
+        if (lane == 0 && inv_norm) inv_norm[row] = inv;
+    }
+}
+// dx = inv * (dy - y * <dy, y>)   (for ||x|| > eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ inv_norm, int N, int D,
+                                                         float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < N; row += gridDim.x * 4) {
+        const float* g = dy + (size_t)row * D;
+        const float* yr = y + (size_t)row * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += g[c] * yr[c];
+        s = wave_sum(s);
+        const float inv = inv_norm[row];
+        for (int c = lane; c < D; c += 64) dx[(size_t)row * D + c] = inv * (g[c] - yr[c] * s);
+    }
+}
+
+// ---- fused AdamW on a flat bucket (torch.optim.AdamW: decoupled decay, bias-corrected) ---------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i];
+        pi *= (1.0f - lr * wd);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+static inline unsigned grid_for(size_t n, int per_block = 256, unsigned cap = 4096) {
+    size_t b = (n + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    return b < 1 ? 1u : (unsigned)b;
+}
+
+}  // namespace clibd
+
+using namespace clibd;
+
+extern "C" int clibd_patchify(const float* image, int B, void* patches_bf16, void* stream) {
+    if (!image || !patches_bf16 || B <= 0) return set_error(CLIBD_EINVAL, "patchify: bad args");
+    if (!aligned16(image) || !aligned16(patches_bf16)) return set_error(CLIBD_EINVAL, "patchify: alignment");
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((size_t)B * 196 * 192)), dim3(256), 0, (hipStream_t)stream, image, B,
+                       (unsigned short*)patches_bf16);
+    return check_launch("patchify");
+}
+
+extern "C" int clibd_vit_cls_rows(const float* cls, const float* pos, int B, int S, int H, float* tok, void* stream) {
+    if (!cls || !pos || !tok || B <= 0 || S <= 0 || H <= 0) return set_error(CLIBD_EINVAL, "vit_cls_rows: bad args");
+    hipLaunchKernelGGL(vit_cls_rows_kernel, dim3(grid_for((size_t)B * H)), dim3(256), 0, (hipStream_t)stream, cls, pos, B, S, H, tok);
+    return check_launch("vit_cls_rows");
+}
+
+extern "C" int clibd_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int S, int H, int vocab,
+                                const float* word, const float* pos, const float* type, float* out, void* stream) {
+    if (!ids || !word || !pos || !type || !out) return set_error(CLIBD_EINVAL, "bert_embed: null pointer");
+    if (B <= 0 || S <= 0 || H <= 0 || H % 4 != 0 || vocab <= 0) return set_error(CLIBD_EINVAL, "bert_embed: bad shape");
+    if (!aligned16(word) || !aligned16(pos) || !aligned16(type) || !aligned16(out)) return set_error(CLIBD_EINVAL, "bert_embed: alignment");
+    hipLaunchKernelGGL(bert_embed_kernel, dim3(grid_for((size_t)B * S * (H / 4))), dim3(256), 0, (hipStream_t)stream, ids,
+                       token_type, B, S, H, vocab, word, pos, type, out);
+    return check_launch("bert_embed");
+}
+
+extern "C" int clibd_softmax_mean_fwd(const void* logits, int B, int S, int C, float* out, void* stream) {
+    if (!logits || !out || B <= 0 || S <= 0) return set_error(CLIBD_EINVAL, "softmax_mean_fwd: bad args");
+    if (C <= 0 || C % 64 != 0 || C > 1024) return set_error(CLIBD_EINVAL, "softmax_mean_fwd: C must be a multiple of 64, <= 1024");
+    const int nch = (C + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(N) hipLaunchKernelGGL(softmax_mean_fwd_kernel<N>, dim3(B), dim3(256), 0, st, (const unsigned short*)logits, S, C, out)
+    switch (nch) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); break; }
+#undef LAUNCH
+    return check_launch("softmax_mean_fwd");
+}
+
+extern "C" int clibd_softmax_mean_bwd(const void* logits, const float* dout, int B, int S, int C, void* dlogits,
+                                      void* stream) {
+    if (!logits || !dout || !dlogits || B <= 0 || S <= 0) return set_error(CLIBD_EINVAL, "softmax_mean_bwd: bad args");
+    if (C <= 0 || C % 64 != 0 || C > 1024) return set_error(CLIBD_EINVAL, "softmax_mean_bwd: C must be a multiple of 64, <= 1024");
+    const int nch = (C + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(grid_for((size_t)B * S, 4));
+#define LAUNCH(N) hipLaunchKernelGGL(softmax_mean_bwd_kernel<N>, grid, dim3(256), 0, st, (const unsigned short*)logits, dout, B, S, C, (unsigned short*)dlogits)
+    switch (nch) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); break; }
+#undef LAUNCH
+    return check_launch("softmax_mean_bwd");
+}
+
+extern "C" int clibd_token_mean_fwd(const float* x, int B, int S, int H, void* out_bf16, void* stream) {
+    if (!x || !out_bf16 || B <= 0 || S <= 0 || H <= 0) return set_error(CLIBD_EINVAL, "token_mean_fwd: bad args");
+    hipLaunchKernelGGL(token_mean_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, S, H, (unsigned short*)out_bf16);
+    return check_launch("token_mean_fwd");
+}
+extern "C" int clibd_token_mean_bwd(const float* dout, int B, int S, int H, float* dx, void* stream) {
+    if (!dout || !dx || B <= 0 || S <= 0 || H <= 0) return set_error(CLIBD_EINVAL, "token_mean_bwd: bad args");
+    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(grid_for((size_t)B * S * H)), dim3(256), 0, (hipStream_t)stream, dout, B, S, H, dx);
+    return check_launch("token_mean_bwd");
+}
+
+extern "C" int clibd_colsum_bf16(const void* x, int ld, int M, int N, float* out, void* stream) {
+    if (!x || !out || M <= 0 || N <= 0 || ld < N) return set_error(CLIBD_EINVAL, "colsum: bad args");
+    dim3 grid((N + 63) / 64, (M + 255) / 256);
+    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ld, M, N, out);
+    return check_launch("colsum_bf16");
+}
+
+extern "C" int clibd_gather_rows(const float* x, int B, int S, int H, float* out, void* stream) {
+    if (!x || !out || B <= 0 || S <= 0 || H <= 0) return set_error(CLIBD_EINVAL, "gather_rows: bad args");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)B * H)), dim3(256), 0, (hipStream_t)stream, x, B, S, H, out);
+    return check_launch("gather_rows");
+}
+extern "C" int clibd_scatter_rows_bf16(const float* dcls, int B, int S, int H, void* dx_bf16, float* dx_f32, void* stream) {
+    if (!dcls || (!dx_bf16 && !dx_f32) || B <= 0 || S <= 0 || H <= 0) return set_error(CLIBD_EINVAL, "scatter_rows: bad args");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((size_t)B * S * H)), dim3(256), 0, (hipStream_t)stream, dcls, B, S, H,
+                       (unsigned short*)dx_bf16, dx_f32);
+    return check_launch("scatter_rows");
+}
+
+extern "C" int clibd_l2norm_fwd(const float* x, int N, int D, float* y, float* inv_norm, void* stream) {
+    if (!x || !y || N <= 0 || D <= 0) return set_error(CLIBD_EINVAL, "l2norm_fwd: bad args");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid_for((size_t)N, 4)), dim3(256), 0, (hipStream_t)stream, x, N, D, y, inv_norm);
+    return check_launch("l2norm_fwd");
+}
+extern "C" int clibd_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int N, int D, float* dx, void* stream) {
+    if (!dy || !y || !inv_norm || !dx || N <= 0 || D <= 0) return set_error(CLIBD_EINVAL, "l2norm_bwd: bad args");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid_for((size_t)N, 4)), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, N, D, dx);
+    return check_launch("l2norm_bwd");
+}
+
+extern "C" int clibd_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v) return set_error(CLIBD_EINVAL, "adamw: null pointer");
+    if (step < 1) return set_error(CLIBD_EINVAL, "adamw: step must be >= 1");
+    if (n == 0) return CLIBD_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, sqrtf(bc2), grad_scale);
+    return check_launch("adamw");
+}

@@ -1,0 +1,353 @@
+// bf16 MFMA GEMM for gfx950:  out = epilogue(A[M,K] · W[N,K]^T), fp32 accumulate.
+//
+// Structure (v1): 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile as 4x4
+// v_mfma_f32_16x16x32_bf16 tiles.  Both operands are K-contiguous ("NT"), staged global->LDS with
+// 16-byte LDS-DMA (global_load_lds_dwordx4) into a 2-deep ring; the LDS image is lane-linear, the
+// XOR swizzle (16-B chunk ^= row&7 inside 128-B rows) is applied on the per-lane SOURCE address and
+// again on the ds_read_b128 address, which makes every fragment read bank-conflict free.
+//
+// MFMA orientation: the W tile is the MFMA "A" operand (rows = n) and the activation tile the "B"
+// operand (cols = m), so each lane ends up with 4 consecutive n per accumulator tile for ONE output
+// row m.  W rows are additionally permuted when they are placed in LDS (row n_local = 16g+4t+r sits at
+// LDS row 16t+4g+r) so the 4 n-tiles of a lane are 16 CONTIGUOUS output columns: 32-byte bf16 /
+// 64-byte fp32 stores per lane, and full 128-B lines per row across a wave.
+#include "common.h"
+#include "../../include/clibd_hip.h"
+#include "host_util.h"
+
+namespace clibd {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+constexpr int GEMM_THREADS = 256;
+
+struct GemmParams {
+    const unsigned short* A;
+    const unsigned short* W;
+    int M, N, K, lda, ldw;
+    int tiles_m, tiles_n, ktiles_per_split;
+    clibd_gemm_epilogue ep;
+};
+
+// LDS row r (0..127) of the W tile holds tile-local output column perm(r)
+__device__ __forceinline__ int w_row_perm(int r) {
+    int r6 = r & 63;
+    int t = r6 >> 4, i = r6 & 15;
+    return (r & 64) + 16 * (i >> 2) + 4 * t + (i & 3);
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block -> (split, tile) mapping, XCD-aware: blocks that share an XCD (id % 8) get a contiguous
+    // chunk of tile ids, n fastest, so neighbouring tiles share the A panel and W stays in that XCD's L2.
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    const int split = bid / ntiles;
+    bid -= split * ntiles;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // group 8 m-tiles per band so a band's W reads repeat while its A panels are hot
+    const int band = 8;
+    const int band_id = bid / (band * p.tiles_n);
+    const int band_m0 = band_id * band;
+    const int band_h = min(band, p.tiles_m - band_m0);
+    const int in_band = bid - band_id * band * p.tiles_n;
+    const int tile_m = band_m0 + in_band % band_h;
+    const int tile_n = in_band / band_h;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int kt0 = split * p.ktiles_per_split;
+    const int nk = min(p.ktiles_per_split, p.K / BK - kt0);
+
+    // ---- per-lane source pointers for this wave's 4 A pieces and 4 W pieces (1 KiB = 8 rows each)
+    const int prow = lane >> 3;                 // row inside the piece
+    const int chunk = (lane & 7) ^ prow;        // logical 16-B chunk stored at LDS slot (lane&7) of that row
+    const char* a_src[4];
+    const char* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + prow;  // LDS row 0..127
+        const int gm = min(m0 + r, p.M - 1);
+        const int gn = min(n0 + w_row_perm(r), p.N - 1);
+        a_src[j] = (const char*)(p.A + (size_t)gm * p.lda + (size_t)kt0 * BK) + chunk * 16;
+        w_src[j] = (const char*)(p.W + (size_t)gn * p.ldw + (size_t)kt0 * BK) + chunk * 16;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes inside a tile): row*128 + ((chunk ^ (row&7)) << 4)
+    const int frow = lane & 15, fch = lane >> 4;
+    int a_off[4], w_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ra = wm * 64 + t * 16 + frow;
+        const int rw = wn * 64 + t * 16 + frow;
+        a_off[t] = ra * 128 + ((fch ^ (ra & 7)) << 4);
+        w_off[t] = rw * 128 + ((fch ^ (rw & 7)) << 4);
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * (2 * TILE_BYTES);
+        const size_t koff = (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(a_src[j] + koff, base + (wave * 4 + j) * 1024);
+            glds16(w_src[j] + koff, base + TILE_BYTES + (wave * 4 + j) * 1024);
+        }
+    };
+
+    if (nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // emits s_waitcnt vmcnt(0): tile kt has landed for every wave; buffer (kt+1)&1 is free
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* ab = smem + (kt & 1) * (2 * TILE_BYTES);
+        const char* wb = ab + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const bf16x8*)(ab + (a_off[t] ^ (kk << 6)));
+                wf[t] = *(const bf16x8*)(wb + (w_off[t] ^ (kk << 6)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const clibd_gemm_epilogue& ep = p.ep;
+    // ---- LoRA rank-8 update as one extra (zero-padded) k-step: lanes with k-chunk 0 carry U[m,0:8] / V[n,0:8]
+    if (ep.rank_u != nullptr && split == 0) {
+        bf16x8 uf[4], vf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uf[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            vf[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (fch == 0) {
+                const int gm = min(m0 + wm * 64 + t * 16 + frow, p.M - 1);
+                const int gn = min(n0 + w_row_perm(wn * 64 + t * 16 + frow), p.N - 1);
+                uf[t] = *(const bf16x8*)((const unsigned short*)ep.rank_u + (size_t)gm * ep.ld_rank_u);
+                vf[t] = *(const bf16x8*)((const unsigned short*)ep.rank_v + (size_t)gn * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[j], uf[i], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: lane owns row m = m0 + 64wm + 16i + (lane&15), columns nb .. nb+15 (e = 4*j + reg)
+    const int nb = n0 + wn * 64 + 16 * fch;
+    if (nb >= p.N) return;  // N % 16 == 0, so a lane's 16 columns are all in or all out
+    float bias[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias[e] = 0.f;
+    if (ep.bias != nullptr && split == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *(const f32x4*)(ep.bias + nb + 4 * q);
+            bias[4 * q + 0] = b4[0]; bias[4 * q + 1] = b4[1]; bias[4 * q + 2] = b4[2]; bias[4 * q + 3] = b4[3];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + frow;
+        if (m >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
+
+        if (ep.split_k > 1) {
+            float* o = ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) atomicAdd(o + e, v[e]);
+            continue;
+        }
+        if (ep.out_pre_bf16 != nullptr) {
+            uint4 lo, hi;
+            lo.x = pack2bf(v[0], v[1]);   lo.y = pack2bf(v[2], v[3]);   lo.z = pack2bf(v[4], v[5]);   lo.w = pack2bf(v[6], v[7]);
+            hi.x = pack2bf(v[8], v[9]);   hi.y = pack2bf(v[10], v[11]); hi.z = pack2bf(v[12], v[13]); hi.w = pack2bf(v[14], v[15]);
+            uint4* o = (uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb);
+            o[0] = lo; o[1] = hi;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = bfround(v[e]);
+        }
+        if (ep.act == CLIBD_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+        } else if (ep.act == CLIBD_ACT_GELU_GRAD) {
+            const uint4* ax = (const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+            const uint4 x0 = ax[0], x1 = ax[1];
+            const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[2 * e] *= gelu_grad_f(bf2f((unsigned short)(xs[e] & 0xffffu)));
+                v[2 * e + 1] *= gelu_grad_f(bf2f((unsigned short)(xs[e] >> 16)));
+            }
+        }
+        if (ep.residual_f32 != nullptr) {
+            const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 r4 = rs[q];
+                v[4 * q + 0] += r4[0]; v[4 * q + 1] += r4[1]; v[4 * q + 2] += r4[2]; v[4 * q + 3] += r4[3];
+            }
+        }
+        if (ep.out_f32 != nullptr) {
+            f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
+        if (ep.out_bf16 != nullptr) {
+            uint4 lo, hi;
+            lo.x = pack2bf(v[0], v[1]);   lo.y = pack2bf(v[2], v[3]);   lo.z = pack2bf(v[4], v[5]);   lo.w = pack2bf(v[6], v[7]);
+            hi.x = pack2bf(v[8], v[9]);   hi.y = pack2bf(v[10], v[11]); hi.z = pack2bf(v[12], v[13]); hi.w = pack2bf(v[14], v[15]);
+            uint4* o = (uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb);
+            o[0] = lo; o[1] = hi;
+        }
+    }
+}
+
+// ---- bf16 transpose with zero padding -------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* in, int ld_in, int R, int C,
+                                                             unsigned short* out, int ld_out) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;   // out row = c, out col = r
+        if (c < C && r < ld_out) out[(size_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* in, unsigned short* out, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        const f32x4 v = *(const f32x4*)(in + i);
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2*)(out + i) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t j = n & ~(size_t)3; j < n; ++j) out[j] = f2bf(in[j]);
+}
+
+__global__ __launch_bounds__(256) void cast_transpose_f32_bf16_kernel(const float* in, int R, int C,
+                                                                      unsigned short* out) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * R + r] = f2bf(tile[tx][i]);
+    }
+}
+
+}  // namespace clibd
+
+using namespace clibd;
+
+extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                                  const clibd_gemm_epilogue* ep, void* stream) {
+    if (!A || !W || !ep) return set_error(CLIBD_EINVAL, "gemm: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0) return set_error(CLIBD_EINVAL, "gemm: non-positive shape");
+    if (K % BK != 0) return set_error(CLIBD_EINVAL, "gemm: K must be a multiple of 64");
+    if (N % 16 != 0) return set_error(CLIBD_EINVAL, "gemm: N must be a multiple of 16");
+    if (lda % 8 != 0 || ldw % 8 != 0 || lda < K || ldw < K) return set_error(CLIBD_EINVAL, "gemm: bad lda/ldw");
+    if (!aligned16(A) || !aligned16(W)) return set_error(CLIBD_EINVAL, "gemm: operands must be 16-byte aligned");
+    if (!ep->out_bf16 && !ep->out_f32 && !ep->out_pre_bf16) return set_error(CLIBD_EINVAL, "gemm: no output");
+    if ((ep->rank_u == nullptr) != (ep->rank_v == nullptr)) return set_error(CLIBD_EINVAL, "gemm: rank_u/rank_v");
+    if (ep->rank_u && (ep->ld_rank_u < 8 || ep->ld_rank_u % 8)) return set_error(CLIBD_EINVAL, "gemm: ld_rank_u");
+    if (ep->act == CLIBD_ACT_GELU_GRAD && (!ep->aux_bf16 || ep->ld_aux % 8 || ep->ld_aux < N))
+        return set_error(CLIBD_EINVAL, "gemm: GELU_GRAD needs aux_bf16 with ld_aux >= N, % 8");
+    if (ep->act < 0 || ep->act > 2) return set_error(CLIBD_EINVAL, "gemm: bad act");
+    if (ep->residual_f32 && (ep->ld_res % 4 || ep->ld_res < N)) return set_error(CLIBD_EINVAL, "gemm: ld_res");
+    if (ep->out_pre_bf16 && (ep->ld_pre % 8 || ep->ld_pre < N)) return set_error(CLIBD_EINVAL, "gemm: ld_pre");
+    if (ep->out_bf16 && (ep->ld_out_bf16 % 8 || ep->ld_out_bf16 < N)) return set_error(CLIBD_EINVAL, "gemm: ld_out_bf16");
+    if (ep->out_f32 && (ep->ld_out_f32 % 4 || ep->ld_out_f32 < N)) return set_error(CLIBD_EINVAL, "gemm: ld_out_f32");
+    const int split = ep->split_k < 1 ? 1 : ep->split_k;
+    if (split > 1 && (ep->out_bf16 || ep->out_pre_bf16 || ep->act != CLIBD_ACT_NONE || ep->residual_f32 || !ep->out_f32))
+        return set_error(CLIBD_EINVAL, "gemm: split_k > 1 supports only a plain fp32 accumulate output");
+    const void* ptrs[] = {ep->bias, ep->rank_u, ep->rank_v, ep->aux_bf16, ep->residual_f32, ep->out_pre_bf16,
+                          ep->out_bf16, ep->out_f32};
+    for (const void* q : ptrs)
+        if (q && !aligned16(q)) return set_error(CLIBD_EINVAL, "gemm: epilogue pointers must be 16-byte aligned");
+
+    GemmParams p;
+    p.A = (const unsigned short*)A; p.W = (const unsigned short*)W;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
+    p.tiles_m = (M + BM - 1) / BM;
+    p.tiles_n = (N + BN - 1) / BN;
+    const int ktiles = K / BK;
+    p.ktiles_per_split = (ktiles + split - 1) / split;
+    p.ep = *ep;
+    p.ep.split_k = split;
+    const long long nblocks = (long long)p.tiles_m * p.tiles_n * split;
+    if (nblocks > 0x7fffffffLL) return set_error(CLIBD_EINVAL, "gemm: grid too large");
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   4 * TILE_BYTES) == hipSuccess;
+    }();
+    (void)attr_ok;
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)nblocks), dim3(GEMM_THREADS), 4 * TILE_BYTES,
+                       (hipStream_t)stream, p);
+    return check_launch("gemm_bf16_nt");
+}
+
+extern "C" int clibd_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0 || ld_in < C || ld_out < R) return set_error(CLIBD_EINVAL, "transpose: bad args");
+    dim3 grid((C + 63) / 64, (ld_out + 63) / 64);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in,
+                       ld_in, R, C, (unsigned short*)out, ld_out);
+    return check_launch("transpose_bf16");
+}
+
+extern "C" int clibd_cast_f32_to_bf16(const float* in, void* out, size_t n, void* stream) {
+    if (!in || !out) return set_error(CLIBD_EINVAL, "cast: null pointer");
+    if (n == 0) return CLIBD_OK;
+    if (!aligned16(in) || ((uintptr_t)out & 7)) return set_error(CLIBD_EINVAL, "cast: alignment");
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in,
+                       (unsigned short*)out, n);
+    return check_launch("cast_f32_to_bf16");
+}
+
+extern "C" int clibd_cast_transpose_f32_to_bf16(const float* in, int R, int C, void* out, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0) return set_error(CLIBD_EINVAL, "cast_transpose: bad args");
+    dim3 grid((C + 63) / 64, (R + 63) / 64);
+    hipLaunchKernelGGL(cast_transpose_f32_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, R, C,
+                       (unsigned short*)out);
+    return check_launch("cast_transpose_f32_to_bf16");
+}

@@ -1,0 +1,267 @@
+// LayerNorm forward / backward for gfx950: one wave64 per row, fp32 statistics, 16-byte vector I/O.
+// HBM-bound: forward reads 4H bytes/row and writes 2H (bf16) [+4H fp32]; the optional LoRA down-projection
+// t = bf16(y) · A_cat^T (8 outputs per row) rides along in registers so the adapter never re-reads y.
+#include "common.h"
+#include "../../include/clibd_hip.h"
+#include "host_util.h"
+
+namespace clibd {
+
+constexpr int LN_MAX_CHUNKS = 4;  // H <= 1024: each lane owns up to 4 float4 chunks (chunk j = cols 4*(lane + 64 j))
+
+// Reduce 8 per-lane partials across the wave with 10 shuffles (butterfly that halves the live values at each
+// of the first three steps).  On return every lane holds the total of value index ((lane>>3)&7).
+__device__ __forceinline__ float wave_reduce8(float v[8], int lane) {
+    float w4[4], w2[2], w1;
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b5 ? v[i + 4] : v[i];
+        const float send = b5 ? v[i] : v[i + 4];
+        w4[i] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b4 ? w4[i + 2] : w4[i];
+        const float send = b4 ? w4[i] : w4[i + 2];
+        w2[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    {
+        const float keep = b3 ? w2[1] : w2[0];
+        const float send = b3 ? w2[0] : w2[1];
+        w1 = keep + __shfl_xor(send, 8, 64);
+    }
+    w1 += __shfl_xor(w1, 4, 64);
+    w1 += __shfl_xor(w1, 2, 64);
+    w1 += __shfl_xor(w1, 1, 64);
+    return w1;  // index = 4*b5 + 2*b4 + b3
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int M, int H,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            unsigned short* __restrict__ y_bf16,
+                                                            float* __restrict__ y_f32, float* __restrict__ stats,
+                                                            const unsigned short* __restrict__ lora_a,
+                                                            unsigned short* __restrict__ t_bf16) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int nchunks = H >> 8;  // full 64-lane chunk groups: H/256 (H % 256 may leave a partial group)
+    (void)nchunks;
+    f32x4 g[NCH], b[NCH];
+    bool act[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        act[j] = c < H;
+        g[j] = act[j] ? *(const f32x4*)(gamma + c) : (f32x4){0, 0, 0, 0};
+        b[j] = act[j] ? *(const f32x4*)(beta + c) : (f32x4){0, 0, 0, 0};
+    }
+    // LoRA A_cat[8,H] bf16: this lane's columns, packed 2 bf16 per dword: la[r][j] = 4 values
+    uint2 la[8][NCH];
+    const bool lora = (lora_a != nullptr);
+    if (lora) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c = 4 * (lane + 64 * j);
+                la[r][j] = act[j] ? *(const uint2*)(lora_a + (size_t)r * H + c) : make_uint2(0, 0);
+            }
+    }
+    const float invH = 1.0f / (float)H;
+    for (int row = wave_in_grid; row < M; row += nwaves) {
+        const float* xr = x + (size_t)row * H;
+        f32x4 v[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            v[j] = act[j] ? *(const f32x4*)(xr + 4 * (lane + 64 * j)) : (f32x4){0, 0, 0, 0};
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mean = wave_sum(s) * invH;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (act[j]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[j][e] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float var = wave_sum(q) * invH;
+        const float rstd = rsqrtf(var + eps);
+        if (stats != nullptr && lane == 0) {
+            stats[2 * (size_t)row] = mean;
+            stats[2 * (size_t)row + 1] = rstd;
+        }
+        float tp[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tp[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (!act[j]) continue;
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mean) * rstd * g[j][e] + b[j][e];
+            const int c = 4 * (lane + 64 * j);
+            if (y_f32 != nullptr) *(f32x4*)(y_f32 + (size_t)row * H + c) = y;
+            uint2 pk;
+            pk.x = pack2bf(y[0], y[1]);
+            pk.y = pack2bf(y[2], y[3]);
+            if (y_bf16 != nullptr) *(uint2*)(y_bf16 + (size_t)row * H + c) = pk;
+            if (lora) {
+                const float y0 = bf2f((unsigned short)(pk.x & 0xffff)), y1 = bf2f((unsigned short)(pk.x >> 16));
+                const float y2 = bf2f((unsigned short)(pk.y & 0xffff)), y3 = bf2f((unsigned short)(pk.y >> 16));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint2 a = la[r][j];
+                    tp[r] += y0 * bf2f((unsigned short)(a.x & 0xffff)) + y1 * bf2f((unsigned short)(a.x >> 16)) +
+                             y2 * bf2f((unsigned short)(a.y & 0xffff)) + y3 * bf2f((unsigned short)(a.y >> 16));
+                }
+            }
+        }
+        if (lora) {
+            const float tv = wave_reduce8(tp, lane);
+            if ((lane & 7) == 0) t_bf16[(size_t)row * 8 + (lane >> 3)] = f2bf(tv);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma ;  optional + dres
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy_bf16,
+                                                            const float* __restrict__ dy_f32,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, int M, int H,
+                                                            const float* __restrict__ dres,
+                                                            float* __restrict__ dx_f32,
+                                                            unsigned short* __restrict__ dx_bf16) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    f32x4 g[NCH];
+    bool act[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        act[j] = c < H;
+        g[j] = act[j] ? *(const f32x4*)(gamma + c) : (f32x4){0, 0, 0, 0};
+    }
+    const float invH = 1.0f / (float)H;
+    for (int row = wave_in_grid; row < M; row += nwaves) {
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+        f32x4 gy[NCH], xh[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            gy[j] = (f32x4){0, 0, 0, 0};
+            xh[j] = (f32x4){0, 0, 0, 0};
+            if (!act[j]) continue;
+            const int c = 4 * (lane + 64 * j);
+            f32x4 d;
+            if (dy_f32 != nullptr) {
+                d = *(const f32x4*)(dy_f32 + (size_t)row * H + c);
+            } else {
+                const uint2 pk = *(const uint2*)(dy_bf16 + (size_t)row * H + c);
+                d[0] = bf2f((unsigned short)(pk.x & 0xffff)); d[1] = bf2f((unsigned short)(pk.x >> 16));
+                d[2] = bf2f((unsigned short)(pk.y & 0xffff)); d[3] = bf2f((unsigned short)(pk.y >> 16));
+            }
+            const f32x4 xv = *(const f32x4*)(x + (size_t)row * H + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gy[j][e] = d[e] * g[j][e];
+                xh[j][e] = (xv[e] - mean) * rstd;
+                s1 += gy[j][e];
+                s2 += gy[j][e] * xh[j][e];
+            }
+        }
+        const float m1 = wave_sum(s1) * invH;
+        const float m2 = wave_sum(s2) * invH;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (!act[j]) continue;
+            const int c = 4 * (lane + 64 * j);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[j][e] - m1 - xh[j][e] * m2);
+            if (dres != nullptr) {
+                const f32x4 r = *(const f32x4*)(dres + (size_t)row * H + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += r[e];
+            }
+            if (dx_f32 != nullptr) *(f32x4*)(dx_f32 + (size_t)row * H + c) = o;
+            if (dx_bf16 != nullptr) {
+                uint2 pk;
+                pk.x = pack2bf(o[0], o[1]);
+                pk.y = pack2bf(o[2], o[3]);
+                *(uint2*)(dx_bf16 + (size_t)row * H + c) = pk;
+            }
+        }
+    }
+}
+
+static inline int ln_grid(int M) {
+    int blocks = (M + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    return blocks < 1 ? 1 : blocks;
+}
+
+}  // namespace clibd
+
+using namespace clibd;
+
+extern "C" int clibd_layernorm_fwd(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                                   void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16,
+                                   void* t_bf16, void* stream) {
+    if (!x || !gamma || !beta) return set_error(CLIBD_EINVAL, "layernorm_fwd: null pointer");
+    if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_fwd: H must be a multiple of 64, <= 1024");
+    if (!y_bf16 && !y_f32) return set_error(CLIBD_EINVAL, "layernorm_fwd: no output");
+    if ((lora_a_bf16 == nullptr) != (t_bf16 == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_fwd: lora_a/t must come together");
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (y_f32 && !aligned16(y_f32)) ||
+        (y_bf16 && !aligned16(y_bf16)) || (lora_a_bf16 && !aligned16(lora_a_bf16)))
+        return set_error(CLIBD_EINVAL, "layernorm_fwd: alignment");
+    const int nch = (H + 255) / 256;
+    dim3 grid(ln_grid(M)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(N)                                                                                              \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<N>, grid, block, 0, st, x, M, H, gamma, beta, eps,                 \
+                       (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)lora_a_bf16,              \
+                       (unsigned short*)t_bf16)
+    switch (nch) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    return check_launch("layernorm_fwd");
+}
+
+extern "C" int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
+                                   const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
+                                   void* dx_bf16, void* stream) {
+    if (!x || !stats || !gamma) return set_error(CLIBD_EINVAL, "layernorm_bwd: null pointer");
+    if ((dy_bf16 == nullptr) == (dy_f32 == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: exactly one of dy_bf16/dy_f32");
+    if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_bwd: H must be a multiple of 64, <= 1024");
+    if (!dx_f32 && !dx_bf16) return set_error(CLIBD_EINVAL, "layernorm_bwd: no output");
+    const int nch = (H + 255) / 256;
+    dim3 grid(ln_grid(M)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(N)                                                                                              \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
+                       stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16)
+    switch (nch) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    return check_launch("layernorm_bwd");
+}

@@ -1,0 +1,170 @@
+// LoRA (rank 4 on q and v) helper kernels for gfx950.
+//
+// Forward/backward rank-8 updates themselves ride inside the GEMM (one extra MFMA k-step, gemm.hip); the
+// down-projection t = x·A^T rides inside LayerNorm (layernorm.hip).  What is left here:
+//   * lora_pack:  fp32 adapter parameters -> the bf16 operand images those kernels consume (tiny, per step);
+//   * lora_wgrad: dA, dB — contractions over the token dimension M; HBM-bound (reads dq, dv, x once).
+//     dt = dq·B_q | dv·B_v is produced by the MFMA GEMM against the packed [16, 3H] image (w_dt).
+#include "common.h"
+#include "../../include/clibd_hip.h"
+#include "host_util.h"
+
+namespace clibd {
+
+// a_q,a_v: [4,H] (nn.Linear(H,4).weight); b_q,b_v: [H,4] (nn.Linear(4,H).weight)
+__global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict__ a_q, const float* __restrict__ a_v,
+                                                        const float* __restrict__ b_q, const float* __restrict__ b_v, int H,
+                                                        unsigned short* __restrict__ v_fwd,   // [3H, 8]
+                                                        unsigned short* __restrict__ v_bwd,   // [H, 8]
+                                                        unsigned short* __restrict__ a_cat,   // [8, H]
+                                                        unsigned short* __restrict__ w_dt) {  // [16, 3H]
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 3H-1
+    if (n >= 3 * H) return;
+    const int seg = n / H, c = n - seg * H;
+    unsigned short vf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (seg == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vf[r] = f2bf(b_q[(size_t)c * 4 + r]);
+    } else if (seg == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vf[4 + r] = f2bf(b_v[(size_t)c * 4 + r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v_fwd[(size_t)n * 8 + r] = vf[r];
+    // w_dt[r, n]: rows 0-3 = B_q[:, r]^T over the q segment, rows 4-7 = B_v[:, r-4]^T over the v segment, rest 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w_dt[(size_t)r * 3 * H + n] = (r < 8) ? vf[r] : (unsigned short)0;
+    if (seg == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned short aq = f2bf(a_q[(size_t)r * H + c]), av = f2bf(a_v[(size_t)r * H + c]);
+            v_bwd[(size_t)c * 8 + r] = aq;
+            v_bwd[(size_t)c * 8 + 4 + r] = av;
+            a_cat[(size_t)r * H + c] = aq;
+            a_cat[(size_t)(4 + r) * H + c] = av;
+        }
+    }
+}
+
+// cross-group (4 row groups) reduction of one 4x4 accumulator family through LDS, then one atomic per value.
+// IS_A: output layout dA[r, k] (k = c + e) else dB[n, r] (n = c + e).
+template <bool IS_A>
+__device__ __forceinline__ void lw_reduce_emit(float (&acc)[4][4], float* red, int grp, int ct, int cthreads,
+                                               float* __restrict__ out, int c, int H) {
+    if (grp > 0) {
+        float* dst = red + ((size_t)(grp - 1) * cthreads + ct) * 16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *(f32x4*)(dst + 4 * e) = (f32x4){acc[e][0], acc[e][1], acc[e][2], acc[e][3]};
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int gsrc = 0; gsrc < 3; ++gsrc) {
+            const float* src = red + ((size_t)gsrc * cthreads + ct) * 16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 v = *(const f32x4*)(src + 4 * e);
+                acc[e][0] += v[0]; acc[e][1] += v[1]; acc[e][2] += v[2]; acc[e][3] += v[3];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (IS_A) atomicAdd(out + (size_t)r * H + c + e, acc[e][r]);
+                else atomicAdd(out + (size_t)(c + e) * 4 + r, acc[e][r]);
+            }
+    }
+    __syncthreads();
+}
+
+// dB_q[n,r] += sum_m dq[m,n] t[m,r]      dB_v[n,r] += sum_m dv[m,n] t[m,4+r]
+// dA_q[r,k] += sum_m dt[m,r] x[m,k]      dA_v[r,k] += sum_m dt[m,4+r] x[m,k]
+// block = 4 row-groups x (H/4) column threads; a thread owns 4 adjacent columns; a block owns ROWS_PER_BLOCK rows.
+constexpr int LW_ROWS = 256;
+
+__global__ __launch_bounds__(1024) void lora_wgrad_kernel(const unsigned short* __restrict__ dqkv, int ld,
+                                                          const unsigned short* __restrict__ x,
+                                                          const unsigned short* __restrict__ t,
+                                                          const unsigned short* __restrict__ dt, int ld_dt, int M, int H,
+                                                          float* __restrict__ dA_q, float* __restrict__ dA_v,
+                                                          float* __restrict__ dB_q, float* __restrict__ dB_v) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [3][H/4][16]
+    const int cthreads = H >> 2;
+    const int grp = threadIdx.x / cthreads;
+    const int ct = threadIdx.x - grp * cthreads;
+    const int c = ct * 4;
+    const int m0 = blockIdx.x * LW_ROWS;
+    const int m1 = min(m0 + LW_ROWS, M);
+    float accBq[4][4], accBv[4][4], accAq[4][4], accAv[4][4];  // [col e][r]
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accBq[e][r] = 0.f; accBv[e][r] = 0.f; accAq[e][r] = 0.f; accAv[e][r] = 0.f; }
+
+    for (int m = m0 + grp; m < m1; m += 4) {
+        const uint2 dq2 = *(const uint2*)(dqkv + (size_t)m * ld + c);
+        const uint2 dv2 = *(const uint2*)(dqkv + (size_t)m * ld + 2 * H + c);
+        const uint2 x2 = *(const uint2*)(x + (size_t)m * H + c);
+        const uint4 t4 = *(const uint4*)(t + (size_t)m * 8);
+        const uint4 d4 = *(const uint4*)(dt + (size_t)m * ld_dt);
+        const float dq[4] = {bf2f((unsigned short)(dq2.x & 0xffff)), bf2f((unsigned short)(dq2.x >> 16)),
+                             bf2f((unsigned short)(dq2.y & 0xffff)), bf2f((unsigned short)(dq2.y >> 16))};
+        const float dv[4] = {bf2f((unsigned short)(dv2.x & 0xffff)), bf2f((unsigned short)(dv2.x >> 16)),
+                             bf2f((unsigned short)(dv2.y & 0xffff)), bf2f((unsigned short)(dv2.y >> 16))};
+        const float xv[4] = {bf2f((unsigned short)(x2.x & 0xffff)), bf2f((unsigned short)(x2.x >> 16)),
+                             bf2f((unsigned short)(x2.y & 0xffff)), bf2f((unsigned short)(x2.y >> 16))};
+        const float tq[4] = {bf2f((unsigned short)(t4.x & 0xffff)), bf2f((unsigned short)(t4.x >> 16)),
+                             bf2f((unsigned short)(t4.y & 0xffff)), bf2f((unsigned short)(t4.y >> 16))};
+        const float tv[4] = {bf2f((unsigned short)(t4.z & 0xffff)), bf2f((unsigned short)(t4.z >> 16)),
+                             bf2f((unsigned short)(t4.w & 0xffff)), bf2f((unsigned short)(t4.w >> 16))};
+        const float gq[4] = {bf2f((unsigned short)(d4.x & 0xffff)), bf2f((unsigned short)(d4.x >> 16)),
+                             bf2f((unsigned short)(d4.y & 0xffff)), bf2f((unsigned short)(d4.y >> 16))};
+        const float gv[4] = {bf2f((unsigned short)(d4.z & 0xffff)), bf2f((unsigned short)(d4.z >> 16)),
+                             bf2f((unsigned short)(d4.w & 0xffff)), bf2f((unsigned short)(d4.w >> 16))};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accBq[e][r] += dq[e] * tq[r];
+                accBv[e][r] += dv[e] * tv[r];
+                accAq[e][r] += gq[r] * xv[e];
+                accAv[e][r] += gv[r] * xv[e];
+            }
+    }
+    lw_reduce_emit<false>(accBq, red, grp, ct, cthreads, dB_q, c, H);
+    lw_reduce_emit<false>(accBv, red, grp, ct, cthreads, dB_v, c, H);
+    lw_reduce_emit<true>(accAq, red, grp, ct, cthreads, dA_q, c, H);
+    lw_reduce_emit<true>(accAv, red, grp, ct, cthreads, dA_v, c, H);
+}
+
+}  // namespace clibd
+
+using namespace clibd;
+
+extern "C" int clibd_lora_pack(const float* a_q, const float* a_v, const float* b_q, const float* b_v, int H,
+                               void* v_fwd_bf16, void* v_bwd_bf16, void* a_cat_bf16, void* w_dt_bf16, void* stream) {
+    if (!a_q || !a_v || !b_q || !b_v || !v_fwd_bf16 || !v_bwd_bf16 || !a_cat_bf16 || !w_dt_bf16)
+        return set_error(CLIBD_EINVAL, "lora_pack: null pointer");
+    if (H <= 0 || H % 64 != 0) return set_error(CLIBD_EINVAL, "lora_pack: H must be a multiple of 64");
+    hipLaunchKernelGGL(lora_pack_kernel, dim3((3 * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, a_q, a_v, b_q, b_v, H,
+                       (unsigned short*)v_fwd_bf16, (unsigned short*)v_bwd_bf16, (unsigned short*)a_cat_bf16,
+                       (unsigned short*)w_dt_bf16);
+    return check_launch("lora_pack");
+}
+
+extern "C" int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* dt_bf16,
+                                int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v, void* stream) {
+    if (!dqkv || !x_bf16 || !t_bf16 || !dt_bf16 || !dA_q || !dA_v || !dB_q || !dB_v)
+        return set_error(CLIBD_EINVAL, "lora_wgrad: null pointer");
+    if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "lora_wgrad: H must be a multiple of 64, <= 1024");
+    if (ld_dqkv < 3 * H || ld_dqkv % 8 || ld_dt < 8 || ld_dt % 8) return set_error(CLIBD_EINVAL, "lora_wgrad: bad leading dimension");
+    if (!aligned16(dqkv) || !aligned16(x_bf16) || !aligned16(t_bf16) || !aligned16(dt_bf16))
+        return set_error(CLIBD_EINVAL, "lora_wgrad: alignment");
+    const int blocks = (M + LW_ROWS - 1) / LW_ROWS;
+    const size_t lds = (size_t)3 * (H / 4) * 16 * sizeof(float);
+    hipLaunchKernelGGL(lora_wgrad_kernel, dim3(blocks), dim3(H), lds, (hipStream_t)stream, (const unsigned short*)dqkv, ld_dqkv,
+                       (const unsigned short*)x_bf16, (const unsigned short*)t_bf16, (const unsigned short*)dt_bf16, ld_dt, M, H,
+                       dA_q, dA_v, dB_q, dB_v);
+    return check_launch("lora_wgrad");
+}

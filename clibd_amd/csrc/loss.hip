@@ -1,0 +1,205 @@
+// K9: all-pairs similarity + soft-target (label-equality) cross-entropy, row-block form, for gfx950.
+//
+//   S[i,j] = scale * <x_i, y_j>          x: [Nx,D] rows owned by this rank (global row offset row0), y: [N,D] all rows
+//   T[i,j] = (labels[row0+i] == labels[j])                    (never materialised)
+//   loss   = sum_i ( LSE_j(S[i,:]) * sum_j T[i,j]  -  sum_j T[i,j] S[i,j] )      == sum_i CE(S[i,:], T[i,:])
+//
+// The similarity runs on the bf16 MFMA GEMM with the split-bf16 trick: x = hi + lo, y = hi + lo (both bf16),
+// S ~ hi·hi + hi·lo + lo·hi, expressed as ONE NT GEMM with K = 3D over the images [hi|hi|lo] and [hi|lo|hi]
+// (error ~2^-16 relative instead of 2^-8: the reference evaluates this product in fp32, loss_func.py:189-190).
+// Row statistics use one wave64 per row with shuffle reductions.  Backward materialises the bf16 coefficient
+// matrix G = w * (tsum_i * softmax(S)_ij - T_ij) once and feeds it to the same GEMM for dX = scale·G·Y and
+// dY = scale·G^T·X.
+#include "common.h"
+#include "../../include/clibd_hip.h"
+#include "host_util.h"
+
+namespace clibd {
+
+// img3[r, 0:D] = hi, img3[r, D:2D] = MID, img3[r, 2D:3D] = LAST  with (MID,LAST) = (hi,lo) for x, (lo,hi) for y
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ in, int R, int D, int x_side,
+                                                     unsigned short* __restrict__ out) {
+    const size_t total = (size_t)R * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / D;
+        const int c = (int)(i - r * D);
+        const float v = in[i];
+        const unsigned short hi = f2bf(v);
+        const unsigned short lo = f2bf(v - bf2f(hi));
+        unsigned short* o = out + r * 3 * (size_t)D;
+        o[c] = hi;
+        o[D + c] = x_side ? hi : lo;
+        o[2 * D + c] = x_side ? lo : hi;
+    }
+}
+
+struct RowStat {
+    float m, s, tsum, tdot;
+};
+
+// one wave per row: online log-sum-exp + target sums
+__global__ __launch_bounds__(256) void softce_rows_fwd_kernel(const float* __restrict__ S, int ldS, int Nx, int N,
+                                                              const int64_t* __restrict__ labels, int row0, float scale,
+                                                              float* __restrict__ lse, float* __restrict__ tsum_out,
+                                                              float* __restrict__ loss_sum) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Nx) return;
+    const int64_t lab = labels[row0 + row];
+    const float* sr = S + (size_t)row * ldS;
+    float m = -3.0e38f, s = 0.f, ts = 0.f, td = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float v = sr[j] * scale;
+        if (v > m) {
+            s = s * __expf(m - v) + 1.0f;
+            m = v;
+        } else {
+            s += __expf(v - m);
+        }
+        if (labels[j] == lab) {
+            ts += 1.0f;
+            td += v;
+        }
+    }
+    const float mw = wave_max(m);
+    s = wave_sum(s * __expf(m - mw));
+    ts = wave_sum(ts);
+    td = wave_sum(td);
+    if (lane == 0) {
+        const float l = mw + __logf(s);
+        lse[row] = l;
+        tsum_out[row] = ts;
+        atomicAdd(loss_sum, l * ts - td);
+    }
+}
+
+// g_ij = w * (tsum_i * exp(scale*R_ij - lse_i) - T_ij) with R = raw similarities;
+// G[i,j] = bf16(scale * g_ij) (zero padded to ldG) feeds the dX/dY GEMMs;  dscale += sum_ij g_ij * R_ij
+__global__ __launch_bounds__(256) void softce_rows_bwd_kernel(const float* __restrict__ S, int ldS, int Nx, int N,
+                                                              const int64_t* __restrict__ labels, int row0,
+                                                              const float* __restrict__ lse, const float* __restrict__ tsum,
+                                                              float w, float scale, unsigned short* __restrict__ G,
+                                                              int ldG, float* __restrict__ dscale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Nx) return;
+    const int64_t lab = labels[row0 + row];
+    const float l = lse[row], ts = tsum[row];
+    const float* sr = S + (size_t)row * ldS;
+    unsigned short* gr = G + (size_t)row * ldG;
+    float ds = 0.f;
+    for (int j = lane; j < ldG; j += 64) {
+        float g = 0.f;
+        if (j < N) {
+            const float v = sr[j];
+            g = w * (ts * __expf(v * scale - l) - (labels[j] == lab ? 1.0f : 0.0f));
+            ds += g * v;
+        }
+        gr[j] = f2bf(g * scale);
+    }
+    ds = wave_sum(ds);
+    if (lane == 0 && dscale != nullptr) atomicAdd(dscale, ds);
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int pad64(int v) { return (v + 63) / 64 * 64; }
+
+struct LossWs {
+    unsigned short *x3, *y3;   // [Nx,3D], [N,3D]
+    float *S, *lse, *tsum;     // [Nx,N], [Nx], [Nx]
+    unsigned short *G, *GT;    // [Nx,Np], [N,Nxp]
+    unsigned short *xT, *yT;   // [D,Nxp], [D,Np]
+    size_t total;
+};
+
+static LossWs carve(void* base, int Nx, int N, int D) {
+    LossWs w;
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* q = p ? p + off : nullptr;
+        off += align_up(bytes, 256);
+        return q;
+    };
+    const int Np = pad64(N), Nxp = pad64(Nx);
+    w.x3 = (unsigned short*)take((size_t)Nx * 3 * D * 2);
+    w.y3 = (unsigned short*)take((size_t)N * 3 * D * 2);
+    w.S = (float*)take((size_t)Nx * N * 4);
+    w.lse = (float*)take((size_t)Nx * 4);
+    w.tsum = (float*)take((size_t)Nx * 4);
+    w.G = (unsigned short*)take((size_t)Nx * Np * 2);
+    w.GT = (unsigned short*)take((size_t)N * Nxp * 2);
+    w.xT = (unsigned short*)take((size_t)D * Nxp * 2);
+    w.yT = (unsigned short*)take((size_t)D * Np * 2);
+    w.total = off;
+    return w;
+}
+
+static int loss_check(const float* x, const float* y, const int64_t* labels, int Nx, int N, int D, int row0) {
+    if (!x || !y || !labels) return set_error(CLIBD_EINVAL, "softce: null pointer");
+    if (Nx <= 0 || N <= 0 || D <= 0) return set_error(CLIBD_EINVAL, "softce: non-positive shape");
+    if (D % 64 != 0) return set_error(CLIBD_EINVAL, "softce: D must be a multiple of 64");
+    if (N % 4 != 0) return set_error(CLIBD_EINVAL, "softce: N must be a multiple of 4");
+    if (row0 < 0 || row0 + Nx > N) return set_error(CLIBD_EINVAL, "softce: row block outside the global batch");
+    return 0;
+}
+
+}  // namespace clibd
+
+using namespace clibd;
+
+extern "C" size_t clibd_softce_workspace_bytes(int Nx, int N, int D) {
+    if (Nx <= 0 || N <= 0 || D <= 0) return 0;
+    return carve(nullptr, Nx, N, D).total;
+}
+
+extern "C" int clibd_softce_rows_fwd(const float* x, const float* y, const int64_t* labels, int Nx, int N, int D, int row0,
+                                     float scale, float* loss_sum, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = loss_check(x, y, labels, Nx, N, D, row0)) return e;
+    if (!loss_sum || !workspace) return set_error(CLIBD_EINVAL, "softce_fwd: null pointer");
+    if (!aligned16(workspace)) return set_error(CLIBD_EINVAL, "softce_fwd: workspace must be 16-byte aligned");
+    const LossWs w = carve(workspace, Nx, N, D);
+    if (workspace_bytes < w.total) return set_error(CLIBD_EINVAL, "softce_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(split3_kernel, dim3(1024), dim3(256), 0, st, x, Nx, D, 1, w.x3);
+    hipLaunchKernelGGL(split3_kernel, dim3(1024), dim3(256), 0, st, y, N, D, 0, w.y3);
+    if (int e = check_launch("softce split")) return e;
+    clibd_gemm_epilogue ep = {};
+    ep.out_f32 = w.S;  // raw similarities <x_i, y_j>
+    ep.ld_out_f32 = N;
+    ep.split_k = 1;
+    if (int e = clibd_gemm_bf16_nt(w.x3, 3 * D, w.y3, 3 * D, Nx, N, 3 * D, &ep, stream)) return e;
+    hipLaunchKernelGGL(softce_rows_fwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, N, Nx, N, labels, row0, scale,
+                       w.lse, w.tsum, loss_sum);
+    return check_launch("softce_rows_fwd");
+}
+
+// Must follow clibd_softce_rows_fwd on the same workspace (reuses its similarity matrix and row statistics).
+extern "C" int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D, int row0, float scale, float weight,
+                                     float* dx, float* dy, float* dscale, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    if (!labels || !dx || !dy || !workspace) return set_error(CLIBD_EINVAL, "softce_bwd: null pointer");
+    if (Nx <= 0 || N <= 0 || D <= 0 || D % 64 != 0 || N % 4 != 0 || row0 < 0 || row0 + Nx > N)
+        return set_error(CLIBD_EINVAL, "softce_bwd: bad shape");
+    if (!aligned16(workspace) || !aligned16(dx) || !aligned16(dy)) return set_error(CLIBD_EINVAL, "softce_bwd: alignment");
+    const LossWs w = carve(workspace, Nx, N, D);
+    if (workspace_bytes < w.total) return set_error(CLIBD_EINVAL, "softce_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int Np = pad64(N), Nxp = pad64(Nx);
+    hipLaunchKernelGGL(softce_rows_bwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, N, Nx, N, labels, row0, w.lse,
+                       w.tsum, weight, scale, w.G, Np, dscale);
+    if (int e = check_launch("softce_rows_bwd")) return e;
+    // operand images: G^T [N,Nxp], xhi^T [D,Nxp], yhi^T [D,Np] (bf16, zero padded along the contraction)
+    if (int e = clibd_transpose_bf16(w.G, Np, Nx, N, w.GT, Nxp, stream)) return e;
+    if (int e = clibd_transpose_bf16(w.x3, 3 * D, Nx, D, w.xT, Nxp, stream)) return e;
+    if (int e = clibd_transpose_bf16(w.y3, 3 * D, N, D, w.yT, Np, stream)) return e;
+    clibd_gemm_epilogue ep = {};
+    ep.split_k = 1;
+    // dx[i,:] += sum_j G[i,j] y[j,:]      (accumulate in place through the residual path)
+    ep.out_f32 = dx; ep.ld_out_f32 = D; ep.residual_f32 = dx; ep.ld_res = D;
+    if (int e = clibd_gemm_bf16_nt(w.G, Np, w.yT, Np, Nx, D, Np, &ep, stream)) return e;
+    // dy[j,:] += sum_i G[i,j] x[i,:]
+    ep.out_f32 = dy; ep.residual_f32 = dy;
+    if (int e = clibd_gemm_bf16_nt(w.GT, Nxp, w.xT, Nxp, N, D, Nxp, &ep, stream)) return e;
+    return CLIBD_OK;
+}

@@ -1,0 +1,371 @@
+"""Tensor-level wrappers over the C ABI (include/clibd_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every function below only checks the
+operands on the host, takes raw pointers and enqueues hand-written gfx950 kernels on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmEpilogue, check
+
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True) -> None:
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a device tensor (clibd_amd has no CPU compute path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+
+
+def _rowmajor(t: torch.Tensor, name: str) -> int:
+    """2-D row-major view with unit inner stride; returns the leading dimension in elements."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride")
+    return t.stride(0)
+
+
+def gemm_nt(
+    a: torch.Tensor,
+    w: torch.Tensor,
+    *,
+    bias: Optional[torch.Tensor] = None,
+    rank_u: Optional[torch.Tensor] = None,
+    rank_v: Optional[torch.Tensor] = None,
+    act: int = ACT_NONE,
+    aux: Optional[torch.Tensor] = None,
+    residual: Optional[torch.Tensor] = None,
+    out_pre: Optional[torch.Tensor] = None,
+    out_bf16: Optional[torch.Tensor] = None,
+    out_f32: Optional[torch.Tensor] = None,
+    split_k: int = 1,
+) -> None:
+    """out = epilogue(a[M,K] @ w[N,K]^T); see clibd_gemm_bf16_nt in include/clibd_hip.h."""
+    _chk(a, BF16, "a", contiguous=False)
+    _chk(w, BF16, "w", contiguous=False)
+    lda, ldw = _rowmajor(a, "a"), _rowmajor(w, "w")
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise ValueError(f"gemm_nt: K mismatch {K} vs {K2}")
+    ep = GemmEpilogue()
+    ep.act = act
+    ep.split_k = split_k
+    if bias is not None:
+        _chk(bias, F32, "bias")
+        if bias.numel() != N:
+            raise ValueError("gemm_nt: bias must have N elements")
+        ep.bias = bias.data_ptr()
+    if rank_u is not None or rank_v is not None:
+        _chk(rank_u, BF16, "rank_u", contiguous=False)
+        _chk(rank_v, BF16, "rank_v")
+        if rank_u.shape[0] != M or rank_u.shape[1] < 8 or tuple(rank_v.shape) != (N, 8):
+            raise ValueError("gemm_nt: rank_u must be [M,>=8], rank_v [N,8]")
+        ep.rank_u, ep.rank_v, ep.ld_rank_u = rank_u.data_ptr(), rank_v.data_ptr(), _rowmajor(rank_u, "rank_u")
+    if aux is not None:
+        _chk(aux, BF16, "aux", contiguous=False)
+        if tuple(aux.shape) != (M, N):
+            raise ValueError("gemm_nt: aux must be [M,N]")
+        ep.aux_bf16, ep.ld_aux = aux.data_ptr(), _rowmajor(aux, "aux")
+    if residual is not None:
+        _chk(residual, F32, "residual", contiguous=False)
+        if tuple(residual.shape) != (M, N):
+            raise ValueError("gemm_nt: residual must be [M,N]")
+        ep.residual_f32, ep.ld_res = residual.data_ptr(), _rowmajor(residual, "residual")
+    for name, t, dt in (("out_pre", out_pre, BF16), ("out_bf16", out_bf16, BF16), ("out_f32", out_f32, F32)):
+        if t is not None:
+            _chk(t, dt, name, contiguous=False)
+            if tuple(t.shape) != (M, N):
+                raise ValueError(f"gemm_nt: {name} must be [M,N]")
+    if out_pre is not None:
+        ep.out_pre_bf16, ep.ld_pre = out_pre.data_ptr(), _rowmajor(out_pre, "out_pre")
+    if out_bf16 is not None:
+        ep.out_bf16, ep.ld_out_bf16 = out_bf16.data_ptr(), _rowmajor(out_bf16, "out_bf16")
+    if out_f32 is not None:
+        ep.out_f32, ep.ld_out_f32 = out_f32.data_ptr(), _rowmajor(out_f32, "out_f32")
+    check(_lib.load().clibd_gemm_bf16_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, C.byref(ep), _stream()), "gemm_bf16_nt")
+
+
+def transpose_bf16(x: torch.Tensor, pad_to: int = 64) -> torch.Tensor:
+    """[R,C] bf16 -> [C, R_pad] bf16 (zero padded along R to a multiple of `pad_to`)."""
+    _chk(x, BF16, "x", contiguous=False)
+    ld = _rowmajor(x, "x")
+    R, Cc = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((Cc, Rp), dtype=BF16, device=x.device)
+    check(_lib.load().clibd_transpose_bf16(x.data_ptr(), ld, R, Cc, out.data_ptr(), Rp, _stream()), "transpose_bf16")
+    return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, F32, "x")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(_lib.load().clibd_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "cast_f32_to_bf16")
+    return out
+
+
+def cast_transpose_bf16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [R,C] -> bf16 [C,R]."""
+    _chk(x, F32, "x")
+    R, Cc = x.shape
+    out = torch.empty((Cc, R), dtype=BF16, device=x.device)
+    check(_lib.load().clibd_cast_transpose_f32_to_bf16(x.data_ptr(), R, Cc, out.data_ptr(), _stream()), "cast_transpose")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, lora_a=None, t_out=None) -> None:
+    _chk(x, F32, "x")
+    M, H = x.shape
+    _chk(gamma, F32, "gamma")
+    _chk(beta, F32, "beta")
+    for nm, t, dt, shape in (("y_bf16", y_bf16, BF16, (M, H)), ("y_f32", y_f32, F32, (M, H)), ("stats", stats, F32, (M, 2)),
+                             ("lora_a", lora_a, BF16, (8, H)), ("t_out", t_out, BF16, (M, 8))):
+        if t is not None:
+            _chk(t, dt, nm)
+            if tuple(t.shape) != shape:
+                raise ValueError(f"layernorm_fwd: {nm} must be {shape}, got {tuple(t.shape)}")
+    check(_lib.load().clibd_layernorm_fwd(x.data_ptr(), M, H, gamma.data_ptr(), beta.data_ptr(), float(eps), _p(y_bf16), _p(y_f32),
+                                          _p(stats), _p(lora_a), _p(t_out), _stream()), "layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None) -> None:
+    _chk(x, F32, "x")
+    M, H = x.shape
+    if dy.dtype == BF16:
+        _chk(dy, BF16, "dy")
+        dyb, dyf = dy.data_ptr(), None
+    else:
+        _chk(dy, F32, "dy")
+        dyb, dyf = None, dy.data_ptr()
+    if tuple(dy.shape) != (M, H):
+        raise ValueError("layernorm_bwd: dy shape")
+    _chk(stats, F32, "stats")
+    _chk(gamma, F32, "gamma")
+    for nm, t, dt in (("dres", dres, F32), ("dx_f32", dx_f32, F32), ("dx_bf16", dx_bf16, BF16)):
+        if t is not None:
+            _chk(t, dt, nm)
+            if tuple(t.shape) != (M, H):
+                raise ValueError(f"layernorm_bwd: {nm} shape")
+    check(_lib.load().clibd_layernorm_bwd(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres), _p(dx_f32),
+                                          _p(dx_bf16), _stream()), "layernorm_bwd")
+
+
+def attention_fwd(qkv: torch.Tensor, B: int, S: int, nheads: int, key_mask: Optional[torch.Tensor], out: torch.Tensor) -> None:
+    _chk(qkv, BF16, "qkv")
+    _chk(out, BF16, "out")
+    H = nheads * 64
+    if tuple(qkv.shape) != (B * S, 3 * H) or tuple(out.shape) != (B * S, H):
+        raise ValueError("attention_fwd: qkv must be [B*S,3H], out [B*S,H] with H = 64*nheads")
+    if key_mask is not None:
+        _chk(key_mask, I32, "key_mask")
+        if tuple(key_mask.shape) != (B, S):
+            raise ValueError("attention_fwd: key_mask must be [B,S]")
+    check(_lib.load().clibd_attention_fwd(qkv.data_ptr(), B, S, nheads, _p(key_mask), out.data_ptr(), _stream()), "attention_fwd")
+
+
+def attention_bwd(qkv, dout, B, S, nheads, key_mask, dqkv) -> None:
+    _chk(qkv, BF16, "qkv")
+    _chk(dout, BF16, "dout")
+    _chk(dqkv, BF16, "dqkv")
+    H = nheads * 64
+    if tuple(qkv.shape) != (B * S, 3 * H) or tuple(dout.shape) != (B * S, H) or tuple(dqkv.shape) != (B * S, 3 * H):
+        raise ValueError("attention_bwd: shapes")
+    if key_mask is not None:
+        _chk(key_mask, I32, "key_mask")
+    check(_lib.load().clibd_attention_bwd(qkv.data_ptr(), dout.data_ptr(), B, S, nheads, _p(key_mask), dqkv.data_ptr(), _stream()),
+          "attention_bwd")
+
+
+def lora_pack(a_q, a_v, b_q, b_v, v_fwd, v_bwd, a_cat, w_dt) -> None:
+    H = a_q.shape[1]
+    for nm, t, shape in (("a_q", a_q, (4, H)), ("a_v", a_v, (4, H)), ("b_q", b_q, (H, 4)), ("b_v", b_v, (H, 4))):
+        _chk(t, F32, nm)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"lora_pack: {nm} must be {shape}")
+    for nm, t, shape in (("v_fwd", v_fwd, (3 * H, 8)), ("v_bwd", v_bwd, (H, 8)), ("a_cat", a_cat, (8, H)), ("w_dt", w_dt, (16, 3 * H))):
+        _chk(t, BF16, nm)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"lora_pack: {nm} must be {shape}")
+    check(_lib.load().clibd_lora_pack(a_q.data_ptr(), a_v.data_ptr(), b_q.data_ptr(), b_v.data_ptr(), H, v_fwd.data_ptr(),
+                                      v_bwd.data_ptr(), a_cat.data_ptr(), w_dt.data_ptr(), _stream()), "lora_pack")
+
+
+def lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v) -> None:
+    _chk(dqkv, BF16, "dqkv")
+    _chk(x, BF16, "x")
+    _chk(t, BF16, "t")
+    _chk(dt, BF16, "dt")
+    M, H = x.shape
+    if tuple(dqkv.shape) != (M, 3 * H) or tuple(t.shape) != (M, 8) or dt.shape[0] != M or dt.shape[1] < 8:
+        raise ValueError("lora_wgrad: shapes")
+    for nm, g, shape in (("dA_q", dA_q, (4, H)), ("dA_v", dA_v, (4, H)), ("dB_q", dB_q, (H, 4)), ("dB_v", dB_v, (H, 4))):
+        _chk(g, F32, nm)
+        if tuple(g.shape) != shape:
+            raise ValueError(f"lora_wgrad: {nm} must be {shape}")
+    check(_lib.load().clibd_lora_wgrad(dqkv.data_ptr(), 3 * H, x.data_ptr(), t.data_ptr(), dt.data_ptr(), dt.shape[1], M, H,
+                                       dA_q.data_ptr(), dA_v.data_ptr(), dB_q.data_ptr(), dB_v.data_ptr(), _stream()), "lora_wgrad")
+
+
+def patchify(image: torch.Tensor) -> torch.Tensor:
+    _chk(image, F32, "image")
+    if image.dim() != 4 or tuple(image.shape[1:]) != (3, 224, 224):
+        raise ValueError("patchify: image must be [B,3,224,224]")
+    B = image.shape[0]
+    out = torch.empty((B * 196, 768), dtype=BF16, device=image.device)
+    check(_lib.load().clibd_patchify(image.data_ptr(), B, out.data_ptr(), _stream()), "patchify")
+    return out
+
+
+def vit_cls_rows(cls: torch.Tensor, pos: torch.Tensor, tok: torch.Tensor) -> None:
+    B, S, H = tok.shape
+    _chk(cls, F32, "cls")
+    _chk(pos, F32, "pos")
+    _chk(tok, F32, "tok")
+    check(_lib.load().clibd_vit_cls_rows(cls.data_ptr(), pos.data_ptr(), B, S, H, tok.data_ptr(), _stream()), "vit_cls_rows")
+
+
+def bert_embed(ids, token_type, word, pos, typ, out) -> None:
+    _chk(ids, I64, "ids")
+    B, S = ids.shape
+    H = word.shape[1]
+    if token_type is not None:
+        _chk(token_type, I64, "token_type")
+    for nm, t in (("word", word), ("pos", pos), ("type", typ), ("out", out)):
+        _chk(t, F32, nm)
+    if pos.shape[0] < S:
+        raise ValueError("bert_embed: sequence longer than the position table")
+    check(_lib.load().clibd_bert_embed(ids.data_ptr(), _p(token_type), B, S, H, word.shape[0], word.data_ptr(), pos.data_ptr(),
+                                       typ.data_ptr(), out.data_ptr(), _stream()), "bert_embed")
+
+
+def softmax_mean_fwd(logits: torch.Tensor, B: int, S: int) -> torch.Tensor:
+    _chk(logits, BF16, "logits")
+    Cc = logits.shape[1]
+    out = torch.empty((B, Cc), dtype=F32, device=logits.device)
+    check(_lib.load().clibd_softmax_mean_fwd(logits.data_ptr(), B, S, Cc, out.data_ptr(), _stream()), "softmax_mean_fwd")
+    return out
+
+
+def softmax_mean_bwd(logits: torch.Tensor, dout: torch.Tensor, B: int, S: int) -> torch.Tensor:
+    _chk(logits, BF16, "logits")
+    _chk(dout, F32, "dout")
+    Cc = logits.shape[1]
+    dl = torch.empty_like(logits)
+    check(_lib.load().clibd_softmax_mean_bwd(logits.data_ptr(), dout.data_ptr(), B, S, Cc, dl.data_ptr(), _stream()), "softmax_mean_bwd")
+    return dl
+
+
+def token_mean_fwd(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, F32, "x")
+    B, S, H = x.shape
+    out = torch.empty((B, H), dtype=BF16, device=x.device)
+    check(_lib.load().clibd_token_mean_fwd(x.data_ptr(), B, S, H, out.data_ptr(), _stream()), "token_mean_fwd")
+    return out
+
+
+def token_mean_bwd(dout: torch.Tensor, S: int) -> torch.Tensor:
+    _chk(dout, F32, "dout")
+    B, H = dout.shape
+    dx = torch.empty((B, S, H), dtype=F32, device=dout.device)
+    check(_lib.load().clibd_token_mean_bwd(dout.data_ptr(), B, S, H, dx.data_ptr(), _stream()), "token_mean_bwd")
+    return dx
+
+
+def colsum_bf16(x: torch.Tensor, out: torch.Tensor) -> None:
+    """out[N] (fp32) += column sums of x[M,N] (bf16)."""
+    _chk(x, BF16, "x", contiguous=False)
+    _chk(out, F32, "out")
+    M, N = x.shape
+    check(_lib.load().clibd_colsum_bf16(x.data_ptr(), _rowmajor(x, "x"), M, N, out.data_ptr(), _stream()), "colsum_bf16")
+
+
+def gather_rows(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, F32, "x")
+    B, S, H = x.shape
+    out = torch.empty((B, H), dtype=F32, device=x.device)
+    check(_lib.load().clibd_gather_rows(x.data_ptr(), B, S, H, out.data_ptr(), _stream()), "gather_rows")
+    return out
+
+
+def scatter_rows(dcls: torch.Tensor, S: int, *, bf16: bool = True, f32: bool = False):
+    _chk(dcls, F32, "dcls")
+    B, H = dcls.shape
+    ob = torch.empty((B * S, H), dtype=BF16, device=dcls.device) if bf16 else None
+    of = torch.empty((B * S, H), dtype=F32, device=dcls.device) if f32 else None
+    check(_lib.load().clibd_scatter_rows_bf16(dcls.data_ptr(), B, S, H, _p(ob), _p(of), _stream()), "scatter_rows")
+    return ob, of
+
+
+def l2norm_fwd(x: torch.Tensor):
+    _chk(x, F32, "x")
+    N, D = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty((N,), dtype=F32, device=x.device)
+    check(_lib.load().clibd_l2norm_fwd(x.data_ptr(), N, D, y.data_ptr(), inv.data_ptr(), _stream()), "l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(dy: torch.Tensor, y: torch.Tensor, inv: torch.Tensor) -> torch.Tensor:
+    _chk(dy, F32, "dy")
+    _chk(y, F32, "y")
+    _chk(inv, F32, "inv")
+    N, D = y.shape
+    dx = torch.empty_like(y)
+    check(_lib.load().clibd_l2norm_bwd(dy.data_ptr(), y.data_ptr(), inv.data_ptr(), N, D, dx.data_ptr(), _stream()), "l2norm_bwd")
+    return dx
+
+
+def softce_workspace(Nx: int, N: int, D: int, device) -> torch.Tensor:
+    nbytes = _lib.load().clibd_softce_workspace_bytes(Nx, N, D)
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+
+
+def softce_rows_fwd(x, y, labels, row0: int, scale: float, loss_sum: torch.Tensor, ws: torch.Tensor) -> None:
+    _chk(x, F32, "x")
+    _chk(y, F32, "y")
+    _chk(labels, I64, "labels")
+    _chk(loss_sum, F32, "loss_sum")
+    Nx, D = x.shape
+    N = y.shape[0]
+    if y.shape[1] != D or labels.numel() != N:
+        raise ValueError("softce_rows_fwd: shapes")
+    check(_lib.load().clibd_softce_rows_fwd(x.data_ptr(), y.data_ptr(), labels.data_ptr(), Nx, N, D, row0, float(scale),
+                                            loss_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "softce_rows_fwd")
+
+
+def softce_rows_bwd(labels, Nx, N, D, row0, scale, weight, dx, dy, dscale, ws) -> None:
+    _chk(labels, I64, "labels")
+    _chk(dx, F32, "dx")
+    _chk(dy, F32, "dy")
+    if tuple(dx.shape) != (Nx, D) or tuple(dy.shape) != (N, D):
+        raise ValueError("softce_rows_bwd: shapes")
+    if dscale is not None:
+        _chk(dscale, F32, "dscale")
+    check(_lib.load().clibd_softce_rows_bwd(labels.data_ptr(), Nx, N, D, row0, float(scale), float(weight), dx.data_ptr(), dy.data_ptr(),
+                                            _p(dscale), ws.data_ptr(), ws.numel(), _stream()), "softce_rows_bwd")
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0) -> None:
+    for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, F32, nm)
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n:
+        raise ValueError("adamw_step: size mismatch")
+    check(_lib.load().clibd_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(lr), float(beta1), float(beta2),
+                                       float(eps), float(weight_decay), int(step), float(grad_scale), _stream()), "adamw_step")

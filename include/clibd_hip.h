@@ -1,0 +1,196 @@
+/*
+ * clibd_hip.h — C ABI of libclibd_hip.so: the MI355X (gfx950) kernels behind the CLIBD contrastive
+ * training step (scripts/train_cl.py -> bioscanclip/epoch/train_epoch.py:21-63 in the reference).
+ *
+ * The reference has NO native/FFI boundary of its own (it is pure Python on PyTorch), so
+ * every entry point below cites the reference *Python* symbol whose arithmetic it replaces.  The Python
+ * mirror of `bioscanclip.model` (package `clibd_amd.model`) binds these through ctypes.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers are DEVICE pointers owned by the caller; kernels never allocate, free or synchronise;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); NULL = the null stream;
+ *   - return 0 on success, a negative CLIBD_E* code otherwise; clibd_last_error() gives a thread-local
+ *     message; shapes are validated on the host BEFORE any launch (a bad shape never reaches the GPU);
+ *   - "bf16" buffers are uint16 bit patterns; activations row-major, leading dimension in ELEMENTS;
+ *   - re-entrant: no mutable global state, safe on different streams / devices concurrently.
+ */
+#ifndef CLIBD_HIP_H
+#define CLIBD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLIBD_OK 0
+#define CLIBD_EINVAL (-1)  /* bad shape / null pointer / unsupported size */
+#define CLIBD_ELAUNCH (-2) /* hipLaunch / runtime error */
+
+const char* clibd_last_error(void);
+int clibd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2/K4/K5: bf16 MFMA GEMM  out = epilogue(A[M,K] · W[N,K]^T)   (nn.Linear layout)
+ * Replaces every torch.nn.Linear on the path: timm Attention.qkv/proj, Mlp.fc1/fc2
+ * (reference call sites model/image_encoder.py:40-46,106-107), HF BertSelfAttention.query/key/value,
+ * BertSelfOutput.dense, BertIntermediate.dense, BertOutput.dense (model/dna_encoder.py:137,
+ * model/language_encoder.py:89) and their dgrad in backward.  fp32 accumulate.
+ *
+ * Epilogue, applied in this order to acc[m,n] (every pointer optional unless noted):
+ *   v = acc + rank_u[m,0:8]·rank_v[n,0:8]   (LoRA rank-(4+4) update, bf16 operands, as one extra MFMA k-step;
+ *                                            reference: _LoRA_qkv_timm.forward image_encoder.py:40-46,
+ *                                            _LoRALayer.forward dna_encoder.py:75-77)
+ *   v += bias[n]
+ *   if out_pre_bf16:  out_pre_bf16[m,n] = bf16(v); v = float(bf16(v))           (pre-activation, saved for bwd)
+ *   if act == CLIBD_ACT_GELU:       v = gelu_erf(v)                             (timm Mlp.act / HF "gelu")
+ *   if act == CLIBD_ACT_GELU_GRAD:  v = v * gelu'(aux_bf16[m,n])                (dgrad through GELU)
+ *   if residual_f32:  v += residual_f32[m,n]
+ *   out_bf16[m,n] = bf16(v) ; out_f32[m,n] = v   (either or both)
+ *   split_k > 1: only out_f32 allowed; partial sums are atomically added into a caller-zeroed out_f32.
+ * Constraints: K % 64 == 0, lda/ldw % 8 == 0, N % 16 == 0, all ld_* % 8 == 0, 16-byte aligned pointers.
+ * ------------------------------------------------------------------------------------------------ */
+enum { CLIBD_ACT_NONE = 0, CLIBD_ACT_GELU = 1, CLIBD_ACT_GELU_GRAD = 2 };
+
+typedef struct clibd_gemm_epilogue {
+    const float* bias;          /* [N] fp32 */
+    const void* rank_u;         /* [M,8] bf16, row stride ld_rank_u (>= 8, % 8) */
+    const void* rank_v;         /* [N,8] bf16, row stride 8 */
+    const void* aux_bf16;       /* [M,N] bf16 (GELU_GRAD input), ld = ld_aux */
+    const float* residual_f32;  /* [M,N] fp32, ld = ld_res */
+    void* out_pre_bf16;         /* [M,N] bf16, ld = ld_pre */
+    void* out_bf16;             /* [M,N] bf16, ld = ld_out_bf16 */
+    float* out_f32;             /* [M,N] fp32, ld = ld_out_f32 */
+    int32_t act;
+    int32_t ld_rank_u, ld_aux, ld_res, ld_pre, ld_out_bf16, ld_out_f32;
+    int32_t split_k;            /* >= 1 */
+} clibd_gemm_epilogue;
+
+int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                       const clibd_gemm_epilogue* ep, void* stream);
+
+/* bf16 transpose with zero padding: out[C, ld_out] (ld_out >= R) = in[R, C]^T; columns R..ld_out-1 zero.
+ * Used to feed the weight-gradient GEMMs (contraction over the token dimension). */
+int clibd_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
+
+/* fp32 -> bf16 cast of a contiguous buffer (weights are kept fp32 in the state dict, bf16 shadow copies
+ * feed the MFMA path, as torch.autocast does per call in the reference, epoch/train_epoch.py:43). */
+int clibd_cast_f32_to_bf16(const float* in, void* out, size_t n, void* stream);
+/* out[C,R] bf16 = transpose(in[R,C] fp32) */
+int clibd_cast_transpose_f32_to_bf16(const float* in, int R, int C, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (timm Block.norm1/norm2/norm eps=1e-6; HF BertEmbeddings/BertSelfOutput/BertOutput
+ * LayerNorm eps=1e-12), fp32 statistics.  x fp32 [M,H] -> y (bf16 and/or fp32), optional saved
+ * (mean, rstd) fp32 [M,2], optional LoRA down-projection t[m,0:8] = bf16(y[m,:]) · lora_a[8,H]^T
+ * (reference: linear_a_q/linear_a_v image_encoder.py:41-42, w_a dna_encoder.py:76) emitted as bf16 [M,8].
+ * H % 64 == 0, H <= 1024.
+ * ------------------------------------------------------------------------------------------------ */
+int clibd_layernorm_fwd(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                        void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
+                        void* stream);
+/* dx = LN'(dy) [+ dres]; dy is bf16 (dy_bf16) or fp32 (dy_f32), exactly one non-null.
+ * Outputs dx_f32 and/or dx_bf16. gamma is frozen on the LoRA path, so no dgamma/dbeta here. */
+int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
+                        const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
+                        void* dx_bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3: multi-head attention, head dim 64, whole sequence per workgroup (S <= 256: ViT 197, BarcodeBERT 133,
+ * BERT-small 20).  qkv bf16 [B*S, 3*H] packed [q | k | v] per row (timm Attention.forward layout
+ * image_encoder.py:20-24; HF BertSelfAttention with q/k/v weights concatenated).
+ * key_mask (optional) int32 [B,S], 1 = attend, 0 = masked (HF extended attention mask,
+ * language_encoder.py:89 via BertModel).  out bf16 [B*S, H].
+ * ------------------------------------------------------------------------------------------------ */
+int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
+                        void* stream);
+int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
+                        void* dqkv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6: LoRA (rank 4 on q and v; reference image_encoder.py:13-46, dna_encoder.py:68-77,
+ * language_encoder.py:24-33).  Adapter parameters: a_q,a_v fp32 [4,H] (nn.Linear(H,4).weight),
+ * b_q,b_v fp32 [H,4] (nn.Linear(4,H).weight); no alpha/r scaling.
+ *
+ * clibd_lora_pack (per step, parameters are trainable) builds the bf16 operand images:
+ *   v_fwd [3H,8]: rank_v of the QKV GEMM   q rows (B_q[n,:],0000) | k rows 0 | v rows (0000,B_v[n-2H,:])
+ *   v_bwd [H,8] : rank_v of the QKV dgrad  (A_q[0:4,k], A_v[0:4,k])
+ *   a_cat [8,H] : [A_q; A_v], the LayerNorm-fused down projection t = x·a_cat^T
+ *   w_dt  [16,3H]: GEMM weight giving dt[m,0:8] = [dq·B_q | dv·B_v] (cols 8..15 zero) from dqkv[M,3H]
+ * clibd_lora_wgrad: parameter gradients, contraction over the M tokens (accumulates, caller zeroes):
+ *   dB_q[n,r] += sum_m dq[m,n] t[m,r]      dB_v[n,r] += sum_m dv[m,n] t[m,4+r]
+ *   dA_q[r,k] += sum_m dt[m,r] x[m,k]      dA_v[r,k] += sum_m dt[m,4+r] x[m,k]
+ *   with dq = dqkv[:,0:H], dv = dqkv[:,2H:3H], x = adapter input bf16 [M,H], t bf16 [M,8], dt bf16 [M,ld_dt].
+ * ------------------------------------------------------------------------------------------------ */
+int clibd_lora_pack(const float* a_q, const float* a_v, const float* b_q, const float* b_v, int H,
+                    void* v_fwd_bf16, void* v_bwd_bf16, void* a_cat_bf16, void* w_dt_bf16, void* stream);
+int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* dt_bf16,
+                     int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embeddings.
+ * K1 patch gather (timm PatchEmbed: Conv2d(3,H,16,16) == GEMM over 16x16x3 patches):
+ *   patches bf16 [B*196, 768] with k = c*256 + py*16 + px  from image fp32 [B,3,224,224].
+ * ViT token assembly: tok fp32 [B,197,H]: row 0 = cls + pos[0]; rows 1.. = patch_proj + pos[1+p]
+ *   (timm VisionTransformer._pos_embed).  Done by the GEMM epilogue (residual = pos) + clibd_vit_cls_rows.
+ * BERT embeddings: word[id] + position[s] + token_type[tt] (HF BertEmbeddings) -> fp32 [B*S,H] (pre-LN sum).
+ * ------------------------------------------------------------------------------------------------ */
+int clibd_patchify(const float* image, int B, void* patches_bf16, void* stream);
+int clibd_vit_cls_rows(const float* cls, const float* pos, int B, int S, int H, float* tok, void* stream);
+int clibd_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int S, int H, int vocab,
+                     const float* word, const float* pos, const float* type, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K7: DNA head tail (model/dna_encoder.py:137): out[b,:] = mean_s softmax(logits[b,s,:]).
+ * logits bf16 [B*S, C]; out fp32 [B,C].  bwd: dlogits bf16 [B*S,C] from dout fp32 [B,C].  C % 64 == 0, C<=1024.
+ * ------------------------------------------------------------------------------------------------ */
+int clibd_softmax_mean_fwd(const void* logits, int B, int S, int C, float* out, void* stream);
+int clibd_softmax_mean_bwd(const void* logits, const float* dout, int B, int S, int C, void* dlogits,
+                           void* stream);
+/* token mean (model/language_encoder.py:89 `.last_hidden_state.mean(dim=1)`): x fp32 [B,S,H] -> bf16/fp32 [B,H] */
+int clibd_token_mean_fwd(const float* x, int B, int S, int H, void* out_bf16, void* stream);
+int clibd_token_mean_bwd(const float* dout, int B, int S, int H, float* dx, void* stream);
+/* column sums of a bf16 [M,N] matrix into fp32 [N] (bias gradients of the trainable heads; accumulates) */
+int clibd_colsum_bf16(const void* x, int ld, int M, int N, float* out, void* stream);
+/* gather / scatter the [CLS] rows: x fp32 [B,S,H] row 0 <-> [B,H] */
+int clibd_gather_rows(const float* x, int B, int S, int H, float* out, void* stream);
+int clibd_scatter_rows_bf16(const float* dcls, int B, int S, int H, void* dx_bf16, float* dx_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8: row L2 normalisation (F.normalize(p=2, dim=-1, eps=1e-12), model/simple_clip.py:45,58,60).
+ * ------------------------------------------------------------------------------------------------ */
+int clibd_l2norm_fwd(const float* x, int N, int D, float* y, float* inv_norm, void* stream);
+int clibd_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int N, int D, float* dx,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K9: all-pairs similarity + soft-target cross-entropy, row-block form, one direction of one modality pair
+ * (model/loss_func.py:41-69 ContrastiveLoss.forward, :138-201 ClipLoss.forward, :19-22 targets):
+ *   S[i,j] = scale * <x_i, y_j>    x: fp32 [Nx,D] = the rows this rank owns (global row offset row0),
+ *                                   y: fp32 [N,D]  = all rows of the other modality (unit-norm inputs)
+ *   T[i,j] = (labels[row0+i] == labels[j])                              (never materialised)
+ *   *loss_sum += sum_i ( LSE_j S[i,:] * sum_j T[i,j] - sum_j T[i,j] S[i,j] )   (= sum_i CE(S[i,:], T[i,:]);
+ *                the reference's nn.CrossEntropyLoss() mean is loss_sum / N, the caller applies it)
+ * The product runs on bf16 MFMA with split operands (hi+lo, three partial products in one K=3D GEMM), which
+ * is ~fp32-accurate like the reference's fp32 matmul outside autocast.  Full N x N semantics: Nx=N,row0=0,
+ * called once per direction (x=a,y=b) and (x=b,y=a).  Data-parallel: each rank passes its own row block.
+ * bwd must follow fwd on the same workspace:  g = weight * dloss_sum/dS;
+ *   dx [Nx,D] += scale * g·y,  dy [N,D] += scale * g^T·x  (fp32, ACCUMULATED),  *dscale += sum g∘(x·y^T).
+ * D % 64 == 0, N % 4 == 0.
+ * ------------------------------------------------------------------------------------------------ */
+size_t clibd_softce_workspace_bytes(int Nx, int N, int D);
+int clibd_softce_rows_fwd(const float* x, const float* y, const int64_t* labels, int Nx, int N, int D, int row0,
+                          float scale, float* loss_sum, void* workspace, size_t workspace_bytes, void* stream);
+int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D, int row0, float scale, float weight,
+                          float* dx, float* dy, float* dscale, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* fused AdamW step on a flat fp32 parameter bucket (torch.optim.AdamW semantics, scripts/train_cl.py:221):
+ * p,g,m,v [n]; g is multiplied by grad_scale first (1/world_size folding etc.). */
+int clibd_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIBD_HIP_H */

@@ -1,0 +1,74 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads, and exports exactly what
+include/clibd_hip.h declares (no compute calls here: there is no GPU on the authoring box)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = ROOT / "include" / "clibd_hip.h"
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(clibd_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from clibd_amd import build
+
+    return ctypes.CDLL(str(build.build(verbose=False)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for must in ("clibd_gemm_bf16_nt", "clibd_layernorm_fwd", "clibd_attention_fwd", "clibd_attention_bwd", "clibd_lora_wgrad",
+                 "clibd_softce_rows_fwd", "clibd_softce_rows_bwd", "clibd_l2norm_fwd", "clibd_adamw_step"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in clibd_hip.h but not exported: {missing}"
+
+
+def test_python_binding_covers_every_declared_symbol(lib):
+    from clibd_amd import _lib
+
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    assert _lib.load().clibd_abi_version() == 1
+
+
+def test_epilogue_struct_layout_matches_header():
+    from clibd_amd._lib import GemmEpilogue
+
+    # 8 pointers + 8 int32 (header order): 8*8 + 8*4 = 96 bytes
+    assert ctypes.sizeof(GemmEpilogue) == 96
+    assert [f[0] for f in GemmEpilogue._fields_] == ["bias", "rank_u", "rank_v", "aux_bf16", "residual_f32", "out_pre_bf16", "out_bf16",
+                                                     "out_f32", "act", "ld_rank_u", "ld_aux", "ld_res", "ld_pre", "ld_out_bf16",
+                                                     "ld_out_f32", "split_k"]
+
+
+def test_host_side_validation_needs_no_gpu(lib):
+    """Bad shapes are rejected on the host before any launch."""
+    from clibd_amd import _lib
+
+    L = _lib.load()
+    ep = _lib.GemmEpilogue()
+    assert L.clibd_gemm_bf16_nt(None, 64, None, 64, 8, 16, 64, ctypes.byref(ep), None) == -1
+    assert b"null" in L.clibd_last_error()
+    assert L.clibd_attention_fwd(ctypes.c_void_p(16), 1, 300, 1, None, ctypes.c_void_p(16), None) == -1
+    assert L.clibd_softce_workspace_bytes(32, 32, 768) > 32 * 32 * 4
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+
+    from clibd_amd import ops
+
+    with pytest.raises(ValueError):
+        ops.l2norm_fwd(torch.zeros(4, 8))
+    for py in (ROOT / "clibd_amd").rglob("*.py"):
+        assert "oracle" not in re.sub(r"#.*|\"\"\".*?\"\"\"", "", py.read_text(), flags=re.S), f"{py} references the oracle"

@@ -1,0 +1,415 @@
+"""Kernel-level parity (GPU): every C-ABI op against a plain PyTorch fp32/fp64 statement of the same op.
+
+All ops are called through clibd_amd.ops -> ctypes -> libclibd_hip.so.  Integer-valued operands make the
+MFMA layout checks exact (asymmetric operands so a transposed fragment cannot pass)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def bfr(x):
+    """round an fp32 tensor to bf16 precision (kept in fp32)"""
+    return x.to(BF16).to(F32)
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
+
+
+def rel_err(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from clibd_amd import ops as _ops
+
+    return _ops
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (77, 48, 192), (512, 768, 768), (1, 16, 64)])
+def test_gemm_exact_integers(ops, dev, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    # asymmetric structure: distinct row/col ramps
+    a[:, 0] += torch.arange(M).float() % 5
+    w[:, 1] += torch.arange(N).float() % 7
+    ref = a.double() @ w.double().T
+    out = torch.empty((M, N), dtype=F32, device=dev)
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), out_f32=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().double(), ref)
+
+
+def test_gemm_strided_operands_and_bf16_out(ops, dev):
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 200, 128, 128
+    abig = torch.randn(M, 3 * K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    a = abig[:, K : 2 * K]
+    ref = bfr(a) @ bfr(w).T
+    outbig = torch.zeros((M, 2 * N), dtype=BF16, device=dev)
+    ad = abig.to(dev, BF16)[:, K : 2 * K]
+    ops.gemm_nt(ad, w.to(dev, BF16), out_bf16=outbig[:, N:])
+    torch.cuda.synchronize()
+    got = outbig.cpu().float()
+    assert torch.equal(got[:, :N], torch.zeros(M, N))
+    assert rel_err(got[:, N:], ref) < 4e-3
+
+
+def test_gemm_epilogue_bias_gelu_pre(ops, dev):
+    g = torch.Generator().manual_seed(2)
+    M, N, K = 260, 384, 256
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    pre_ref = bfr(bfr(a) @ bfr(w).T + b)
+    act_ref = gelu(pre_ref)
+    pre = torch.empty((M, N), dtype=BF16, device=dev)
+    act = torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), bias=b.to(dev), act=ops.ACT_GELU, out_pre=pre, out_bf16=act)
+    torch.cuda.synchronize()
+    assert rel_err(pre.cpu().float(), pre_ref) < 3e-3
+    assert rel_err(act.cpu().float(), act_ref) < 4e-3
+    # gelu is applied to the *rounded* pre-activation the kernel stored
+    assert (act.cpu().float() - bfr(gelu(pre.cpu().float()))).abs().max().item() < 2e-2
+
+
+def test_gemm_epilogue_gelu_grad_and_residual(ops, dev):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 130, 256, 128
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    aux = torch.randn(M, N, generator=g) * 2
+    res = torch.randn(M, N, generator=g)
+    ref = (bfr(a) @ bfr(w).T) * gelu_grad(bfr(aux)) + res
+    outf = torch.empty((M, N), dtype=F32, device=dev)
+    outb = torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), act=ops.ACT_GELU_GRAD, aux=aux.to(dev, BF16), residual=res.to(dev), out_f32=outf,
+                out_bf16=outb)
+    torch.cuda.synchronize()
+    assert rel_err(outf.cpu(), ref) < 1e-4
+    assert rel_err(outb.cpu().float(), ref) < 4e-3
+
+
+def test_gemm_rank8_update(ops, dev):
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 150, 256, 128
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    u = torch.randn(M, 16, generator=g)  # row stride 16, only the first 8 columns are operands
+    v = torch.randn(N, 8, generator=g)
+    ref = bfr(a) @ bfr(w).T + bfr(u[:, :8]) @ bfr(v).T
+    out = torch.empty((M, N), dtype=F32, device=dev)
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), rank_u=u.to(dev, BF16), rank_v=v.to(dev, BF16), out_f32=out)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 1e-5
+
+
+def test_gemm_split_k_accumulates(ops, dev):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 96, 64, 1024
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    ref = bfr(a) @ bfr(w).T
+    out = torch.zeros((M, N), dtype=F32, device=dev)
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), out_f32=out, split_k=4)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 1e-5
+
+
+def test_gemm_rejects_bad_shapes(ops, dev):
+    from clibd_amd._lib import ClibdHipError
+
+    a = torch.zeros((8, 96), dtype=BF16, device=dev)  # K not a multiple of 64
+    w = torch.zeros((16, 96), dtype=BF16, device=dev)
+    with pytest.raises(ClibdHipError):
+        ops.gemm_nt(a, w, out_f32=torch.empty((8, 16), dtype=F32, device=dev))
+    with pytest.raises(ValueError):
+        ops.gemm_nt(torch.zeros((8, 64), dtype=BF16), torch.zeros((16, 64), dtype=BF16), out_f32=torch.empty((8, 16)))
+
+
+def test_transpose_and_casts(ops, dev):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(133, 200, generator=g)
+    xt = ops.transpose_bf16(x.to(dev, BF16))
+    torch.cuda.synchronize()
+    assert xt.shape == (200, 192)
+    assert torch.equal(xt.cpu().float()[:, :133], bfr(x).T)
+    assert torch.equal(xt.cpu().float()[:, 133:], torch.zeros(200, 59))
+    y = torch.randn(70, 130, generator=g)
+    assert torch.equal(ops.cast_bf16(y.to(dev)).cpu().float(), bfr(y))
+    assert torch.equal(ops.cast_transpose_bf16(y.to(dev)).cpu().float(), bfr(y).T)
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("H,eps", [(768, 1e-6), (512, 1e-12), (128, 1e-12), (1024, 1e-5)])
+def test_layernorm_fwd_bwd(ops, dev, H, eps):
+    g = torch.Generator().manual_seed(H)
+    M = 37
+    x = torch.randn(M, H, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    acat = torch.randn(8, H, generator=g) * 0.05
+    xd = x.double().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(xd, (H,), gamma.double(), beta.double(), eps)
+    yb = torch.empty((M, H), dtype=BF16, device=dev)
+    yf = torch.empty((M, H), dtype=F32, device=dev)
+    stats = torch.empty((M, 2), dtype=F32, device=dev)
+    t = torch.empty((M, 8), dtype=BF16, device=dev)
+    ops.layernorm_fwd(x.to(dev), gamma.to(dev), beta.to(dev), eps, y_bf16=yb, y_f32=yf, stats=stats, lora_a=acat.to(dev, BF16), t_out=t)
+    torch.cuda.synchronize()
+    assert (yf.cpu().double() - yref.detach()).abs().max().item() < 2e-5
+    assert torch.equal(yb.cpu().float(), bfr(yf.cpu()))
+    tref = bfr(yf.cpu()) @ bfr(acat).T
+    assert (t.cpu().float() - tref).abs().max().item() < 2e-2 * tref.abs().max().item() + 1e-3
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    assert (stats.cpu()[:, 0].double() - mean).abs().max().item() < 1e-5
+    assert rel_err(stats.cpu()[:, 1], 1.0 / torch.sqrt(var + eps)) < 1e-5
+    # backward: dx = LN'(dy) + dres
+    dy = torch.randn(M, H, generator=g)
+    dres = torch.randn(M, H, generator=g)
+    (gref,) = torch.autograd.grad(yref, xd, dy.double())
+    dxf = torch.empty((M, H), dtype=F32, device=dev)
+    dxb = torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_bwd(dy.to(dev), x.to(dev), stats, gamma.to(dev), dres=dres.to(dev), dx_f32=dxf, dx_bf16=dxb)
+    torch.cuda.synchronize()
+    assert rel_err(dxf.cpu(), gref + dres.double()) < 2e-5
+    assert torch.equal(dxb.cpu().float(), bfr(dxf.cpu()))
+    # bf16 upstream gradient
+    (gref2,) = torch.autograd.grad(torch.nn.functional.layer_norm(xd, (H,), gamma.double(), beta.double(), eps), xd, bfr(dy).double())
+    ops.layernorm_bwd(dy.to(dev, BF16), x.to(dev), stats, gamma.to(dev), dx_f32=dxf)
+    torch.cuda.synchronize()
+    assert rel_err(dxf.cpu(), gref2) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, B, S, nh, mask):
+    """fp32 statement: scores fp32, softmax fp32, P rounded to bf16 (straight-through), PV fp32."""
+    H = nh * 64
+    q, k, v = qkv.view(B, S, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    pb = p + (p.to(BF16).to(p.dtype) - p).detach()
+    o = pb @ v
+    return o.permute(0, 2, 1, 3).reshape(B * S, H)
+
+
+@pytest.mark.parametrize("B,S,nh,masked", [(2, 197, 2, False), (3, 133, 3, False), (4, 20, 2, True), (1, 32, 1, False), (2, 64, 1, True),
+                                           (1, 256, 1, False), (2, 7, 1, False)])
+def test_attention_fwd_bwd(ops, dev, B, S, nh, masked):
+    g = torch.Generator().manual_seed(S * 3 + nh)
+    H = nh * 64
+    qkv = bfr(torch.randn(B * S, 3 * H, generator=g))
+    mask = None
+    if masked:
+        lens = torch.randint(max(1, S // 3), S + 1, (B,), generator=g)
+        mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int32)
+    qd = qkv.double().requires_grad_(True)
+    oref = _attn_ref(qd, B, S, nh, mask)
+    out = torch.empty((B * S, H), dtype=BF16, device=dev)
+    ops.attention_fwd(qkv.to(dev, BF16), B, S, nh, None if mask is None else mask.to(dev), out)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().float(), oref.detach()) < 5e-3
+    assert (out.cpu().float() - oref.detach().float()).abs().max().item() < 3e-2
+    do = bfr(torch.randn(B * S, H, generator=g))
+    (gref,) = torch.autograd.grad(oref, qd, do.double())
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=BF16, device=dev)
+    ops.attention_bwd(qkv.to(dev, BF16), do.to(dev, BF16), B, S, nh, None if mask is None else mask.to(dev), dqkv)
+    torch.cuda.synchronize()
+    got = dqkv.cpu().float()
+    assert torch.isfinite(got).all()
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert rel_err(got[:, sl], gref[:, sl]) < 1.5e-2, name
+
+
+# ----------------------------------------------------------------------------------------------- LoRA
+def test_lora_pack_and_wgrad(ops, dev):
+    g = torch.Generator().manual_seed(11)
+    H, M = 128, 700
+    a_q, a_v = torch.randn(4, H, generator=g), torch.randn(4, H, generator=g)
+    b_q, b_v = torch.randn(H, 4, generator=g), torch.randn(H, 4, generator=g)
+    v_fwd = torch.empty((3 * H, 8), dtype=BF16, device=dev)
+    v_bwd = torch.empty((H, 8), dtype=BF16, device=dev)
+    a_cat = torch.empty((8, H), dtype=BF16, device=dev)
+    w_dt = torch.empty((16, 3 * H), dtype=BF16, device=dev)
+    ops.lora_pack(a_q.to(dev), a_v.to(dev), b_q.to(dev), b_v.to(dev), v_fwd, v_bwd, a_cat, w_dt)
+    torch.cuda.synchronize()
+    vf = torch.zeros(3 * H, 8)
+    vf[:H, :4] = bfr(b_q)
+    vf[2 * H :, 4:] = bfr(b_v)
+    assert torch.equal(v_fwd.cpu().float(), vf)
+    assert torch.equal(v_bwd.cpu().float(), torch.cat([bfr(a_q).T, bfr(a_v).T], dim=1))
+    assert torch.equal(a_cat.cpu().float(), torch.cat([bfr(a_q), bfr(a_v)], dim=0))
+    wd = torch.zeros(16, 3 * H)
+    wd[:4, :H] = bfr(b_q).T
+    wd[4:8, 2 * H :] = bfr(b_v).T
+    assert torch.equal(w_dt.cpu().float(), wd)
+
+    dqkv = bfr(torch.randn(M, 3 * H, generator=g))
+    x = bfr(torch.randn(M, H, generator=g))
+    t = bfr(torch.randn(M, 8, generator=g))
+    # dt through the GEMM against w_dt (what the backward pass does)
+    dt = torch.empty((M, 16), dtype=BF16, device=dev)
+    ops.gemm_nt(dqkv.to(dev, BF16), w_dt, out_bf16=dt)
+    torch.cuda.synchronize()
+    dt_ref = torch.cat([dqkv[:, :H] @ bfr(b_q), dqkv[:, 2 * H :] @ bfr(b_v)], dim=1)
+    assert rel_err(dt.cpu().float()[:, :8], dt_ref) < 4e-3
+    assert torch.equal(dt.cpu().float()[:, 8:], torch.zeros(M, 8))
+    dA_q, dA_v = torch.zeros((4, H), device=dev), torch.zeros((4, H), device=dev)
+    dB_q, dB_v = torch.zeros((H, 4), device=dev), torch.zeros((H, 4), device=dev)
+    ops.lora_wgrad(dqkv.to(dev, BF16), x.to(dev, BF16), t.to(dev, BF16), dt, dA_q, dA_v, dB_q, dB_v)
+    torch.cuda.synchronize()
+    dtf = dt.cpu().float()
+    assert rel_err(dB_q.cpu(), dqkv[:, :H].T @ t[:, :4]) < 1e-5
+    assert rel_err(dB_v.cpu(), dqkv[:, 2 * H :].T @ t[:, 4:]) < 1e-5
+    assert rel_err(dA_q.cpu(), dtf[:, :4].T @ x) < 1e-5
+    assert rel_err(dA_v.cpu(), dtf[:, 4:8].T @ x) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- embeddings / heads
+def test_patchify_matches_conv_unfold(ops, dev):
+    g = torch.Generator().manual_seed(12)
+    B = 2
+    img = torch.rand(B, 3, 224, 224, generator=g)
+    ref = torch.nn.functional.unfold(img, kernel_size=16, stride=16).transpose(1, 2).reshape(B * 196, 768)
+    got = ops.patchify(img.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu().float(), bfr(ref))
+
+
+def test_vit_cls_rows_and_bert_embed(ops, dev):
+    g = torch.Generator().manual_seed(13)
+    B, S, H = 3, 5, 64
+    cls, pos = torch.randn(H, generator=g), torch.randn(S, H, generator=g)
+    tok = torch.zeros((B, S, H), device=dev)
+    ops.vit_cls_rows(cls.to(dev), pos.to(dev), tok)
+    torch.cuda.synchronize()
+    assert torch.equal(tok.cpu()[:, 0], (cls + pos[0]).expand(B, H))
+    assert torch.equal(tok.cpu()[:, 1:], torch.zeros(B, S - 1, H))
+    V = 50
+    ids = torch.randint(0, V, (B, S), generator=g)
+    tt = torch.randint(0, 2, (B, S), generator=g)
+    word, posw, typ = torch.randn(V, H, generator=g), torch.randn(16, H, generator=g), torch.randn(2, H, generator=g)
+    out = torch.empty((B * S, H), device=dev)
+    ops.bert_embed(ids.to(dev), tt.to(dev), word.to(dev), posw.to(dev), typ.to(dev), out)
+    torch.cuda.synchronize()
+    ref = word[ids] + posw[:S][None] + typ[tt]
+    assert torch.equal(out.cpu(), ref.reshape(B * S, H))
+    ops.bert_embed(ids.to(dev), None, word.to(dev), posw.to(dev), typ.to(dev), out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), (word[ids] + posw[:S][None] + typ[0]).reshape(B * S, H))
+
+
+@pytest.mark.parametrize("B,S,C", [(3, 133, 768), (2, 5, 128), (1, 20, 1024)])
+def test_softmax_mean_fwd_bwd(ops, dev, B, S, C):
+    g = torch.Generator().manual_seed(C + S)
+    logits = bfr(torch.randn(B * S, C, generator=g) * 3)
+    ld = logits.double().requires_grad_(True)
+    ref = torch.softmax(ld.view(B, S, C), dim=-1).mean(dim=1)
+    out = ops.softmax_mean_fwd(logits.to(dev, BF16), B, S)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref.detach()) < 1e-5
+    assert (out.cpu().sum(1) - 1).abs().max().item() < 1e-5
+    dout = torch.randn(B, C, generator=g)
+    (gref,) = torch.autograd.grad(ref, ld, dout.double())
+    dl = ops.softmax_mean_bwd(logits.to(dev, BF16), dout.to(dev), B, S)
+    torch.cuda.synchronize()
+    assert rel_err(dl.cpu().float(), gref) < 4e-3
+
+
+def test_token_mean_colsum_gather_scatter(ops, dev):
+    g = torch.Generator().manual_seed(14)
+    B, S, H = 4, 20, 512
+    x = torch.randn(B, S, H, generator=g)
+    m = ops.token_mean_fwd(x.to(dev))
+    torch.cuda.synchronize()
+    assert (m.cpu().float() - bfr(x.mean(1))).abs().max().item() < 1e-2
+    d = torch.randn(B, H, generator=g)
+    dx = ops.token_mean_bwd(d.to(dev), S)
+    torch.cuda.synchronize()
+    assert torch.allclose(dx.cpu(), (d / S)[:, None, :].expand(B, S, H), rtol=1e-6, atol=1e-7)
+    y = bfr(torch.randn(1000, 200, generator=g))
+    cs = torch.ones(200, device=dev)
+    ops.colsum_bf16(y.to(dev, BF16), cs)
+    torch.cuda.synchronize()
+    assert rel_err(cs.cpu(), y.sum(0) + 1) < 1e-5
+    assert torch.equal(ops.gather_rows(x.to(dev)).cpu(), x[:, 0])
+    sb, sf = ops.scatter_rows(d.to(dev), S, bf16=True, f32=True)
+    torch.cuda.synchronize()
+    ref = torch.zeros(B, S, H)
+    ref[:, 0] = d
+    assert torch.equal(sf.cpu().view(B, S, H), ref)
+    assert torch.equal(sb.cpu().float().view(B, S, H), bfr(ref))
+
+
+def test_l2norm_fwd_bwd(ops, dev):
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(50, 768, generator=g) * 3
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xd, p=2, dim=-1)
+    y, inv = ops.l2norm_fwd(x.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), ref.detach()) < 1e-6
+    dy = torch.randn(50, 768, generator=g)
+    (gref,) = torch.autograd.grad(ref, xd, dy.double())
+    dx = ops.l2norm_bwd(dy.to(dev), y, inv)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu(), gref) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- K9 loss
+def _softce_ref(x, y, labels, row0, scale):
+    S = scale * (x @ y.T)
+    T = (labels[row0 : row0 + x.shape[0], None] == labels[None, :]).to(S.dtype)
+    return -(T * torch.log_softmax(S, dim=1)).sum()
+
+
+@pytest.mark.parametrize("Nx,N,row0,dup", [(32, 32, 0, False), (64, 64, 0, True), (24, 96, 48, True), (256, 2048, 512, False)])
+def test_softce_rows_fwd_bwd(ops, dev, Nx, N, row0, dup):
+    g = torch.Generator().manual_seed(N + Nx)
+    D = 768
+    x = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=-1)[row0 : row0 + Nx].contiguous()
+    y = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=-1)
+    labels = torch.arange(N) // 2 if dup else torch.arange(N)
+    scale = 1.0 / 0.07
+    xd, yd = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    sd = torch.tensor(scale, dtype=torch.float64, requires_grad=True)
+    ref = _softce_ref(xd, yd, labels, row0, sd)
+    w = 0.37 / N
+    gx, gy, gs = torch.autograd.grad(ref * w, (xd, yd, sd))
+    ws = ops.softce_workspace(Nx, N, D, dev)
+    loss = torch.zeros(1, device=dev)
+    ops.softce_rows_fwd(x.to(dev), y.to(dev), labels.to(dev), row0, scale, loss, ws)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 2e-4 * abs(ref.item()) + 1e-3
+    dx = torch.zeros((Nx, D), device=dev)
+    dy = torch.ones((N, D), device=dev)  # accumulate semantics
+    ds = torch.zeros(1, device=dev)
+    ops.softce_rows_bwd(labels.to(dev), Nx, N, D, row0, scale, w, dx, dy, ds, ws)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu(), gx) < 6e-3
+    assert rel_err(dy.cpu() - 1, gy) < 6e-3
+    assert abs(ds.item() - gs.item()) < 1e-3 * abs(gs.item()) + 1e-6
+
+
+def test_adamw_matches_torch(ops, dev):
+    g = torch.Generator().manual_seed(16)
+    n = 10007
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) for _ in range(3)]
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step, gr in enumerate(grads, 1):
+        pt.grad = gr.clone()
+        opt.step()
+        ops.adamw_step(p, (gr * 4).to(dev), m, v, 3e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=0.25)
+    torch.cuda.synchronize()
+    assert (p.cpu() - pt.detach()).abs().max().item() < 2e-6
