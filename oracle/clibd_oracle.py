@@ -1,0 +1,539 @@
+"""CPU ORACLE for the CLIBD contrastive training step — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (clibd_amd/) never does and has no CPU fallback.
+
+What it is: a plain-PyTorch fp32 restatement of the arithmetic on the reference's hot path
+(scripts/train_cl.py -> bioscanclip/epoch/train_epoch.py:21-63), module by module, with the reference's
+attribute / state-dict names so that (a) the reference's own wrapper classes can wrap these bodies when the
+golden vectors are generated (tests/golden/make_golden.py, run in the authoring container only) and (b) golden
+state dicts load here unchanged.
+
+Pinning status:
+  * losses            — pinned: compared with the imported reference `ContrastiveLoss` / `ClipLoss`
+                        (bioscanclip/model/loss_func.py:25-69,110-201) on committed golden vectors.
+  * BERT towers       — pinned: the reference `CLIBDDNAEncoder` / `CLIBDLanguageEncoder`
+                        (model/dna_encoder.py:80-137, model/language_encoder.py:36-89) wrap HF transformers'
+                        BertForMaskedLM / BertModel; golden IO + grads committed.
+  * LoRA surgery/head — pinned by importing the reference `CLIBDImageEncoder` / `_LoRA_qkv_timm`
+                        (model/image_encoder.py:13-107) around `VisionTransformer` below.
+  * ViT body          — third-party timm ~=1.0.9 (requirements.txt:9) is NOT in /root/reference and not installed:
+                        restated from its published architecture (vit_base_patch16_224) and cross-checked against
+                        transformers.ViTModel.  "parity unpinned" at that boundary in the strict sense.
+  * top-k             — faiss-gpu 1.7.2 (requirements.txt:22) absent: exact fp32 inner product + stable top-k.
+
+`precision("bf16")` switches every linear layer / attention product to bf16-rounded operands with fp32
+accumulation — the same rounding points as the HIP kernels (torch.autocast(bf16) in the reference,
+epoch/train_epoch.py:42-46); `precision("fp32")` is the reference's CPU path.
+"""
+from __future__ import annotations
+
+import contextlib
+import itertools
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_PRECISION = "fp32"
+
+
+@contextlib.contextmanager
+def precision(mode: str):
+    global _PRECISION
+    assert mode in ("fp32", "bf16")
+    old, _PRECISION = _PRECISION, mode
+    try:
+        yield
+    finally:
+        _PRECISION = old
+
+
+def _r(x: torch.Tensor) -> torch.Tensor:
+    """bf16 rounding with a straight-through gradient (autocast casts are differentiable identities)."""
+    if _PRECISION == "fp32":
+        return x
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
+def _rg(x: torch.Tensor) -> torch.Tensor:
+    """round the *gradient* flowing back through x to bf16 (grad of a bf16 tensor is bf16 under autocast)."""
+    if _PRECISION == "fp32" or not x.requires_grad:
+        return x
+
+    class _G(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.to(torch.bfloat16).to(g.dtype)
+
+    return _G.apply(x)
+
+
+def olinear(x, weight, bias=None):
+    """nn.Linear with the kernels' rounding points: bf16 operands, fp32 accumulate, fp32 bias, bf16 output."""
+    y = F.linear(_r(x), _r(weight), None)
+    if bias is not None:
+        y = y + bias
+    return _rg(_r(y))
+
+
+def gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+# =====================================================================================================
+# ViT (timm vit_base_patch16_224 architecture; created at model/simple_clip.py:150-153)
+# =====================================================================================================
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch=16, in_chans=3, dim=768):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, dim, kernel_size=patch, stride=patch)
+        self.num_patches = (img_size // patch) ** 2
+        self.patch = patch
+
+    def forward(self, x):
+        # conv with stride == kernel is a GEMM over flattened patches, k = c*P*P + py*P + px
+        B = x.shape[0]
+        P = self.patch
+        cols = F.unfold(x, kernel_size=P, stride=P).transpose(1, 2)  # [B, L, C*P*P]
+        w = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
+        return olinear(cols, w, self.proj.bias).reshape(B, self.num_patches, -1)
+
+
+def attention_core(q, k, v, mask_add=None):
+    """q,k,v [B,h,S,dh]; scores and softmax in fp32, probabilities rounded to bf16 before P·V (bf16 mode)."""
+    s = (_r(q) @ _r(k).transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+    if mask_add is not None:
+        s = s + mask_add
+    p = torch.softmax(s, dim=-1)
+    return _rg(_r(_r(p) @ _r(v)))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.head_dim = dim // heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x) if not isinstance(self.qkv, nn.Linear) else olinear(x, self.qkv.weight, self.qkv.bias)
+        q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
+        o = attention_core(q, k, v).transpose(1, 2).reshape(B, N, C)
+        return olinear(o, self.proj.weight, self.proj.bias)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        h = olinear(x, self.fc1.weight, self.fc1.bias)
+        return olinear(_rg(_r(gelu_erf(h))), self.fc2.weight, self.fc2.bias)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio=4.0, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class VisionTransformer(nn.Module):
+    """timm-compatible attribute names: patch_embed.proj, cls_token, pos_embed, blocks[i].{norm1,attn.{qkv,proj},
+    norm2,mlp.{fc1,fc2}}, norm, head, reset_classifier — what model/image_encoder.py:49-107 touches."""
+
+    def __init__(self, img_size=224, patch=16, dim=768, depth=12, heads=12, num_classes=1000):
+        super().__init__()
+        self.embed_dim = dim
+        self.patch_embed = PatchEmbed(img_size, patch, 3, dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches + 1, dim) * 0.02)
+        self.blocks = nn.Sequential(*[Block(dim, heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.head = nn.Linear(dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def reset_classifier(self, num_classes: int):
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        x = self.blocks(x)
+        return self.norm(x)
+
+    def forward(self, x):
+        x = self.forward_features(x)[:, 0]
+        if isinstance(self.head, nn.Linear):
+            return olinear(x, self.head.weight, self.head.bias)
+        return x
+
+
+class LoRAQKV(nn.Module):
+    """model/image_encoder.py:13-46: qkv = W x + b; q += B_q(A_q x); v += B_v(A_v x); no alpha/r scale."""
+
+    def __init__(self, qkv, linear_a_q, linear_b_q, linear_a_v, linear_b_v):
+        super().__init__()
+        self.qkv, self.linear_a_q, self.linear_b_q, self.linear_a_v, self.linear_b_v = qkv, linear_a_q, linear_b_q, linear_a_v, linear_b_v
+        self.dim = qkv.in_features
+
+    def forward(self, x):
+        # the kernel adds bias after the rank update and rounds once; algebraically the same sum
+        base = F.linear(_r(x), _r(self.qkv.weight), None)
+        tq = olinear(x, self.linear_a_q.weight)
+        tv = olinear(x, self.linear_a_v.weight)
+        dq = F.linear(_r(tq), _r(self.linear_b_q.weight))
+        dv = F.linear(_r(tv), _r(self.linear_b_v.weight))
+        zeros = torch.zeros_like(dq)
+        out = base + torch.cat([dq, zeros, dv], dim=-1) + self.qkv.bias
+        return _rg(_r(out))
+
+
+def _lora_init(a: nn.Linear, b: nn.Linear):
+    nn.init.kaiming_uniform_(a.weight, a=math.sqrt(5))
+    nn.init.zeros_(b.weight)
+
+
+class ImageEncoder(nn.Module):
+    """model/image_encoder.py:49-107 (state-dict prefix `base_image_encoder.`)."""
+
+    def __init__(self, vit: VisionTransformer, r: int = 4, num_classes: int = 0, lora_layer=None):
+        super().__init__()
+        assert r > 0
+        layers = lora_layer if lora_layer else list(range(len(vit.blocks)))  # `if lora_layer:` quirk, :54-57
+        for p in vit.parameters():
+            p.requires_grad = False
+        for i, blk in enumerate(vit.blocks):
+            if i not in layers:
+                continue
+            d = blk.attn.qkv.in_features
+            aq, bq, av, bv = nn.Linear(d, r, bias=False), nn.Linear(r, d, bias=False), nn.Linear(d, r, bias=False), nn.Linear(r, d, bias=False)
+            _lora_init(aq, bq)
+            _lora_init(av, bv)
+            blk.attn.qkv = LoRAQKV(blk.attn.qkv, aq, bq, av, bv)
+        self.base_image_encoder = vit
+        if num_classes > 0:
+            vit.reset_classifier(num_classes)
+
+    def forward(self, x):
+        return self.base_image_encoder(x)
+
+
+# =====================================================================================================
+# BERT (HF transformers BertForMaskedLM / BertModel arithmetic; model/dna_encoder.py:25-37,
+# model/language_encoder.py:12-20).  Parameter names follow HF so reference state dicts load.
+# =====================================================================================================
+class LoRALinear(nn.Module):
+    """model/dna_encoder.py:68-77 `_LoRALayer`: w(x) + w_b(w_a(x))."""
+
+    def __init__(self, w, w_a, w_b):
+        super().__init__()
+        self.w, self.w_a, self.w_b = w, w_a, w_b
+        self.in_features = w.in_features
+
+    def forward(self, x):
+        base = F.linear(_r(x), _r(self.w.weight), None)
+        t = olinear(x, self.w_a.weight)
+        out = base + F.linear(_r(t), _r(self.w_b.weight)) + self.w.bias
+        return _rg(_r(out))
+
+
+def _lin(mod, x):
+    if isinstance(mod, nn.Linear):
+        return olinear(x, mod.weight, mod.bias)
+    return mod(x)
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, vocab, hidden, max_pos=512, type_vocab=2, eps=1e-12):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab, hidden)
+        self.position_embeddings = nn.Embedding(max_pos, hidden)
+        self.token_type_embeddings = nn.Embedding(type_vocab, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+
+    def forward(self, ids, token_type_ids=None):
+        S = ids.shape[1]
+        tt = token_type_ids if token_type_ids is not None else torch.zeros_like(ids)
+        pos = torch.arange(S, device=ids.device)[None, :]
+        return self.LayerNorm(self.word_embeddings(ids) + self.token_type_embeddings(tt) + self.position_embeddings(pos))
+
+
+class _SelfAttn(nn.Module):
+    def __init__(self, hidden, heads):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(hidden, hidden), nn.Linear(hidden, hidden), nn.Linear(hidden, hidden)
+        self.heads = heads
+
+    def forward(self, x, mask_add):
+        B, S, Hd = x.shape
+        sp = lambda t: t.view(B, S, self.heads, Hd // self.heads).transpose(1, 2)
+        o = attention_core(sp(_lin(self.query, x)), sp(_lin(self.key, x)), sp(_lin(self.value, x)), mask_add)
+        return o.transpose(1, 2).reshape(B, S, Hd)
+
+
+class _DenseLN(nn.Module):
+    def __init__(self, din, dout, eps):
+        super().__init__()
+        self.dense = nn.Linear(din, dout)
+        self.LayerNorm = nn.LayerNorm(dout, eps=eps)
+
+    def forward(self, x, residual):
+        return self.LayerNorm(olinear(x, self.dense.weight, self.dense.bias) + residual)
+
+
+class _Attn(nn.Module):
+    def __init__(self, hidden, heads, eps):
+        super().__init__()
+        self.self = _SelfAttn(hidden, heads)
+        self.output = _DenseLN(hidden, hidden, eps)
+
+
+class _Inter(nn.Module):
+    def __init__(self, hidden, ff):
+        super().__init__()
+        self.dense = nn.Linear(hidden, ff)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, hidden, heads, ff, eps=1e-12):
+        super().__init__()
+        self.attention = _Attn(hidden, heads, eps)
+        self.intermediate = _Inter(hidden, ff)
+        self.output = _DenseLN(ff, hidden, eps)
+
+    def forward(self, x, mask_add=None):
+        a = self.attention.output(self.attention.self(x, mask_add), x)
+        h = olinear(a, self.intermediate.dense.weight, self.intermediate.dense.bias)
+        return self.output(_rg(_r(gelu_erf(h))), a)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n, hidden, heads, ff):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(hidden, heads, ff) for _ in range(n)])
+
+
+class _Pooler(nn.Module):
+    def __init__(self, hidden):
+        super().__init__()
+        self.dense = nn.Linear(hidden, hidden)
+
+
+class BertModel(nn.Module):
+    def __init__(self, vocab=30522, hidden=512, layers=4, heads=8, ff=2048, max_pos=512, pooler=True):
+        super().__init__()
+        self.embeddings = BertEmbeddings(vocab, hidden, max_pos)
+        self.encoder = _Encoder(layers, hidden, heads, ff)
+        if pooler:
+            self.pooler = _Pooler(hidden)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None):
+        x = self.embeddings(input_ids, token_type_ids)
+        mask_add = None
+        if attention_mask is not None:
+            mask_add = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
+        for layer in self.encoder.layer:
+            x = layer(x, mask_add)
+        return x  # last_hidden_state
+
+
+class _Transform(nn.Module):
+    def __init__(self, hidden, eps=1e-12):
+        super().__init__()
+        self.dense = nn.Linear(hidden, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+
+
+class _Predictions(nn.Module):
+    def __init__(self, hidden, vocab):
+        super().__init__()
+        self.transform = _Transform(hidden)
+        self.decoder = nn.Linear(hidden, vocab)
+        self.bias = nn.Parameter(torch.zeros(vocab))
+
+
+class _Cls(nn.Module):
+    def __init__(self, hidden, vocab):
+        super().__init__()
+        self.predictions = _Predictions(hidden, vocab)
+
+
+class BertForMaskedLM(nn.Module):
+    def __init__(self, vocab=1027, hidden=768, layers=12, heads=12, ff=3072, max_pos=512):
+        super().__init__()
+        self.bert = BertModel(vocab, hidden, layers, heads, ff, max_pos, pooler=False)
+        self.cls = _Cls(hidden, vocab)
+
+    def forward(self, ids):
+        x = self.bert(ids)
+        t = self.cls.predictions.transform
+        h = t.LayerNorm(_rg(_r(gelu_erf(olinear(x, t.dense.weight, t.dense.bias)))))
+        d = self.cls.predictions.decoder
+        return olinear(h, d.weight, d.bias)  # logits
+
+
+def _add_bert_lora(layers, r, lora_layer):
+    idx = lora_layer if lora_layer is not None else list(range(len(layers)))  # `is not None` test, dna_encoder.py:85-88
+    for i, layer in enumerate(layers):
+        if i not in idx:
+            continue
+        sa = layer.attention.self
+        d = sa.query.in_features
+        aq, bq, av, bv = nn.Linear(d, r, bias=False), nn.Linear(r, d, bias=False), nn.Linear(d, r, bias=False), nn.Linear(r, d, bias=False)
+        _lora_init(aq, bq)
+        _lora_init(av, bv)
+        sa.query = LoRALinear(sa.query, aq, bq)
+        sa.value = LoRALinear(sa.value, av, bv)
+
+
+class DNAEncoder(nn.Module):
+    """model/dna_encoder.py:80-137: LoRA on query/value, MLM decoder replaced by Linear(H, num_classes),
+    output = logits.softmax(-1).mean(1)."""
+
+    def __init__(self, model: BertForMaskedLM, r: int = 4, num_classes: int = 0, lora_layer=None):
+        super().__init__()
+        assert r > 0
+        for p in model.parameters():
+            p.requires_grad = False
+        _add_bert_lora(model.bert.encoder.layer, r, lora_layer)
+        self.base_dna_encoder = model
+        if num_classes > 0:
+            dec = model.cls.predictions.decoder
+            model.cls.predictions.decoder = nn.Linear(dec.in_features, num_classes)
+
+    def forward(self, sequence):
+        return self.base_dna_encoder(sequence).softmax(dim=-1).mean(dim=1)
+
+
+class LanguageEncoder(nn.Module):
+    """model/language_encoder.py:36-89: proj(last_hidden_state.mean(1)) — mean includes padded positions."""
+
+    def __init__(self, model: BertModel, r: int = 4, num_classes: int = 0, lora_layer=None):
+        super().__init__()
+        assert r > 0
+        for p in model.parameters():
+            p.requires_grad = False
+        _add_bert_lora(model.encoder.layer, r, lora_layer)
+        self.base_language_encoder = model
+        if num_classes > 0:
+            self.proj = nn.Linear(model.pooler.dense.out_features, num_classes)
+
+    def forward(self, x: dict):
+        h = self.base_language_encoder(x["input_ids"], x.get("token_type_ids"), x.get("attention_mask"))
+        return olinear(h.mean(dim=1), self.proj.weight, self.proj.bias)
+
+
+# =====================================================================================================
+# SimpleCLIP + losses (model/simple_clip.py:21-61, model/loss_func.py)
+# =====================================================================================================
+class SimpleCLIP(nn.Module):
+    def __init__(self, image_encoder, dna_encoder, language_encoder, init_logit_scale: float = math.log(1 / 0.07)):
+        super().__init__()
+        self.image_encoder, self.dna_encoder, self.language_encoder = image_encoder, dna_encoder, language_encoder
+        self.logit_scale = nn.Parameter(torch.ones([]) * init_logit_scale)
+
+    def forward(self, image_input, dna_input, language_input):
+        img = dna = txt = None
+        if self.dna_encoder is not None:
+            dna = F.normalize(self.dna_encoder(dna_input).float(), p=2, dim=-1)
+        if self.image_encoder is not None:
+            img = F.normalize(self.image_encoder(image_input).float(), p=2, dim=-1)
+        if self.language_encoder is not None:
+            txt = F.normalize(self.language_encoder(language_input).float(), p=2, dim=-1)
+        return img, dna, txt, self.logit_scale.exp(), None
+
+
+def label_matrix(labels):
+    """loss_func.py:19-22"""
+    return (labels[None, :] == labels[:, None]).float()
+
+
+def soft_ce(logits, targets):
+    """nn.CrossEntropyLoss() with probability targets: mean_i( -sum_j t_ij log_softmax(logits)_ij )."""
+    return -(targets * torch.log_softmax(logits, dim=1)).sum(dim=1).mean()
+
+
+def contrastive_loss(features, labels, logit_scale, bind_to=None, no_image_text_loss=False):
+    """loss_func.py:41-69 / :159-201.  `features` = [image, dna, text] (None allowed); the loop over ordered pairs,
+    the second normalisation and both directions per pair are kept exactly as the reference evaluates them."""
+    present = [(i, f) for i, f in enumerate(features) if f is not None]
+    if len(present) < 2:
+        raise ValueError("Too less element for calculating the contrastive loss.")
+    T = label_matrix(labels)
+    bind = {"image": 0, "dna": 1, "text": 2}.get(bind_to) if bind_to is not None else None
+    feats = [f for _, f in present]
+    terms = []
+    # NB: the reference indexes the *filtered* list (idx 0/1/2 are positions after dropping None entries)
+    for ia, fa in enumerate(feats):
+        for ib, fb in enumerate(feats):
+            if bind is not None and ia != bind and ib != bind:
+                continue
+            if ia == ib:
+                continue
+            if no_image_text_loss and (ia == 0 or ib == 0) and (ia == 2 or ib == 2):
+                continue
+            a, b = F.normalize(fa, p=2, dim=1), F.normalize(fb, p=2, dim=1)
+            terms.append(soft_ce(logit_scale * a @ b.T, T))
+            terms.append(soft_ce(logit_scale * b @ a.T, T))
+    return sum(terms) / len(terms)
+
+
+# =====================================================================================================
+# batch contract helpers (util/util.py:77-98, model/dna_encoder.py:53-63) and eval top-k (util/util.py:521-528)
+# =====================================================================================================
+_KMER_ID = {"".join(k): 3 + i for i, k in enumerate(itertools.product("ACGT", repeat=5))}
+
+
+def kmer_tokenize(seq: str, max_len: int = 660, k: int = 5) -> list:
+    """[0] + ids of the non-overlapping 5-mers of the sequence padded with 'N' / truncated to 660 nt.
+    specials <MASK>=0, <CLS>=1, <UNK>=2; k-mers in product('ACGT', repeat=5) order start at 3."""
+    s = seq[:max_len] if len(seq) > max_len else seq + "N" * (max_len - len(seq))
+    return [0] + [_KMER_ID.get(s[i : i + k], 2) for i in range(0, len(s) - k + 1, k)]
+
+
+def topk_inner_product(query, keys, k=5):
+    """faiss.IndexFlatIP.search on L2-normalised inputs: exact fp32 scores, ties -> lower index."""
+    q = F.normalize(query.float(), dim=1)
+    kk = F.normalize(keys.float(), dim=1)
+    # per-pair sums in one fixed order (a blocked GEMM may round identical rows differently): small cases only
+    s = torch.cat([(q[i : i + 16, None, :] * kk[None, :, :]).sum(-1) for i in range(0, q.shape[0], 16)], dim=0)
+    idx = torch.argsort(-s, dim=1, stable=True)[:, :k]
+    return torch.gather(s, 1, idx), idx
+
+
+# =====================================================================================================
+# one training step (epoch/train_epoch.py:21-63) on CPU — the cpu_baseline leg of bench.py
+# =====================================================================================================
+def build_image_dna_model(dim=768, depth=12, heads=12, dna_layers=12, out_dim=768, seed=42, img_size=224):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    vit = VisionTransformer(img_size=img_size, dim=dim, depth=depth, heads=heads, num_classes=0)
+    bert = BertForMaskedLM(vocab=1027, hidden=dim, layers=dna_layers, heads=heads, ff=4 * dim)
+    del g
+    return SimpleCLIP(ImageEncoder(vit, 4, out_dim), DNAEncoder(bert, 4, out_dim), None)
+
+
+def train_step(model: SimpleCLIP, optimizer, image, dna, labels, text=None):
+    optimizer.zero_grad(set_to_none=True)
+    img, dn, txt, scale, _ = model(image, dna, text)
+    loss = contrastive_loss([img, dn, txt], labels, scale)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()

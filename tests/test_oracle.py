@@ -1,0 +1,193 @@
+"""Pin the CPU oracle (oracle/clibd_oracle.py) to the reference: every golden vector under tests/golden/ was
+produced by importing bioscan-ml/clibd's own modules (tests/golden/make_golden.py).  CPU only."""
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import clibd_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(G, name), map_location="cpu", weights_only=False)
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------- losses
+def test_known_answers_from_survey():
+    ka = load("loss_golden.pt")["known_answers"]
+    # bioscanclip ContrastiveLoss, seed-0 randn(32,768) pairs (SURVEY.md §8c / BASELINE.md §4)
+    assert abs(float(ka["unique"]) - 3.676485061645508) < 1e-6
+    assert abs(float(ka["dup"]) - 7.247870445251465) < 1e-6
+    for key, labels in (("unique", torch.arange(32)), ("dup", torch.arange(32) // 2)):
+        got = O.contrastive_loss([ka["a"], ka["b"], None], labels, 1 / 0.07)
+        assert abs(float(got) - float(ka[key])) < 2e-6
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_loss_matches_reference_cliploss(i):
+    c = load("loss_golden.pt")["loss_cases"][i]
+    feats = [None if f is None else f.clone().requires_grad_(True) for f in c["features"]]
+    ls = c["log_scale"].clone().requires_grad_(True)
+    loss = O.contrastive_loss(feats, c["labels"], ls.exp(), bind_to=c["bind_to"], no_image_text_loss=c["no_image_text_loss"])
+    assert abs(float(loss) - float(c["clip_loss"])) < 5e-6
+    if "contrastive_loss" in c:
+        assert abs(float(loss) - float(c["contrastive_loss"])) < 5e-6
+    present = [f for f in feats if f is not None]
+    grads = torch.autograd.grad(loss, present + [ls])
+    for g, r in zip(grads, c["clip_grads"]):
+        assert rel(g, r) < 1e-5
+
+
+def test_loss_needs_two_modalities():
+    with pytest.raises(ValueError):
+        O.contrastive_loss([torch.randn(4, 8), None, None], torch.arange(4), 1.0)
+
+
+def test_unique_labels_equal_symmetric_infonce():
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(16, 64, generator=g), torch.randn(16, 64, generator=g)
+    an, bn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(b, dim=1)
+    s = 10.0 * an @ bn.T
+    t = torch.arange(16)
+    ref = 0.5 * (torch.nn.functional.cross_entropy(s, t) + torch.nn.functional.cross_entropy(s.T, t))
+    assert abs(float(O.contrastive_loss([a, b, None], t, 10.0)) - float(ref)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- towers
+def build_dna(gd):
+    c = gd["config"]
+    m = O.DNAEncoder(O.BertForMaskedLM(vocab=1027, hidden=c["hidden_size"], layers=c["num_hidden_layers"], heads=c["num_attention_heads"],
+                                       ff=c["intermediate_size"]), r=4, num_classes=128)
+    missing = m.load_state_dict(gd["state_dict"], strict=True)
+    return m.eval()
+
+
+def build_text(gt):
+    c = gt["config"]
+    m = O.LanguageEncoder(O.BertModel(vocab=gt["vocab"], hidden=c["hidden_size"], layers=c["num_hidden_layers"],
+                                      heads=c["num_attention_heads"], ff=c["intermediate_size"]), r=4, num_classes=128)
+    m.load_state_dict(gt["state_dict"], strict=True)
+    return m.eval()
+
+
+def build_image(gi):
+    c = gi["config"]
+    m = O.ImageEncoder(O.VisionTransformer(img_size=224, patch=16, dim=c["dim"], depth=c["depth"], heads=c["heads"], num_classes=10), r=4,
+                       num_classes=128)
+    m.load_state_dict(gi["state_dict"], strict=True)
+    return m.eval()
+
+
+def check_grads(module, loss, golden, tol=2e-4):
+    params = {n: p for n, p in module.named_parameters() if p.requires_grad}
+    assert sorted(params) == sorted(golden), (sorted(params), sorted(golden))
+    gs = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    for (n, p), g in zip(params.items(), gs):
+        g = torch.zeros_like(p) if g is None else g
+        assert rel(g, golden[n]) < tol or (g - golden[n]).abs().max() < 1e-7, n
+
+
+def test_dna_tower_matches_reference_and_state_dict_keys():
+    gd = load("dna_tiny_golden.pt")
+    m = build_dna(gd)
+    y = m(gd["ids"])
+    assert (y - gd["out"]).abs().max().item() < 2e-6
+    assert torch.allclose(y.sum(1), torch.ones(4), atol=1e-5)  # mean of softmax rows
+    check_grads(m, (y * gd["cot"]).sum(), gd["grads"])
+    # trainable set = LoRA A/B of query/value + the replaced decoder (dna_encoder.py:97-123)
+    train = sorted(n for n, p in m.named_parameters() if p.requires_grad)
+    assert all((".w_a." in n or ".w_b." in n or "decoder" in n) for n in train)
+    assert "base_dna_encoder.bert.encoder.layer.0.attention.self.query.w.weight" in gd["state_dict"]
+    assert gd["state_dict"]["base_dna_encoder.bert.encoder.layer.0.attention.self.query.w_a.weight"].shape == (4, 128)
+    assert gd["state_dict"]["base_dna_encoder.bert.encoder.layer.0.attention.self.value.w_b.weight"].shape == (128, 4)
+
+
+def test_text_tower_matches_reference_with_padding_mask():
+    gt = load("text_tiny_golden.pt")
+    m = build_text(gt)
+    y = m(gt["inputs"])
+    assert (y - gt["out"]).abs().max().item() < 2e-5
+    check_grads(m, (y * gt["cot"]).sum(), gt["grads"])
+    assert "proj.weight" in gt["state_dict"] and "base_language_encoder.pooler.dense.weight" in gt["state_dict"]
+
+
+def test_image_tower_matches_reference_wrapper_and_vit_crosscheck():
+    gi = load("image_tiny_golden.pt")
+    m = build_image(gi)
+    img = gi["image_u8"].float() / 255.0
+    y = m(img)
+    assert (y - gi["out"]).abs().max().item() < 2e-5
+    check_grads(m, (y * gi["cot"]).sum(), gi["grads"])
+    keys = gi["state_dict"].keys()
+    assert "base_image_encoder.blocks.0.attn.qkv.qkv.weight" in keys
+    assert "base_image_encoder.blocks.1.attn.qkv.linear_a_q.weight" in keys and "base_image_encoder.head.weight" in keys
+    # the ViT body (timm absent) agreed with transformers.ViTModel when the fixture was generated
+    assert gi["vit_body_crosscheck"]["max_abs_diff"] < 2e-4
+
+
+def test_lora_layer_quirks():
+    """image: `if lora_layer:` -> [] still wraps every block; BERT: `is not None` -> [] disables."""
+    vit = O.VisionTransformer(dim=64, depth=2, heads=1, num_classes=0)
+    ie = O.ImageEncoder(vit, 4, 32, lora_layer=[])
+    assert all(isinstance(b.attn.qkv, O.LoRAQKV) for b in ie.base_image_encoder.blocks)
+    de = O.DNAEncoder(O.BertForMaskedLM(vocab=1027, hidden=64, layers=2, heads=1, ff=128), 4, 32, lora_layer=[])
+    assert all(isinstance(l.attention.self.query, torch.nn.Linear) for l in de.base_dna_encoder.bert.encoder.layer)
+    # B = 0 at init: adapters are the identity
+    assert float(ie.base_image_encoder.blocks[0].attn.qkv.linear_b_q.weight.abs().sum()) == 0.0
+
+
+def test_full_step_matches_reference_simpleclip_cliploss():
+    gs, gd, gt, gi = load("step_tiny_golden.pt"), load("dna_tiny_golden.pt"), load("text_tiny_golden.pt"), load("image_tiny_golden.pt")
+    model = O.SimpleCLIP(build_image(gi), build_dna(gd), build_text(gt))
+    with torch.no_grad():
+        model.logit_scale.copy_(gs["logit_scale"])
+    assert list(model.state_dict().keys()) == gs["state_dict_keys"]
+    img = gs["image_u8"].float() / 255.0
+    for tag, use_text in (("id", False), ("idt", True)):
+        io, do_, to, scale, bias = model(img, gs["dna"], gs["text"])
+        assert bias is None
+        for f, r in zip((io, do_, to), gs[f"features_{tag}"]):
+            assert (f - r).abs().max().item() < 2e-5
+        loss = O.contrastive_loss([io, do_, to if use_text else None], gs["labels"], scale)
+        assert abs(float(loss) - float(gs[f"loss_{tag}"])) < 2e-5
+        check_grads(model, loss, gs[f"grads_{tag}"], tol=1e-3)
+
+
+def test_bf16_emulation_stays_close_to_fp32():
+    gd = load("dna_tiny_golden.pt")
+    m = build_dna(gd)
+    with O.precision("bf16"):
+        yb = m(gd["ids"])
+    assert rel(yb, gd["out"]) < 3e-2 and rel(yb, gd["out"]) > 0  # rounding is active but small
+
+
+# ------------------------------------------------------------------------------------------- batch contract / eval
+def test_kmer_tokenizer_contract():
+    ids = O.kmer_tokenize("ACGTA" * 132)
+    assert len(ids) == 133 and ids[0] == 0
+    # id = 3 + base-4 value with A0 C1 G2 T3 (product('ACGT', repeat=5) order)
+    val = sum(d * 4 ** (4 - i) for i, d in enumerate([0, 1, 2, 3, 0]))
+    assert ids[1] == 3 + val
+    assert O.kmer_tokenize("AAAAA")[1] == 3 and O.kmer_tokenize("TTTTT")[1] == 3 + 1023
+    short = O.kmer_tokenize("ACGTAC")  # padded with N -> second k-mer 'CNNNN' is <UNK>=2
+    assert short[1] == 3 + val - 0 and short[2] == 2 and short[-1] == 2 and len(short) == 133
+    assert len(O.kmer_tokenize("A" * 1000)) == 133
+
+
+def test_topk_inner_product_is_exact_and_stable():
+    g = torch.Generator().manual_seed(7)
+    keys = torch.randn(50, 32, generator=g)
+    q = keys[[3, 10, 10]] * 2.0  # scaled copies: normalisation makes them exact matches
+    sim, idx = O.topk_inner_product(q, keys, k=5)
+    assert idx[:, 0].tolist() == [3, 10, 10]
+    assert torch.allclose(sim[:, 0], torch.ones(3), atol=1e-6)
+    keys2 = torch.cat([keys, keys[:1]])  # duplicate key 0 at index 50: tie -> lower index first
+    _, idx2 = O.topk_inner_product(keys[:1], keys2, k=2)
+    assert idx2[0].tolist() == [0, 50]
