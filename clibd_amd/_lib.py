@@ -53,7 +53,8 @@ SIGNATURES = {
     "clibd_lora_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_lora_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_patchify": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
-    "clibd_vit_cls_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_vit_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clibd_gelu_bwd_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "clibd_bert_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_softmax_mean_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "clibd_softmax_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -65,8 +66,8 @@ SIGNATURES = {
     "clibd_l2norm_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clibd_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "clibd_softce_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "clibd_softce_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "clibd_softce_rows_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "clibd_softce_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "clibd_softce_rows_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
 }
 

@@ -26,13 +26,35 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     }
 }
 
-// tok[b,0,:] = cls + pos[0,:]
-__global__ __launch_bounds__(256) void vit_cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
-                                                           int B, int S, int H, float* __restrict__ tok) {
-    const int total = B * H;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int b = i / H, h = i % H;
-        tok[(size_t)b * S * H + h] = cls[h] + pos[h];
+// tok[b,0,:] = cls + pos[0,:];  tok[b,1+p,:] = proj[b*P+p,:] + pos[1+p,:]   (timm VisionTransformer._pos_embed)
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ proj, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, int B, int S, int H,
+                                                           float* __restrict__ tok) {
+    const int hq = H / 4;
+    const size_t total = (size_t)B * S * hq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % hq) * 4;
+        const size_t row = i / hq;
+        const int s = (int)(row % S);
+        const size_t b = row / S;
+        const f32x4 p = *(const f32x4*)(pos + (size_t)s * H + c);
+        const f32x4 v = (s == 0) ? *(const f32x4*)(cls + c) : *(const f32x4*)(proj + (b * (S - 1) + (s - 1)) * H + c);
+        *(f32x4*)(tok + row * H + c) = (f32x4){v[0] + p[0], v[1] + p[1], v[2] + p[2], v[3] + p[3]};
+    }
+}
+
+// dx = dy * gelu'(pre)   (bf16 in/out; the dense -> GELU -> LayerNorm transform of the BERT MLM head)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ pre,
+                                                       size_t n4, unsigned short* __restrict__ dx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint2 d = *(const uint2*)(dy + 4 * i);
+        const uint2 x = *(const uint2*)(pre + 4 * i);
+        uint2 o;
+        o.x = pack2bf(bf2f((unsigned short)(d.x & 0xffff)) * gelu_grad_f(bf2f((unsigned short)(x.x & 0xffff))),
+                      bf2f((unsigned short)(d.x >> 16)) * gelu_grad_f(bf2f((unsigned short)(x.x >> 16))));
+        o.y = pack2bf(bf2f((unsigned short)(d.y & 0xffff)) * gelu_grad_f(bf2f((unsigned short)(x.y & 0xffff))),
+                      bf2f((unsigned short)(d.y >> 16)) * gelu_grad_f(bf2f((unsigned short)(x.y >> 16))));
+        *(uint2*)(dx + 4 * i) = o;
     }
 }
 
@@ -296,10 +318,21 @@ extern "C" int clibd_patchify(const float* image, int B, void* patches_bf16, voi
     return check_launch("patchify");
 }
 
-extern "C" int clibd_vit_cls_rows(const float* cls, const float* pos, int B, int S, int H, float* tok, void* stream) {
-    if (!cls || !pos || !tok || B <= 0 || S <= 0 || H <= 0) return set_error(CLIBD_EINVAL, "vit_cls_rows: bad args");
-    hipLaunchKernelGGL(vit_cls_rows_kernel, dim3(grid_for((size_t)B * H)), dim3(256), 0, (hipStream_t)stream, cls, pos, B, S, H, tok);
-    return check_launch("vit_cls_rows");
+extern "C" int clibd_vit_assemble_tokens(const float* proj, const float* cls, const float* pos, int B, int S, int H, float* tok,
+                                         void* stream) {
+    if (!proj || !cls || !pos || !tok || B <= 0 || S <= 1 || H <= 0 || H % 4 != 0) return set_error(CLIBD_EINVAL, "vit_assemble_tokens: bad args");
+    if (!aligned16(proj) || !aligned16(cls) || !aligned16(pos) || !aligned16(tok)) return set_error(CLIBD_EINVAL, "vit_assemble_tokens: alignment");
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for((size_t)B * S * (H / 4))), dim3(256), 0, (hipStream_t)stream, proj, cls, pos, B, S, H, tok);
+    return check_launch("vit_assemble_tokens");
+}
+
+extern "C" int clibd_gelu_bwd_bf16(const void* dy, const void* pre, size_t n, void* dx, void* stream) {
+    if (!dy || !pre || !dx) return set_error(CLIBD_EINVAL, "gelu_bwd: null pointer");
+    if (n % 4 != 0) return set_error(CLIBD_EINVAL, "gelu_bwd: n must be a multiple of 4");
+    if (n == 0) return CLIBD_OK;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
+                       (const unsigned short*)pre, n / 4, (unsigned short*)dx);
+    return check_launch("gelu_bwd");
 }
 
 extern "C" int clibd_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int S, int H, int vocab,

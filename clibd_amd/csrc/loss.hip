@@ -39,13 +39,15 @@ struct RowStat {
 
 // one wave per row: online log-sum-exp + target sums
 __global__ __launch_bounds__(256) void softce_rows_fwd_kernel(const float* __restrict__ S, int ldS, int Nx, int N,
-                                                              const int64_t* __restrict__ labels, int row0, float scale,
+                                                              const int64_t* __restrict__ labels, int row0,
+                                                              const float* __restrict__ scale_ptr,
                                                               float* __restrict__ lse, float* __restrict__ tsum_out,
                                                               float* __restrict__ loss_sum) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Nx) return;
     const int64_t lab = labels[row0 + row];
+    const float scale = *scale_ptr;
     const float* sr = S + (size_t)row * ldS;
     float m = -3.0e38f, s = 0.f, ts = 0.f, td = 0.f;
     for (int j = lane; j < N; j += 64) {
@@ -78,13 +80,17 @@ __global__ __launch_bounds__(256) void softce_rows_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void softce_rows_bwd_kernel(const float* __restrict__ S, int ldS, int Nx, int N,
                                                               const int64_t* __restrict__ labels, int row0,
                                                               const float* __restrict__ lse, const float* __restrict__ tsum,
-                                                              float w, float scale, unsigned short* __restrict__ G,
+                                                              float w, const float* __restrict__ wscale_ptr,
+                                                              const float* __restrict__ scale_ptr,
+                                                              unsigned short* __restrict__ G,
                                                               int ldG, float* __restrict__ dscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Nx) return;
     const int64_t lab = labels[row0 + row];
     const float l = lse[row], ts = tsum[row];
+    const float scale = *scale_ptr;
+    if (wscale_ptr != nullptr) w *= *wscale_ptr;
     const float* sr = S + (size_t)row * ldS;
     unsigned short* gr = G + (size_t)row * ldG;
     float ds = 0.f;
@@ -154,9 +160,9 @@ extern "C" size_t clibd_softce_workspace_bytes(int Nx, int N, int D) {
 }
 
 extern "C" int clibd_softce_rows_fwd(const float* x, const float* y, const int64_t* labels, int Nx, int N, int D, int row0,
-                                     float scale, float* loss_sum, void* workspace, size_t workspace_bytes, void* stream) {
+                                     const float* scale, float* loss_sum, void* workspace, size_t workspace_bytes, void* stream) {
     if (int e = loss_check(x, y, labels, Nx, N, D, row0)) return e;
-    if (!loss_sum || !workspace) return set_error(CLIBD_EINVAL, "softce_fwd: null pointer");
+    if (!loss_sum || !workspace || !scale) return set_error(CLIBD_EINVAL, "softce_fwd: null pointer");
     if (!aligned16(workspace)) return set_error(CLIBD_EINVAL, "softce_fwd: workspace must be 16-byte aligned");
     const LossWs w = carve(workspace, Nx, N, D);
     if (workspace_bytes < w.total) return set_error(CLIBD_EINVAL, "softce_fwd: workspace too small");
@@ -175,10 +181,10 @@ extern "C" int clibd_softce_rows_fwd(const float* x, const float* y, const int64
 }
 
 // Must follow clibd_softce_rows_fwd on the same workspace (reuses its similarity matrix and row statistics).
-extern "C" int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D, int row0, float scale, float weight,
-                                     float* dx, float* dy, float* dscale, void* workspace, size_t workspace_bytes,
+extern "C" int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D, int row0, const float* scale, float weight,
+                                     const float* weight_scale, float* dx, float* dy, float* dscale, void* workspace, size_t workspace_bytes,
                                      void* stream) {
-    if (!labels || !dx || !dy || !workspace) return set_error(CLIBD_EINVAL, "softce_bwd: null pointer");
+    if (!labels || !dx || !dy || !workspace || !scale) return set_error(CLIBD_EINVAL, "softce_bwd: null pointer");
     if (Nx <= 0 || N <= 0 || D <= 0 || D % 64 != 0 || N % 4 != 0 || row0 < 0 || row0 + Nx > N)
         return set_error(CLIBD_EINVAL, "softce_bwd: bad shape");
     if (!aligned16(workspace) || !aligned16(dx) || !aligned16(dy)) return set_error(CLIBD_EINVAL, "softce_bwd: alignment");
@@ -187,7 +193,7 @@ extern "C" int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D
     hipStream_t st = (hipStream_t)stream;
     const int Np = pad64(N), Nxp = pad64(Nx);
     hipLaunchKernelGGL(softce_rows_bwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, N, Nx, N, labels, row0, w.lse,
-                       w.tsum, weight, scale, w.G, Np, dscale);
+                       w.tsum, weight, weight_scale, scale, w.G, Np, dscale);
     if (int e = check_launch("softce_rows_bwd")) return e;
     // operand images: G^T [N,Nxp], xhi^T [D,Nxp], yhi^T [D,Np] (bf16, zero padded along the contraction)
     if (int e = clibd_transpose_bf16(w.G, Np, Nx, N, w.GT, Nxp, stream)) return e;

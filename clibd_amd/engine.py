@@ -1,0 +1,301 @@
+"""Tower engines: forward + hand-derived backward of the three CLIBD encoders on the HIP kernels.
+
+Each tower is ONE torch.autograd.Function (inputs = the trainable parameters, output = the tower's [B, D]
+embedding): the forward enqueues the fused kernels layer by layer and keeps exactly the activations the
+LoRA backward needs; the backward walks the layers in reverse (dgrad only for the frozen base weights,
+rank-4 adapter gradients, head weight gradients).  Numerics follow torch.autocast(bf16) in the reference
+(epoch/train_epoch.py:42-46): bf16 GEMM/attention operands with fp32 accumulation, fp32 residual stream,
+fp32 LayerNorm / softmax statistics.
+
+Reference arithmetic being replaced (all third-party model code the reference delegates to):
+  ViT block        timm vision_transformer.Block       via model/image_encoder.py:106-107
+  BERT layer       HF BertLayer (post-LN)              via model/dna_encoder.py:137, language_encoder.py:89
+  LoRA             model/image_encoder.py:40-46, model/dna_encoder.py:75-77
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class NotSupportedYet(NotImplementedError):
+    pass
+
+
+@dataclass
+class LoraParams:
+    """The four adapter matrices of one layer (nn.Parameters, fp32): a_* [4,H], b_* [H,4]."""
+    a_q: torch.nn.Parameter
+    b_q: torch.nn.Parameter
+    a_v: torch.nn.Parameter
+    b_v: torch.nn.Parameter
+
+    def tensors(self):
+        return [self.a_q, self.b_q, self.a_v, self.b_v]
+
+
+@dataclass
+class LayerSpec:
+    """Parameter handles of one transformer layer (fp32 masters living in the nn.Module tree)."""
+    qkv_w: Sequence[torch.Tensor]   # one fused [3H,H] tensor or (q,k,v) [H,H] each
+    qkv_b: Sequence[torch.Tensor]
+    proj_w: torch.Tensor
+    proj_b: torch.Tensor
+    fc1_w: torch.Tensor
+    fc1_b: torch.Tensor
+    fc2_w: torch.Tensor
+    fc2_b: torch.Tensor
+    ln1_w: torch.Tensor             # ViT: norm1 (before attention).  BERT: attention.output.LayerNorm
+    ln1_b: torch.Tensor
+    ln2_w: torch.Tensor             # ViT: norm2 (before MLP).        BERT: output.LayerNorm
+    ln2_b: torch.Tensor
+    lora: Optional[LoraParams] = None
+
+    def frozen(self):
+        return [*self.qkv_w, *self.qkv_b, self.proj_w, self.proj_b, self.fc1_w, self.fc1_b, self.fc2_w, self.fc2_b, self.ln1_w,
+                self.ln1_b, self.ln2_w, self.ln2_b]
+
+
+class _LayerCache:
+    """bf16 device images of one layer's frozen weights: W [N,K] for forward, W^T [K,N] for dgrad."""
+    __slots__ = ("wqkv", "wqkv_t", "bqkv", "wo", "wo_t", "bo", "w1", "w1_t", "b1", "w2", "w2_t", "b2", "g1", "be1", "g2", "be2",
+                 "v_fwd", "v_bwd", "a_cat", "w_dt")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    return t if (t.dtype == F32 and t.is_contiguous()) else t.to(F32).contiguous()
+
+
+class TransformerStack:
+    """Shared machinery of the ViT (pre-LN) and BERT (post-LN) encoder stacks."""
+
+    def __init__(self, layers: List[LayerSpec], hidden: int, heads: int, pre_ln: bool, eps: float):
+        if hidden != heads * 64:
+            raise NotSupportedYet(f"attention kernel is specialised for head_dim 64 (hidden={hidden}, heads={heads})")
+        if hidden % 64 or hidden > 1024:
+            raise NotSupportedYet("hidden size must be a multiple of 64 and <= 1024")
+        self.layers, self.H, self.heads, self.pre_ln, self.eps = layers, hidden, heads, pre_ln, eps
+        self.FF = layers[0].fc1_w.shape[0]
+        self._cache: List[_LayerCache] = []
+        self._cache_key = None
+
+    # ---- frozen-weight images ---------------------------------------------------------------------------------
+    def _key(self):
+        k = 0
+        for L in self.layers:
+            for p in L.frozen():
+                k += p._version + (p.data_ptr() & 0xFFFF)
+        return (k, self.layers[0].proj_w.device)
+
+    def check_frozen(self):
+        for L in self.layers:
+            for p in L.frozen():
+                if p.requires_grad:
+                    raise NotSupportedYet(
+                        "base (non-LoRA) encoder weights require grad: full fine-tuning (disable_lora) is not implemented "
+                        "on the HIP path yet (SURVEY §8f-4); freeze the base weights")
+
+    def refresh(self):
+        key = self._key()
+        if key == self._cache_key:
+            return
+        self._cache = []
+        with torch.no_grad():
+            for L in self.layers:
+                c = _LayerCache()
+                wqkv = _f32c(L.qkv_w[0]) if len(L.qkv_w) == 1 else torch.cat([_f32c(w) for w in L.qkv_w], dim=0)
+                c.wqkv, c.wqkv_t = ops.cast_bf16(wqkv), ops.cast_transpose_bf16(wqkv)
+                c.bqkv = _f32c(L.qkv_b[0]).clone() if len(L.qkv_b) == 1 else torch.cat([_f32c(b) for b in L.qkv_b], dim=0)
+                c.wo, c.wo_t, c.bo = ops.cast_bf16(_f32c(L.proj_w)), ops.cast_transpose_bf16(_f32c(L.proj_w)), _f32c(L.proj_b)
+                c.w1, c.w1_t, c.b1 = ops.cast_bf16(_f32c(L.fc1_w)), ops.cast_transpose_bf16(_f32c(L.fc1_w)), _f32c(L.fc1_b)
+                c.w2, c.w2_t, c.b2 = ops.cast_bf16(_f32c(L.fc2_w)), ops.cast_transpose_bf16(_f32c(L.fc2_w)), _f32c(L.fc2_b)
+                c.g1, c.be1, c.g2, c.be2 = _f32c(L.ln1_w), _f32c(L.ln1_b), _f32c(L.ln2_w), _f32c(L.ln2_b)
+                c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = None
+                self._cache.append(c)
+        self._cache_key = key
+
+    def pack_lora(self):
+        """Per step: adapter parameters are trainable, so their bf16 operand images are rebuilt."""
+        H = self.H
+        for L, c in zip(self.layers, self._cache):
+            if L.lora is None:
+                continue
+            if c.v_fwd is None:
+                dev = L.proj_w.device
+                c.v_fwd = torch.empty((3 * H, 8), dtype=BF16, device=dev)
+                c.v_bwd = torch.empty((H, 8), dtype=BF16, device=dev)
+                c.a_cat = torch.empty((8, H), dtype=BF16, device=dev)
+                c.w_dt = torch.empty((16, 3 * H), dtype=BF16, device=dev)
+            lp = L.lora
+            ops.lora_pack(_f32c(lp.a_q), _f32c(lp.a_v), _f32c(lp.b_q), _f32c(lp.b_v), c.v_fwd, c.v_bwd, c.a_cat, c.w_dt)
+
+    def lora_a(self, i: int):
+        if i >= len(self.layers) or self.layers[i].lora is None:
+            return None
+        return self._cache[i].a_cat
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool):
+        """x_f32 [M,H] residual stream entering layer 0.  Post-LN stacks also pass its bf16 image and the layer-0
+        adapter down-projection t0 (both produced by the embedding LayerNorm).  Returns (x_f32, x_bf16, saved)."""
+        H, FF, M = self.H, self.FF, B * S
+        dev = x_f32.device
+        saved = []
+        new = lambda cols, dt: torch.empty((M, cols), dtype=dt, device=dev)
+        o = new(H, BF16)          # attention output (temporary, reused by every layer)
+        a = new(FF, BF16)         # post-GELU activation (temporary)
+        xn2 = new(H, BF16) if self.pre_ln else None
+        t = t0
+        for i, (L, c) in enumerate(zip(self.layers, self._cache)):
+            has_lora = L.lora is not None
+            rec = {}
+            if self.pre_ln:
+                # xn = LN1(x) (+ t = xn·A^T);  qkv = xn Wqkv^T + b + t·B^T
+                xn = new(H, BF16)
+                st1 = torch.empty((M, 2), dtype=F32, device=dev)
+                t = torch.empty((M, 8), dtype=BF16, device=dev) if has_lora else None
+                ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
+                qkv = new(3 * H, BF16)
+                ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
+                ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
+                x1 = new(H, F32)
+                ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
+                st2 = torch.empty((M, 2), dtype=F32, device=dev)
+                ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
+                h = new(FF, BF16)
+                ops.gemm_nt(xn2, c.w1, bias=c.b1, act=ops.ACT_GELU, out_pre=h, out_bf16=a)
+                x2 = new(H, F32)
+                ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1, out_f32=x2)
+                if save:
+                    rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h)
+                x_f32 = x2
+            else:
+                qkv = new(3 * H, BF16)
+                ops.gemm_nt(x_bf16, c.wqkv, bias=c.bqkv, rank_u=t if has_lora else None, rank_v=c.v_fwd if has_lora else None,
+                            out_bf16=qkv)
+                ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
+                s1 = new(H, F32)
+                ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=s1)
+                x1_f32, x1_bf16 = new(H, F32), new(H, BF16)
+                st1 = torch.empty((M, 2), dtype=F32, device=dev)
+                ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_bf16=x1_bf16, y_f32=x1_f32, stats=st1)
+                h = new(FF, BF16)
+                ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU, out_pre=h, out_bf16=a)
+                s2 = new(H, F32)
+                ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1_f32, out_f32=s2)
+                x2_f32, x2_bf16 = new(H, F32), new(H, BF16)
+                st2 = torch.empty((M, 2), dtype=F32, device=dev)
+                nxt = self.lora_a(i + 1)
+                t_next = torch.empty((M, 8), dtype=BF16, device=dev) if nxt is not None else None
+                ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next)
+                if save:
+                    rec = dict(x_bf16=x_bf16, t=t if has_lora else None, qkv=qkv, s1=s1, st1=st1, h=h, s2=s2, st2=st2)
+                x_f32, x_bf16, t = x2_f32, x2_bf16, t_next
+            saved.append(rec)
+        return x_f32, x_bf16, saved
+
+    # ---- backward -----------------------------------------------------------------------------------------------
+    def backward(self, dx_f32, dx_bf16, saved, B: int, S: int, key_mask, grads: dict):
+        """dx = gradient w.r.t. the stack output (fp32 residual stream; pre-LN also needs its bf16 image).
+        Fills grads[id(param)] for the adapters.  The input embeddings are frozen, so nothing is returned."""
+        H, FF, M = self.H, self.FF, B * S
+        dev = dx_f32.device
+        new = lambda cols, dt: torch.empty((M, cols), dtype=dt, device=dev)
+        dh = new(FF, BF16)
+        dtmp = new(H, BF16)
+        dqkv = new(3 * H, BF16)
+        dt = torch.empty((M, 16), dtype=BF16, device=dev)
+        first_lora = min((i for i, L in enumerate(self.layers) if L.lora is not None), default=len(self.layers))
+        for i in range(len(self.layers) - 1, -1, -1):
+            L, c, rec = self.layers[i], self._cache[i], saved[i]
+            has_lora = L.lora is not None
+            if i < first_lora:
+                break  # nothing trainable at or below this layer
+            if self.pre_ln:
+                ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_GELU_GRAD, aux=rec["h"], out_bf16=dh)          # d(fc1 out)
+                ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
+                dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
+                ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16)
+                ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtmp)                                             # d(attn out)
+                ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv)
+                if has_lora:
+                    self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads)
+                if i > first_lora:
+                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
+                    ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
+                    ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16)
+                    dx_f32, dx_bf16 = ndx_f32, ndx_bf16
+            else:
+                ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
+                ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16)
+                ops.gemm_nt(ds2_bf16, c.w2_t, act=ops.ACT_GELU_GRAD, aux=rec["h"], out_bf16=dh)
+                dx1 = new(H, F32)
+                ops.gemm_nt(dh, c.w1_t, residual=ds2_f32, out_f32=dx1)
+                ds1_f32, ds1_bf16 = new(H, F32), new(H, BF16)
+                ops.layernorm_bwd(dx1, rec["s1"], rec["st1"], c.g1, dx_f32=ds1_f32, dx_bf16=ds1_bf16)
+                ops.gemm_nt(ds1_bf16, c.wo_t, out_bf16=dtmp)
+                ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv)
+                if has_lora:
+                    self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads)
+                if i > first_lora:
+                    ndx = new(H, F32)
+                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
+                                residual=ds1_f32, out_f32=ndx)
+                    dx_f32 = ndx
+
+    def _lora_grads(self, L, c, dqkv, x_bf16, t, dt, grads):
+        H = self.H
+        ops.gemm_nt(dqkv, c.w_dt, out_bf16=dt)  # dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v
+        lp = L.lora
+        ops.lora_wgrad(dqkv, x_bf16, t, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
+
+
+class GradBucket:
+    """One flat, zero-initialised fp32 buffer holding the gradients of a tower's trainable parameters."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros((max(n, 1),), dtype=F32, device=dev)
+        self.views, off = {}, 0
+        for p in self.params:
+            self.views[id(p)] = self.flat[off : off + p.numel()].view(p.shape)
+            off += p.numel()
+
+    def ordered(self):
+        return [self.views[id(p)] for p in self.params]
+
+
+def dense_head_backward(dout_f32: torch.Tensor, x_bf16: torch.Tensor, weight: torch.nn.Parameter, bias: torch.nn.Parameter,
+                        grads: dict, out_bf16: bool):
+    """y = x W^T + b with a TRAINABLE W [D,K]:  dW += dy^T x, db += colsum(dy), returns dx = dy W.
+    dout_f32 [M,D] fp32 (M small: one row per sample) or bf16 [M,D]."""
+    dy_b = ops.cast_bf16(dout_f32) if dout_f32.dtype == F32 else dout_f32
+    M, D = dy_b.shape
+    K = x_bf16.shape[1]
+    dyT = ops.transpose_bf16(dy_b)          # [D, Mp]
+    xT = ops.transpose_bf16(x_bf16)         # [K, Mp]
+    Mp = dyT.shape[1]
+    split = max(1, min(32, Mp // 2048))
+    gw = grads[id(weight)]
+    if split > 1:
+        ops.gemm_nt(dyT, xT, out_f32=gw, split_k=split)      # atomically accumulates into the zeroed bucket
+    else:
+        ops.gemm_nt(dyT, xT, out_f32=gw, residual=gw)        # accumulate in place
+    ops.colsum_bf16(dy_b, grads[id(bias)])
+    w_t = ops.cast_transpose_bf16(_f32c(weight))   # [K, D]
+    if out_bf16:
+        dx = torch.empty((M, K), dtype=BF16, device=dy_b.device)
+        ops.gemm_nt(dy_b, w_t, out_bf16=dx)
+    else:
+        dx = torch.empty((M, K), dtype=F32, device=dy_b.device)
+        ops.gemm_nt(dy_b, w_t, out_f32=dx)
+    return dx

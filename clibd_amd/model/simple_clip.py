@@ -1,0 +1,133 @@
+"""`SimpleCLIP` and `load_clip_model`: drop-in for `bioscanclip.model.simple_clip` (reference
+model/simple_clip.py:21-61, 100-246) on the MI355X HIP engine.
+
+forward(image_input, dna_input, language_input) ->
+    (image_output, dna_output, language_output, logit_scale.exp(), logit_bias)
+with every present tower output L2-normalised (K8 kernel) and `None` for absent towers — the reference contract.
+The open_clip / BioCLIP branches of the reference (simple_clip.py:137-146) are outside the hot path
+and raise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .dna_encoder import CLIBDDNAEncoder, load_pre_trained_bioscan_bert
+from .image_encoder import CLIBDImageEncoder, create_vit
+from .language_encoder import CLIBDLanguageEncoder, load_pre_trained_bert
+
+F32 = torch.float32
+
+
+class _L2NormFn(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=-1) (simple_clip.py:45,58,60)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = ops.l2norm_fwd(x.detach().to(F32).contiguous())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return ops.l2norm_bwd(dy.to(F32).contiguous(), y, inv)
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    return _L2NormFn.apply(x)
+
+
+class SimpleCLIP(nn.Module):
+    def __init__(self, image_encoder, dna_encoder, language_encoder, open_clip_model=None, init_logit_scale: float = np.log(1 / 0.07),
+                 init_logit_bias: Optional[float] = None, for_bio_clip=False):
+        super().__init__()
+        if open_clip_model is not None or for_bio_clip:
+            raise NotImplementedError("open_clip / BioCLIP towers are not part of the MI355X hot path (SURVEY §2, row 3)")
+        self.image_encoder = image_encoder
+        self.dna_encoder = dna_encoder
+        self.language_encoder = language_encoder
+        self.open_clip_model = None
+        self.tokenizer_for_open_clip = None
+        self.logit_scale = nn.Parameter(torch.ones([]) * init_logit_scale)
+        if init_logit_bias is not None:
+            self.logit_bias = nn.Parameter(torch.ones([]) * init_logit_bias)
+        else:
+            self.logit_bias = None
+
+    def forward(self, image_input, dna_input, language_input):
+        image_output = dna_output = language_output = None
+        if self.dna_encoder is not None:
+            dna_output = l2_normalize(self.dna_encoder(dna_input))
+        if self.image_encoder is not None:
+            image_output = l2_normalize(self.image_encoder(image_input))
+        if self.language_encoder is not None:
+            language_output = l2_normalize(self.language_encoder(language_input))
+        return image_output, dna_output, language_output, self.logit_scale.exp(), self.logit_bias
+
+
+def _get(cfg, name, default=None):
+    return getattr(cfg, name) if hasattr(cfg, name) else default
+
+
+def load_clip_model(args, device=None):
+    """Factory with the reference's flag semantics (`args.model_config.*`, simple_clip.py:100-246), including its quirks:
+    `using_open_clip` overwrites `disable_lora` (simple_clip.py:114-116); the image tower treats `lora_layer=[]` as "all
+    layers" while the BERT towers treat it as "none" (SURVEY §3.4).  Pretrained weights come from LOCAL checkpoints only
+    (`args.bioscan_bert_checkpoint`, `args.model_config.image.vit_checkpoint`); absent ones mean random initialisation."""
+    mc = args.model_config
+    disable_lora = bool(_get(mc, "disable_lora", False))
+    if hasattr(mc, "using_open_clip"):
+        disable_lora = bool(mc.using_open_clip)
+    image_cfg, lang_cfg, dna_cfg = _get(mc, "image"), _get(mc, "language"), _get(mc, "dna")
+    image_model = _get(image_cfg, "model") if image_cfg is not None else None
+    language_model = _get(lang_cfg, "model") if lang_cfg is not None else None
+    if _get(mc, "for_bio_clip", False) or (image_model == "lora_clip_image" and language_model == "lora_clip_text"):
+        raise NotImplementedError("open_clip / BioCLIP towers are not part of the MI355X hot path (SURVEY §2, row 3)")
+    out_dim = mc.output_dim
+
+    image_encoder = dna_encoder = language_encoder = None
+    if image_cfg is not None:
+        if _get(image_cfg, "input_type", "image") != "image":
+            raise NotImplementedError("pre-extracted feature (MLP) towers are out of scope (SURVEY §2 row 8)")
+        vit = create_vit(_get(image_cfg, "pre_train_model", "vit_base_patch16_224"))
+        ck = _get(image_cfg, "vit_checkpoint")
+        if ck:
+            sd = torch.load(ck, map_location="cpu", weights_only=False)
+            sd = sd.get("state_dict", sd)
+            vit.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}, strict=False)
+        image_encoder = CLIBDImageEncoder(vit_model=vit, r=4, num_classes=out_dim, lora_layer=[] if disable_lora else None)
+    if lang_cfg is not None:
+        if _get(lang_cfg, "input_type", "sequence") != "sequence":
+            raise TypeError(f"Using {lang_cfg.input_type} as language input is not support yet.")
+        _, bert = load_pre_trained_bert(_get(lang_cfg, "pre_train_model", "prajjwal1/bert-small"))
+        language_encoder = CLIBDLanguageEncoder(model=bert, r=4, num_classes=out_dim, lora_layer=[] if disable_lora else None)
+    if dna_cfg is not None:
+        if _get(dna_cfg, "input_type", "sequence") != "sequence":
+            raise NotImplementedError("pre-extracted feature (MLP) towers are out of scope (SURVEY §2 row 8)")
+        ckpt = _get(args, "bioscan_bert_checkpoint")
+        pre = _get(mc, "pre_train_for_barcode_bert")
+        if pre == "BIOSCAN-5M":
+            ckpt = _get(args, "bioscan_bert_checkpoint_trained_with_bioscan_5_m", ckpt)
+        elif pre == "CANADA-1-5M":
+            ckpt = _get(args, "bioscan_bert_checkpoint_trained_with_canada_1_5_m", ckpt)
+        import os
+
+        bert = load_pre_trained_bioscan_bert(ckpt if (ckpt and os.path.exists(str(ckpt))) else None)
+        dna_encoder = CLIBDDNAEncoder(model=bert, r=4, num_classes=out_dim, lora_layer=[] if disable_lora else None)
+
+    model = SimpleCLIP(image_encoder=image_encoder, dna_encoder=dna_encoder, language_encoder=language_encoder)
+    if device is not None:
+        model.to(device)
+    if disable_lora:
+        for p in model.parameters():
+            p.requires_grad = True  # full fine-tune: the HIP towers raise NotSupportedYet at the first training step
+    for cfg, enc in ((image_cfg, model.image_encoder), (dna_cfg, model.dna_encoder), (lang_cfg, model.language_encoder)):
+        if cfg is not None and _get(cfg, "freeze", False) and enc is not None:
+            for p in enc.parameters():
+                p.requires_grad = False
+    return model

@@ -232,12 +232,29 @@ def patchify(image: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def vit_cls_rows(cls: torch.Tensor, pos: torch.Tensor, tok: torch.Tensor) -> None:
-    B, S, H = tok.shape
+def vit_assemble_tokens(proj: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, B: int) -> torch.Tensor:
+    """tok[b,0] = cls + pos[0]; tok[b,1+p] = proj[b*P+p] + pos[1+p]  -> fp32 [B,S,H]"""
+    _chk(proj, F32, "proj")
     _chk(cls, F32, "cls")
     _chk(pos, F32, "pos")
-    _chk(tok, F32, "tok")
-    check(_lib.load().clibd_vit_cls_rows(cls.data_ptr(), pos.data_ptr(), B, S, H, tok.data_ptr(), _stream()), "vit_cls_rows")
+    H = proj.shape[1]
+    S = pos.numel() // H
+    if proj.shape[0] != B * (S - 1) or cls.numel() != H:
+        raise ValueError("vit_assemble_tokens: shapes")
+    tok = torch.empty((B, S, H), dtype=F32, device=proj.device)
+    check(_lib.load().clibd_vit_assemble_tokens(proj.data_ptr(), cls.data_ptr(), pos.data_ptr(), B, S, H, tok.data_ptr(), _stream()),
+          "vit_assemble_tokens")
+    return tok
+
+
+def gelu_bwd(dy: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
+    _chk(dy, BF16, "dy")
+    _chk(pre, BF16, "pre")
+    if dy.shape != pre.shape:
+        raise ValueError("gelu_bwd: shapes")
+    dx = torch.empty_like(dy)
+    check(_lib.load().clibd_gelu_bwd_bf16(dy.data_ptr(), pre.data_ptr(), dy.numel(), dx.data_ptr(), _stream()), "gelu_bwd")
+    return dx
 
 
 def bert_embed(ids, token_type, word, pos, typ, out) -> None:
@@ -336,7 +353,9 @@ def softce_workspace(Nx: int, N: int, D: int, device) -> torch.Tensor:
     return torch.empty((nbytes,), dtype=torch.uint8, device=device)
 
 
-def softce_rows_fwd(x, y, labels, row0: int, scale: float, loss_sum: torch.Tensor, ws: torch.Tensor) -> None:
+def softce_rows_fwd(x, y, labels, row0: int, scale: torch.Tensor, loss_sum: torch.Tensor, ws: torch.Tensor) -> None:
+    """`scale` is a 1-element fp32 DEVICE tensor (no host sync on the temperature)."""
+    _chk(scale, F32, "scale")
     _chk(x, F32, "x")
     _chk(y, F32, "y")
     _chk(labels, I64, "labels")
@@ -345,19 +364,20 @@ def softce_rows_fwd(x, y, labels, row0: int, scale: float, loss_sum: torch.Tenso
     N = y.shape[0]
     if y.shape[1] != D or labels.numel() != N:
         raise ValueError("softce_rows_fwd: shapes")
-    check(_lib.load().clibd_softce_rows_fwd(x.data_ptr(), y.data_ptr(), labels.data_ptr(), Nx, N, D, row0, float(scale),
+    check(_lib.load().clibd_softce_rows_fwd(x.data_ptr(), y.data_ptr(), labels.data_ptr(), Nx, N, D, row0, scale.data_ptr(),
                                             loss_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "softce_rows_fwd")
 
 
-def softce_rows_bwd(labels, Nx, N, D, row0, scale, weight, dx, dy, dscale, ws) -> None:
+def softce_rows_bwd(labels, Nx, N, D, row0, scale, weight, dx, dy, dscale, ws, weight_scale=None) -> None:
     _chk(labels, I64, "labels")
+    _chk(scale, F32, "scale")
     _chk(dx, F32, "dx")
     _chk(dy, F32, "dy")
     if tuple(dx.shape) != (Nx, D) or tuple(dy.shape) != (N, D):
         raise ValueError("softce_rows_bwd: shapes")
     if dscale is not None:
         _chk(dscale, F32, "dscale")
-    check(_lib.load().clibd_softce_rows_bwd(labels.data_ptr(), Nx, N, D, row0, float(scale), float(weight), dx.data_ptr(), dy.data_ptr(),
+    check(_lib.load().clibd_softce_rows_bwd(labels.data_ptr(), Nx, N, D, row0, scale.data_ptr(), float(weight), _p(weight_scale), dx.data_ptr(), dy.data_ptr(),
                                             _p(dscale), ws.data_ptr(), ws.numel(), _stream()), "softce_rows_bwd")
 
 

@@ -131,12 +131,13 @@ int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf16, const vo
  * Embeddings.
  * K1 patch gather (timm PatchEmbed: Conv2d(3,H,16,16) == GEMM over 16x16x3 patches):
  *   patches bf16 [B*196, 768] with k = c*256 + py*16 + px  from image fp32 [B,3,224,224].
- * ViT token assembly: tok fp32 [B,197,H]: row 0 = cls + pos[0]; rows 1.. = patch_proj + pos[1+p]
- *   (timm VisionTransformer._pos_embed).  Done by the GEMM epilogue (residual = pos) + clibd_vit_cls_rows.
+ * ViT token assembly: tok fp32 [B,S,H]: row 0 = cls + pos[0]; rows 1.. = patch_proj[b*(S-1)+p] + pos[1+p]
+ *   (timm VisionTransformer._pos_embed).
  * BERT embeddings: word[id] + position[s] + token_type[tt] (HF BertEmbeddings) -> fp32 [B*S,H] (pre-LN sum).
  * ------------------------------------------------------------------------------------------------ */
 int clibd_patchify(const float* image, int B, void* patches_bf16, void* stream);
-int clibd_vit_cls_rows(const float* cls, const float* pos, int B, int S, int H, float* tok, void* stream);
+int clibd_vit_assemble_tokens(const float* proj, const float* cls, const float* pos, int B, int S, int H, float* tok,
+                              void* stream);
 int clibd_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int S, int H, int vocab,
                      const float* word, const float* pos, const float* type, float* out, void* stream);
 
@@ -150,6 +151,8 @@ int clibd_softmax_mean_bwd(const void* logits, const float* dout, int B, int S, 
 /* token mean (model/language_encoder.py:89 `.last_hidden_state.mean(dim=1)`): x fp32 [B,S,H] -> bf16/fp32 [B,H] */
 int clibd_token_mean_fwd(const float* x, int B, int S, int H, void* out_bf16, void* stream);
 int clibd_token_mean_bwd(const float* dout, int B, int S, int H, float* dx, void* stream);
+/* dx = dy * gelu'(pre), bf16 in/out, n % 4 == 0 (HF BertPredictionHeadTransform: dense -> gelu -> LayerNorm) */
+int clibd_gelu_bwd_bf16(const void* dy, const void* pre, size_t n, void* dx, void* stream);
 /* column sums of a bf16 [M,N] matrix into fp32 [N] (bias gradients of the trainable heads; accumulates) */
 int clibd_colsum_bf16(const void* x, int ld, int M, int N, float* out, void* stream);
 /* gather / scatter the [CLS] rows: x fp32 [B,S,H] row 0 <-> [B,H] */
@@ -174,15 +177,15 @@ int clibd_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int
  * The product runs on bf16 MFMA with split operands (hi+lo, three partial products in one K=3D GEMM), which
  * is ~fp32-accurate like the reference's fp32 matmul outside autocast.  Full N x N semantics: Nx=N,row0=0,
  * called once per direction (x=a,y=b) and (x=b,y=a).  Data-parallel: each rank passes its own row block.
- * bwd must follow fwd on the same workspace:  g = weight * dloss_sum/dS;
+ * bwd must follow fwd on the same workspace:  g = weight * (*weight_scale) * dloss_sum/dS;
  *   dx [Nx,D] += scale * g·y,  dy [N,D] += scale * g^T·x  (fp32, ACCUMULATED),  *dscale += sum g∘(x·y^T).
  * D % 64 == 0, N % 4 == 0.
  * ------------------------------------------------------------------------------------------------ */
 size_t clibd_softce_workspace_bytes(int Nx, int N, int D);
 int clibd_softce_rows_fwd(const float* x, const float* y, const int64_t* labels, int Nx, int N, int D, int row0,
-                          float scale, float* loss_sum, void* workspace, size_t workspace_bytes, void* stream);
-int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D, int row0, float scale, float weight,
-                          float* dx, float* dy, float* dscale, void* workspace, size_t workspace_bytes,
+                          const float* scale /* device scalar */, float* loss_sum, void* workspace, size_t workspace_bytes, void* stream);
+int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D, int row0, const float* scale, float weight,
+                          const float* weight_scale /* optional device scalar multiplied into weight */, float* dx, float* dy, float* dscale, void* workspace, size_t workspace_bytes,
                           void* stream);
 
 /* fused AdamW step on a flat fp32 parameter bucket (torch.optim.AdamW semantics, scripts/train_cl.py:221):

@@ -1,0 +1,235 @@
+"""Module-level parity (GPU): the drop-in `clibd_amd.model` classes on the HIP kernels against
+  (1) the committed golden vectors generated from the reference's own classes (fp32 CPU path), and
+  (2) the CPU oracle run with the kernels' bf16 rounding points (tight tolerance).
+Tolerances: tower outputs / loss within 1e-3 of the bf16-emulating oracle (north-star bf16 tolerance);
+gradients rel-L2 <= 2e-2 and cosine >= 0.999 (SURVEY §8d parity gates)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(G, name), map_location="cpu", weights_only=False)
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def grads_named(module, loss):
+    ps = {n: p for n, p in module.named_parameters() if p.requires_grad}
+    gs = torch.autograd.grad(loss, list(ps.values()), allow_unused=True)
+    return {n: (torch.zeros_like(p) if g is None else g).detach().cpu() for (n, p), g in zip(ps.items(), gs)}
+
+
+def assert_grads(got, ref, rel_tol=2e-2, cos_tol=0.999, what=""):
+    assert sorted(got) == sorted(ref)
+    for n in ref:
+        r = ref[n]
+        if r.abs().max() < 1e-9:
+            assert got[n].abs().max() < 1e-6, (what, n)
+            continue
+        assert rel(got[n], r) < rel_tol, (what, n, rel(got[n], r))
+        assert cos(got[n], r) > cos_tol, (what, n, cos(got[n], r))
+
+
+# ------------------------------------------------------------------------------------------ builders
+def hip_dna(gd, dev):
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder
+
+    c = gd["config"]
+    m = CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, **c)), r=4, num_classes=128)
+    m.load_state_dict(gd["state_dict"], strict=True)
+    return m.to(dev)
+
+
+def hip_text(gt, dev):
+    from clibd_amd.model import BertConfigLite, BertModel, CLIBDLanguageEncoder
+
+    m = CLIBDLanguageEncoder(BertModel(BertConfigLite(vocab_size=gt["vocab"], **gt["config"])), r=4, num_classes=128)
+    m.load_state_dict(gt["state_dict"], strict=True)
+    return m.to(dev)
+
+
+def hip_image(gi, dev):
+    from clibd_amd.model import CLIBDImageEncoder, VisionTransformer
+
+    c = gi["config"]
+    m = CLIBDImageEncoder(VisionTransformer(embed_dim=c["dim"], depth=c["depth"], num_heads=c["heads"], num_classes=10), r=4, num_classes=128)
+    m.load_state_dict(gi["state_dict"], strict=True)
+    return m.to(dev)
+
+
+def oracle_models():
+    from tests.test_oracle import build_dna, build_image, build_text
+
+    return build_dna, build_text, build_image
+
+
+# ------------------------------------------------------------------------------------------ towers
+def test_dna_tower_parity(dev):
+    from oracle import clibd_oracle as O
+
+    gd = load("dna_tiny_golden.pt")
+    m = hip_dna(gd, dev)
+    y = m(gd["ids"].to(dev))
+    assert y.shape == (4, 128) and y.dtype == torch.float32
+    assert torch.allclose(y.sum(1).cpu(), torch.ones(4), atol=1e-4)
+    got = grads_named(m, (y * gd["cot"].to(dev)).sum())
+    build_dna, _, _ = oracle_models()
+    om = build_dna(gd)
+    with O.precision("bf16"):
+        yo = om(gd["ids"])
+        go = {n: g for n, g in zip([n for n, p in om.named_parameters() if p.requires_grad],
+                                   torch.autograd.grad((yo * gd["cot"]).sum(), [p for p in om.parameters() if p.requires_grad]))}
+    # (2) bf16-emulating oracle: tight
+    assert (y.cpu() - yo.detach()).abs().max().item() < 1e-3 * yo.abs().max().item() + 1e-5
+    assert rel(y.cpu(), yo.detach()) < 3e-3
+    assert_grads(got, go, what="dna vs oracle-bf16")
+    # (1) reference fp32 golden: bf16 tolerance
+    assert rel(y.cpu(), gd["out"]) < 2e-2
+    assert_grads(got, gd["grads"], rel_tol=5e-2, cos_tol=0.998, what="dna vs reference fp32")
+
+
+def test_text_tower_parity_with_padding_mask(dev):
+    from oracle import clibd_oracle as O
+
+    gt = load("text_tiny_golden.pt")
+    m = hip_text(gt, dev)
+    x = {k: v.to(dev) for k, v in gt["inputs"].items()}
+    y = m(x)
+    got = grads_named(m, (y * gt["cot"].to(dev)).sum())
+    _, build_text, _ = oracle_models()
+    om = build_text(gt)
+    with O.precision("bf16"):
+        yo = om(gt["inputs"])
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * gt["cot"]).sum(), [p for _, p in ps])))
+    assert rel(y.cpu(), yo.detach()) < 3e-3
+    assert_grads(got, go, what="text vs oracle-bf16")
+    assert rel(y.cpu(), gt["out"]) < 2e-2
+    assert_grads(got, gt["grads"], rel_tol=5e-2, cos_tol=0.998, what="text vs reference fp32")
+
+
+def test_image_tower_parity(dev):
+    from oracle import clibd_oracle as O
+
+    gi = load("image_tiny_golden.pt")
+    m = hip_image(gi, dev)
+    img = gi["image_u8"].float() / 255.0
+    y = m(img.to(dev))
+    got = grads_named(m, (y * gi["cot"].to(dev)).sum())
+    _, _, build_image = oracle_models()
+    om = build_image(gi)
+    with O.precision("bf16"):
+        yo = om(img)
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * gi["cot"]).sum(), [p for _, p in ps])))
+    assert rel(y.cpu(), yo.detach()) < 3e-3
+    assert_grads(got, go, what="image vs oracle-bf16")
+    assert rel(y.cpu(), gi["out"]) < 2e-2
+    assert_grads(got, gi["grads"], rel_tol=5e-2, cos_tol=0.998, what="image vs reference fp32")
+
+
+def test_towers_eval_mode_and_no_grad(dev):
+    gd = load("dna_tiny_golden.pt")
+    m = hip_dna(gd, dev).eval()
+    with torch.no_grad():
+        y = m(gd["ids"].to(dev))
+    assert not y.requires_grad and rel(y.cpu(), gd["out"]) < 2e-2
+
+
+def test_frozen_base_weights_are_required(dev):
+    from clibd_amd.engine import NotSupportedYet
+
+    gd = load("dna_tiny_golden.pt")
+    m = hip_dna(gd, dev)
+    for p in m.parameters():
+        p.requires_grad = True  # disable_lora-style full fine-tune: next row, must fail loudly
+    with pytest.raises(NotSupportedYet):
+        m(gd["ids"].to(dev))
+
+
+# ------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("i", range(7))
+def test_loss_modules_match_reference_goldens(dev, i):
+    from clibd_amd.model import ClipLoss, ContrastiveLoss
+
+    c = load("loss_golden.pt")["loss_cases"][i]
+    feats = [None if f is None else f.clone().to(dev).requires_grad_(True) for f in c["features"]]
+    ls = c["log_scale"].clone().to(dev).requires_grad_(True)
+    crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss(),
+                    bind_to=c["bind_to"], no_image_text_loss=c["no_image_text_loss"])
+    loss = crit(feats[0], feats[1], feats[2], c["labels"].to(dev), ls.exp())
+    assert abs(loss.item() - float(c["clip_loss"])) < 1e-3
+    present = [f for f in feats if f is not None]
+    gs = torch.autograd.grad(loss, present + [ls])
+    for g, r in zip(gs, c["clip_grads"]):
+        assert rel(g.cpu(), r) < 1e-2
+        assert cos(g.cpu(), r) > 0.9999
+    if "contrastive_loss" in c:
+        l2 = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)(feats[0], feats[1], feats[2], c["labels"].to(dev),
+                                                                                          ls.exp())
+        assert abs(l2.item() - float(c["contrastive_loss"])) < 1e-3
+
+
+def test_loss_known_answers_and_errors(dev):
+    from clibd_amd.model import ContrastiveLoss
+
+    ka = load("loss_golden.pt")["known_answers"]
+    crit = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)
+    a, b = ka["a"].to(dev), ka["b"].to(dev)
+    assert abs(crit(a, b, None, torch.arange(32, device=dev), 1 / 0.07).item() - 3.676485061645508) < 5e-4
+    assert abs(crit(a, b, None, (torch.arange(32) // 2).to(dev), None).item() - 7.247870445251465) < 5e-4
+    with pytest.raises(ValueError):
+        crit(a, None, None, torch.arange(32, device=dev), 1.0)
+
+
+# ------------------------------------------------------------------------------------------ full step
+@pytest.mark.parametrize("tag,use_text", [("id", False), ("idt", True)])
+def test_full_step_matches_reference(dev, tag, use_text):
+    from clibd_amd.model import ClipLoss, SimpleCLIP
+    from oracle import clibd_oracle as O
+
+    gs, gd, gt, gi = load("step_tiny_golden.pt"), load("dna_tiny_golden.pt"), load("text_tiny_golden.pt"), load("image_tiny_golden.pt")
+    model = SimpleCLIP(hip_image(gi, dev), hip_dna(gd, dev), hip_text(gt, dev)).to(dev)
+    with torch.no_grad():
+        model.logit_scale.copy_(gs["logit_scale"])
+    assert list(model.state_dict().keys()) == gs["state_dict_keys"]
+    img = (gs["image_u8"].float() / 255.0).to(dev)
+    text = {k: v.to(dev) for k, v in gs["text"].items()}
+    io, do_, to, scale, bias = model(img, gs["dna"].to(dev), text)
+    assert bias is None
+    crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+    loss = crit(io, do_, to if use_text else None, gs["labels"].to(dev), scale)
+    got = grads_named(model, loss)
+    # oracle with the kernels' rounding points
+    build_dna, build_text, build_image = oracle_models()
+    om = O.SimpleCLIP(build_image(gi), build_dna(gd), build_text(gt))
+    with torch.no_grad():
+        om.logit_scale.copy_(gs["logit_scale"])
+    with O.precision("bf16"):
+        oi, od, ot, osc, _ = om(gs["image_u8"].float() / 255.0, gs["dna"], gs["text"])
+        lo = O.contrastive_loss([oi, od, ot if use_text else None], gs["labels"], osc)
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], [torch.zeros_like(p) if g is None else g
+                                           for (_, p), g in zip(ps, torch.autograd.grad(lo, [p for _, p in ps], allow_unused=True))]))
+    for f, r in zip((io, do_, to), (oi, od, ot)):
+        assert (f.cpu() - r.detach()).abs().max().item() < 1e-3          # unit-norm embeddings: abs tolerance
+    assert abs(loss.item() - lo.item()) < 1e-3                           # north-star: loss within 1e-3 (bf16 tolerance)
+    assert_grads(got, go, what="step vs oracle-bf16")
+    # reference fp32 goldens
+    for f, r in zip((io, do_, to), gs[f"features_{tag}"]):
+        assert (f.cpu() - r).abs().max().item() < 5e-3
+    assert abs(loss.item() - float(gs[f"loss_{tag}"])) < 2e-2
+    assert_grads(got, gs[f"grads_{tag}"], rel_tol=6e-2, cos_tol=0.997, what="step vs reference fp32")

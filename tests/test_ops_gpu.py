@@ -285,15 +285,19 @@ def test_patchify_matches_conv_unfold(ops, dev):
     assert torch.equal(got.cpu().float(), bfr(ref))
 
 
-def test_vit_cls_rows_and_bert_embed(ops, dev):
+def test_vit_assemble_gelu_bwd_and_bert_embed(ops, dev):
     g = torch.Generator().manual_seed(13)
     B, S, H = 3, 5, 64
     cls, pos = torch.randn(H, generator=g), torch.randn(S, H, generator=g)
-    tok = torch.zeros((B, S, H), device=dev)
-    ops.vit_cls_rows(cls.to(dev), pos.to(dev), tok)
+    proj = torch.randn(B * (S - 1), H, generator=g)
+    tok = ops.vit_assemble_tokens(proj.to(dev), cls.to(dev), pos.to(dev), B)
     torch.cuda.synchronize()
-    assert torch.equal(tok.cpu()[:, 0], (cls + pos[0]).expand(B, H))
-    assert torch.equal(tok.cpu()[:, 1:], torch.zeros(B, S - 1, H))
+    ref = torch.cat([cls.expand(B, 1, H), proj.view(B, S - 1, H)], dim=1) + pos[None]
+    assert torch.equal(tok.cpu(), ref)
+    dyv, pre = bfr(torch.randn(40, 64, generator=g)), bfr(torch.randn(40, 64, generator=g) * 2)
+    dxv = ops.gelu_bwd(dyv.to(dev, BF16), pre.to(dev, BF16))
+    torch.cuda.synchronize()
+    assert rel_err(dxv.cpu().float(), dyv * gelu_grad(pre)) < 4e-3
     V = 50
     ids = torch.randint(0, V, (B, S), generator=g)
     tt = torch.randint(0, 2, (B, S), generator=g)
@@ -387,13 +391,14 @@ def test_softce_rows_fwd_bwd(ops, dev, Nx, N, row0, dup):
     gx, gy, gs = torch.autograd.grad(ref * w, (xd, yd, sd))
     ws = ops.softce_workspace(Nx, N, D, dev)
     loss = torch.zeros(1, device=dev)
-    ops.softce_rows_fwd(x.to(dev), y.to(dev), labels.to(dev), row0, scale, loss, ws)
+    sc = torch.tensor([scale], device=dev)
+    ops.softce_rows_fwd(x.to(dev), y.to(dev), labels.to(dev), row0, sc, loss, ws)
     torch.cuda.synchronize()
     assert abs(loss.item() - ref.item()) < 2e-4 * abs(ref.item()) + 1e-3
     dx = torch.zeros((Nx, D), device=dev)
     dy = torch.ones((N, D), device=dev)  # accumulate semantics
     ds = torch.zeros(1, device=dev)
-    ops.softce_rows_bwd(labels.to(dev), Nx, N, D, row0, scale, w, dx, dy, ds, ws)
+    ops.softce_rows_bwd(labels.to(dev), Nx, N, D, row0, sc, w, dx, dy, ds, ws)
     torch.cuda.synchronize()
     assert rel_err(dx.cpu(), gx) < 6e-3
     assert rel_err(dy.cpu() - 1, gy) < 6e-3

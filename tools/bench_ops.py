@@ -117,10 +117,11 @@ def main():
     lab = torch.arange(N, device=dev)
     ws = ops.softce_workspace(N, N, D, dev)
     loss = torch.zeros(1, device=dev)
-    ms = timeit(lambda: ops.softce_rows_fwd(xx, yy, lab, 0, 14.28, loss, ws))
+    sc = torch.tensor([14.28], device=dev)
+    ms = timeit(lambda: ops.softce_rows_fwd(xx, yy, lab, 0, sc, loss, ws))
     print(f"softce_fwd N={N}: {ms:.3f} ms")
     dx, dy, ds = torch.zeros(N, D, device=dev), torch.zeros(N, D, device=dev), torch.zeros(1, device=dev)
-    ms = timeit(lambda: ops.softce_rows_bwd(lab, N, N, D, 0, 14.28, 1.0 / N, dx, dy, ds, ws))
+    ms = timeit(lambda: ops.softce_rows_bwd(lab, N, N, D, 0, sc, 1.0 / N, dx, dy, ds, ws))
     print(f"softce_bwd N={N}: {ms:.3f} ms")
 
 
