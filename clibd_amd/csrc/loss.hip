@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void softce_rows_bwd_kernel(const float* __res
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int pad64(int v) { return (v + 63) / 64 * 64; }
+static inline int pad16(int v) { return (v + 15) / 16 * 16; }
 
 struct LossWs {
     unsigned short *x3, *y3;   // [Nx,3D], [N,3D]
@@ -129,8 +130,8 @@ static LossWs carve(void* base, int Nx, int N, int D) {
     };
     const int Np = pad64(N), Nxp = pad64(Nx);
     w.x3 = (unsigned short*)take((size_t)Nx * 3 * D * 2);
-    w.y3 = (unsigned short*)take((size_t)N * 3 * D * 2);
-    w.S = (float*)take((size_t)Nx * N * 4);
+    w.y3 = (unsigned short*)take((size_t)pad16(N) * 3 * D * 2);   // rows N..N16-1 zero
+    w.S = (float*)take((size_t)Nx * pad16(N) * 4);              // ld = N16, columns N.. ignored
     w.lse = (float*)take((size_t)Nx * 4);
     w.tsum = (float*)take((size_t)Nx * 4);
     w.G = (unsigned short*)take((size_t)Nx * Np * 2);
@@ -145,7 +146,6 @@ static int loss_check(const float* x, const float* y, const int64_t* labels, int
     if (!x || !y || !labels) return set_error(CLIBD_EINVAL, "softce: null pointer");
     if (Nx <= 0 || N <= 0 || D <= 0) return set_error(CLIBD_EINVAL, "softce: non-positive shape");
     if (D % 64 != 0) return set_error(CLIBD_EINVAL, "softce: D must be a multiple of 64");
-    if (N % 4 != 0) return set_error(CLIBD_EINVAL, "softce: N must be a multiple of 4");
     if (row0 < 0 || row0 + Nx > N) return set_error(CLIBD_EINVAL, "softce: row block outside the global batch");
     return 0;
 }
@@ -170,12 +170,15 @@ extern "C" int clibd_softce_rows_fwd(const float* x, const float* y, const int64
     hipLaunchKernelGGL(split3_kernel, dim3(1024), dim3(256), 0, st, x, Nx, D, 1, w.x3);
     hipLaunchKernelGGL(split3_kernel, dim3(1024), dim3(256), 0, st, y, N, D, 0, w.y3);
     if (int e = check_launch("softce split")) return e;
+    const int N16 = pad16(N);
+    if (N16 != N && hipMemsetAsync(w.y3 + (size_t)N * 3 * D, 0, (size_t)(N16 - N) * 3 * D * 2, st) != hipSuccess)
+        return set_error(CLIBD_ELAUNCH, "softce_fwd: memset failed");
     clibd_gemm_epilogue ep = {};
     ep.out_f32 = w.S;  // raw similarities <x_i, y_j>
-    ep.ld_out_f32 = N;
+    ep.ld_out_f32 = N16;
     ep.split_k = 1;
-    if (int e = clibd_gemm_bf16_nt(w.x3, 3 * D, w.y3, 3 * D, Nx, N, 3 * D, &ep, stream)) return e;
-    hipLaunchKernelGGL(softce_rows_fwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, N, Nx, N, labels, row0, scale,
+    if (int e = clibd_gemm_bf16_nt(w.x3, 3 * D, w.y3, 3 * D, Nx, N16, 3 * D, &ep, stream)) return e;
+    hipLaunchKernelGGL(softce_rows_fwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, N16, Nx, N, labels, row0, scale,
                        w.lse, w.tsum, loss_sum);
     return check_launch("softce_rows_fwd");
 }
@@ -185,14 +188,14 @@ extern "C" int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D
                                      const float* weight_scale, float* dx, float* dy, float* dscale, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     if (!labels || !dx || !dy || !workspace || !scale) return set_error(CLIBD_EINVAL, "softce_bwd: null pointer");
-    if (Nx <= 0 || N <= 0 || D <= 0 || D % 64 != 0 || N % 4 != 0 || row0 < 0 || row0 + Nx > N)
+    if (Nx <= 0 || N <= 0 || D <= 0 || D % 64 != 0 || row0 < 0 || row0 + Nx > N)
         return set_error(CLIBD_EINVAL, "softce_bwd: bad shape");
     if (!aligned16(workspace) || !aligned16(dx) || !aligned16(dy)) return set_error(CLIBD_EINVAL, "softce_bwd: alignment");
     const LossWs w = carve(workspace, Nx, N, D);
     if (workspace_bytes < w.total) return set_error(CLIBD_EINVAL, "softce_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int Np = pad64(N), Nxp = pad64(Nx);
-    hipLaunchKernelGGL(softce_rows_bwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, N, Nx, N, labels, row0, w.lse,
+    hipLaunchKernelGGL(softce_rows_bwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, pad16(N), Nx, N, labels, row0, w.lse,
                        w.tsum, weight, weight_scale, scale, w.G, Np, dscale);
     if (int e = check_launch("softce_rows_bwd")) return e;
     // operand images: G^T [N,Nxp], xhi^T [D,Nxp], yhi^T [D,Np] (bf16, zero padded along the contraction)

@@ -179,7 +179,7 @@ int clibd_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int
  * called once per direction (x=a,y=b) and (x=b,y=a).  Data-parallel: each rank passes its own row block.
  * bwd must follow fwd on the same workspace:  g = weight * (*weight_scale) * dloss_sum/dS;
  *   dx [Nx,D] += scale * g·y,  dy [N,D] += scale * g^T·x  (fp32, ACCUMULATED),  *dscale += sum g∘(x·y^T).
- * D % 64 == 0, N % 4 == 0.
+ * D % 64 == 0; any Nx, N.
  * ------------------------------------------------------------------------------------------------ */
 size_t clibd_softce_workspace_bytes(int Nx, int N, int D);
 int clibd_softce_rows_fwd(const float* x, const float* y, const int64_t* labels, int Nx, int N, int D, int row0,

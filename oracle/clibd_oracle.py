@@ -75,12 +75,14 @@ def _rg(x: torch.Tensor) -> torch.Tensor:
     return _G.apply(x)
 
 
-def olinear(x, weight, bias=None):
-    """nn.Linear with the kernels' rounding points: bf16 operands, fp32 accumulate, fp32 bias, bf16 output."""
+def olinear(x, weight, bias=None, round_out=True):
+    """nn.Linear with the kernels' rounding points: bf16 operands, fp32 accumulate, fp32 bias, bf16 output.
+    round_out=False: the GEMM epilogue keeps fp32 (residual add / fp32 head output fused before any rounding);
+    the gradient entering the GEMM is still bf16 (the dgrad GEMM's A operand)."""
     y = F.linear(_r(x), _r(weight), None)
     if bias is not None:
         y = y + bias
-    return _rg(_r(y))
+    return _rg(_r(y) if round_out else y)
 
 
 def gelu_erf(x):
@@ -103,7 +105,7 @@ class PatchEmbed(nn.Module):
         P = self.patch
         cols = F.unfold(x, kernel_size=P, stride=P).transpose(1, 2)  # [B, L, C*P*P]
         w = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
-        return olinear(cols, w, self.proj.bias).reshape(B, self.num_patches, -1)
+        return olinear(cols, w, self.proj.bias, round_out=False).reshape(B, self.num_patches, -1)
 
 
 def attention_core(q, k, v, mask_add=None):
@@ -128,7 +130,7 @@ class Attention(nn.Module):
         qkv = self.qkv(x) if not isinstance(self.qkv, nn.Linear) else olinear(x, self.qkv.weight, self.qkv.bias)
         q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
         o = attention_core(q, k, v).transpose(1, 2).reshape(B, N, C)
-        return olinear(o, self.proj.weight, self.proj.bias)
+        return olinear(o, self.proj.weight, self.proj.bias, round_out=False)
 
 
 class Mlp(nn.Module):
@@ -139,7 +141,7 @@ class Mlp(nn.Module):
 
     def forward(self, x):
         h = olinear(x, self.fc1.weight, self.fc1.bias)
-        return olinear(_rg(_r(gelu_erf(h))), self.fc2.weight, self.fc2.bias)
+        return olinear(_rg(_r(gelu_erf(h))), self.fc2.weight, self.fc2.bias, round_out=False)
 
 
 class Block(nn.Module):
@@ -181,7 +183,7 @@ class VisionTransformer(nn.Module):
     def forward(self, x):
         x = self.forward_features(x)[:, 0]
         if isinstance(self.head, nn.Linear):
-            return olinear(x, self.head.weight, self.head.bias)
+            return olinear(x, self.head.weight, self.head.bias, round_out=False)
         return x
 
 
@@ -295,7 +297,7 @@ class _DenseLN(nn.Module):
         self.LayerNorm = nn.LayerNorm(dout, eps=eps)
 
     def forward(self, x, residual):
-        return self.LayerNorm(olinear(x, self.dense.weight, self.dense.bias) + residual)
+        return self.LayerNorm(olinear(x, self.dense.weight, self.dense.bias, round_out=False) + residual)
 
 
 class _Attn(nn.Module):
@@ -384,7 +386,7 @@ class BertForMaskedLM(nn.Module):
     def forward(self, ids):
         x = self.bert(ids)
         t = self.cls.predictions.transform
-        h = t.LayerNorm(_rg(_r(gelu_erf(olinear(x, t.dense.weight, t.dense.bias)))))
+        h = t.LayerNorm(_rg(gelu_erf(olinear(x, t.dense.weight, t.dense.bias))))  # fp32 GELU output feeds the LayerNorm
         d = self.cls.predictions.decoder
         return olinear(h, d.weight, d.bias)  # logits
 
@@ -437,7 +439,7 @@ class LanguageEncoder(nn.Module):
 
     def forward(self, x: dict):
         h = self.base_language_encoder(x["input_ids"], x.get("token_type_ids"), x.get("attention_mask"))
-        return olinear(h.mean(dim=1), self.proj.weight, self.proj.bias)
+        return olinear(h.mean(dim=1), self.proj.weight, self.proj.bias, round_out=False)
 
 
 # =====================================================================================================
