@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CLIBD Image+DNA contrastive TRAINING step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward of the ViT-B/16 + BarcodeBERT(BERT-base) towers with rank-4 LoRA adapters, L2-normalise,
+packed RCCL all-gather of the embeddings, soft-target InfoNCE over the global batch, backward (dgrad through the frozen
+bases, adapter + head gradients), flat-bucket gradient all-reduce and fused AdamW — on synthetic 224x224 images and
+660-nt barcodes (133 tokens), random-init weights of the reference's shapes.  Per-GPU batch 256 (BASELINE configs[1]
+at N=1, configs[2] = global 2048 at N=8): weak scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of every
+GEMM launch in the timed region / their summed HIP-event durations on the launch stream, against the 2.5 PFLOP/s
+dense bf16 peak.  `cpu_baseline` is the CPU oracle's training step (oracle/clibd_oracle.py, the reference's CPU path
+restated and pinned to it) timed on this host's cores with a bounded sample, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+GF_PER_PAIR_TRAIN = 117.6     # LoRA training step, I+D pair (fwd 58.78 GF + dgrad-only bwd)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--per-gpu-batch", type=int, default=256)
+    ap.add_argument("--tri-modal", action="store_true", help="add the BERT-small text tower (BASELINE configs[3])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-gemm-timing", action="store_true")
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """HIP-event brackets around every GEMM launch (same stream as the launch) + algorithmic FLOPs."""
+
+    def __init__(self):
+        self.events, self.flops, self.enabled = [], 0.0, False
+
+    def install(self):
+        from clibd_amd import ops
+
+        inner = ops.gemm_nt
+        timer = self
+
+        def timed(a, w, **kw):
+            if not timer.enabled:
+                return inner(a, w, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inner(a, w, **kw)
+            e1.record()
+            timer.events.append((e0, e1))
+            timer.flops += 2.0 * a.shape[0] * w.shape[0] * a.shape[1]
+
+        ops.gemm_nt = timed
+        import clibd_amd.engine as eng
+        import clibd_amd.towers as tw
+
+        assert eng.ops is ops and tw.ops is ops
+
+    def result(self):
+        if not self.events:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events)
+        return {"launches": len(self.events), "total_ms": ms, "tflops": self.flops / (ms * 1e-3) / 1e12}
+
+
+def cpu_baseline(batch: int):
+    """Oracle (CPU restatement of the reference's fp32 path) training step: fwd + loss + bwd + AdamW, full-size towers."""
+    from oracle import clibd_oracle as O
+
+    torch.set_num_threads(os.cpu_count())
+    torch.manual_seed(42)
+    model = O.build_image_dna_model()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    g = torch.Generator().manual_seed(42)
+    image = torch.rand(batch, 3, 224, 224, generator=g)
+    dna = torch.cat([torch.zeros(batch, 1, dtype=torch.long), torch.randint(3, 1027, (batch, 132), generator=g)], dim=1)
+    labels = torch.arange(batch)
+    t0 = time.time()
+    loss = O.train_step(model, opt, image, dna, labels)
+    dt = time.time() - t0
+    return {"value": batch / dt, "unit": "paired samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 training step (fwd+loss+bwd+AdamW), batch {batch}, fp32, ViT-B/16 + BERT-base(133 tok) LoRA r=4, torch {torch.__version__} CPU, "
+                      f"{torch.get_num_threads()} threads, {dt:.1f} s, loss {float(loss):.4f}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import (CLIBDDNAEncoder, CLIBDImageEncoder, CLIBDLanguageEncoder, SimpleCLIP, create_vit,
+                                 load_pre_trained_bert, load_pre_trained_bioscan_bert)
+    from clibd_amd.train import Trainer, scale_learning_rate
+
+    torch.manual_seed(42)
+    b = args.per_gpu_batch
+    image_enc = CLIBDImageEncoder(create_vit("vit_base_patch16_224"), r=4, num_classes=768)
+    dna_enc = CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), r=4, num_classes=768)
+    text_enc = CLIBDLanguageEncoder(load_pre_trained_bert()[1], r=4, num_classes=768) if args.tri_modal else None
+    model = SimpleCLIP(image_enc, dna_enc, text_enc).to(dev)
+    with torch.no_grad():  # exercise the adapters: B != 0 (B = 0 at init would make half the LoRA backward trivially zero)
+        for enc in (image_enc, dna_enc, text_enc):
+            if enc is not None:
+                for wb in enc.w_Bs:
+                    wb.weight.normal_(0, 0.02)
+    trainer = Trainer(model, lr=scale_learning_rate(1e-3, b, world_size=world), world_size=world, rank=rank, all_gather=True)
+    batch = synthetic_batch(b, dev, seed=42, rank=rank, with_text=args.tri_modal)
+
+    timer = GemmTimer()
+    if not args.no_gemm_timing:
+        timer.install()
+
+    def one_step():
+        return trainer.step(batch["image"], batch["dna"], batch["text"], batch["labels"])
+
+    for _ in range(args.warmup):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        pairs_per_s = b * world * args.steps / elapsed
+        gemm = timer.result()
+        step_frac = pairs_per_s * GF_PER_PAIR_TRAIN * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12)
+        roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "kernel": "gemm_bf16_nt_kernel", "step_frac": step_frac,
+                "note": "achieved = sum of 2MNK over every GEMM launch of the timed steps / summed HIP-event durations (rank 0); "
+                        "step_frac = pairs/s x 117.6 GF / (n_gpus x peak), i.e. the whole step against the MFMA roof"}
+        if gemm:
+            roof.update(achieved=gemm["tflops"], frac=gemm["tflops"] / PEAK_BF16_TFLOPS, launches=gemm["launches"],
+                        gemm_ms_per_step=gemm["total_ms"] / args.steps)
+        out = {
+            "metric": "paired samples/sec/step (I+D contrastive)" if not args.tri_modal else "triples/sec/step (I+D+T contrastive)",
+            "value": pairs_per_s, "unit": "paired samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights)",
+            "config": {"workload": "Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) LoRA r=4, bf16 MFMA" +
+                                   (" + BERT-small text tower" if args.tri_modal else ""),
+                       "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}", "image": "3x224x224", "dna_tokens": 133,
+                       "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW"},
+            "loss": loss_val, "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+            except Exception as e:  # pragma: no cover
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

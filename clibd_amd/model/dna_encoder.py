@@ -232,13 +232,16 @@ class CLIBDDNAEncoder(nn.Module):
         for w_B in self.w_Bs:
             nn.init.zeros_(w_B.weight)
 
-    def forward(self, sequence) -> torch.Tensor:
+    def tower(self) -> BertTower:
         if self._tower is None:
             pred = self.base_dna_encoder.cls.predictions
             self._tower = BertTower(self.base_dna_encoder.bert, "mlm",
                                     dict(transform_dense=pred.transform.dense, transform_ln=pred.transform.LayerNorm, decoder=pred.decoder))
         self._tower.hm["decoder"] = self.base_dna_encoder.cls.predictions.decoder
-        return self._tower(sequence, None, None)
+        return self._tower
+
+    def forward(self, sequence) -> torch.Tensor:
+        return self.tower()(sequence, None, None)
 
 
 class Freeze_DNA_Encoder(nn.Module):

@@ -156,7 +156,10 @@ class CLIBDImageEncoder(nn.Module):
         for w_B in self.w_Bs:
             nn.init.zeros_(w_B.weight)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def tower(self) -> ViTTower:
         if self._tower is None:
             self._tower = ViTTower(self.base_image_encoder, self._lora)
-        return self._tower(x)
+        return self._tower
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.tower()(x)

@@ -58,7 +58,10 @@ class CLIBDLanguageEncoder(nn.Module):
         for w_B in self.w_Bs:
             nn.init.zeros_(w_B.weight)
 
-    def forward(self, x) -> torch.Tensor:
+    def tower(self) -> BertTower:
         if self._tower is None:
             self._tower = BertTower(self.base_language_encoder, "mean", dict(proj=self.proj))
-        return self._tower(x["input_ids"], x.get("token_type_ids"), x.get("attention_mask"))
+        return self._tower
+
+    def forward(self, x) -> torch.Tensor:
+        return self.tower()(x["input_ids"], x.get("token_type_ids"), x.get("attention_mask"))

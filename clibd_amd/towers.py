@@ -36,6 +36,12 @@ class _TowerFn(torch.autograd.Function):
             raise RuntimeError("backward through a tower that ran without saving activations")
         params = _trainable(tower.trainable_params())  # same objects/order as the apply() call
         assert len(params) == len(ctx.params)
+        sink = tower.grad_sink
+        if sink is not None and all(id(p) in sink for p in params):
+            # trainer-owned flat gradient bucket (clibd_amd.optim.FusedAdamW): accumulate straight into it
+            tower._backward(dout.contiguous().to(F32), state, sink)
+            ctx.state = None
+            return (None, None, None, *([None] * len(params)))
         bucket = GradBucket(params)
         tower._backward(dout.contiguous().to(F32), state, bucket.views)
         ctx.state = None
@@ -43,6 +49,8 @@ class _TowerFn(torch.autograd.Function):
 
 
 class _Tower:
+    grad_sink = None  # optional {id(param): fp32 accumulation tensor}; set by the trainer, see _TowerFn.backward
+
     def trainable_params(self) -> List[torch.nn.Parameter]:
         raise NotImplementedError
 

@@ -1,0 +1,77 @@
+"""The contrastive training step: counterpart of the body of `train_epoch`
+(reference epoch/train_epoch.py:21-63) and of the DDP/AdamW setup in scripts/train_cl.py:195-262.
+
+One process per GPU.  Data parallel = the packed RCCL all-gather / reduce-scatter inside `ClipLoss`
+(clibd_amd.model.loss_func) + ONE flat-bucket gradient all-reduce here; no DDP wrapper, no per-step host sync
+(the reference's `loss.item()` / anomaly mode / per-epoch tokenizer download are not reproduced).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .model.loss_func import ClipLoss, ContrastiveLoss
+from .optim import FusedAdamW
+
+try:
+    import torch.distributed as dist
+except ImportError:  # pragma: no cover
+    dist = None
+
+
+def scale_learning_rate(lr, batch_size, base_batch_size=500, world_size=1):
+    """util/util.py:753-756"""
+    return lr * batch_size * world_size / base_batch_size
+
+
+class Trainer:
+    def __init__(self, model, lr: float = 1e-3, world_size: int = 1, rank: int = 0, all_gather: bool = True,
+                 fix_temperature: Optional[float] = None, bind_to=None, no_image_text_loss=False, weight_decay: float = 1e-2):
+        self.model, self.world_size, self.rank = model, world_size, rank
+        self.fix_temperature = fix_temperature
+        self.optimizer = FusedAdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+        if all_gather:
+            self.criterion = ClipLoss(local_loss=False, gather_with_grad=True, rank=rank, world_size=world_size,
+                                      criterion=torch.nn.CrossEntropyLoss(), bind_to=bind_to, no_image_text_loss=no_image_text_loss)
+        else:
+            self.criterion = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)
+        self.optimizer.grad_scale = 1.0 / world_size  # SUM all-reduce then mean: what DDP does (train_cl.py:204)
+        # let the towers accumulate parameter gradients straight into the optimizer's flat bucket
+        sink = {id(p): p.grad for p in self.optimizer.param_groups[0]["params"]}
+        for enc in (model.image_encoder, model.dna_encoder, model.language_encoder):
+            if enc is not None and hasattr(enc, "tower"):
+                enc.tower().grad_sink = sink
+
+    def step(self, image, dna, text, labels) -> torch.Tensor:
+        """forward (all towers) -> loss -> backward -> gradient all-reduce -> AdamW.  Returns the (device) loss."""
+        self.optimizer.zero_grad()
+        image_out, dna_out, text_out, logit_scale, _ = self.model(image, dna, text)
+        if self.fix_temperature is not None:
+            logit_scale = 1.0 / 0.07
+        loss = self.criterion(image_out, dna_out, text_out, labels, logit_scale)
+        loss.backward()
+        if self.world_size > 1:
+            dist.all_reduce(self.optimizer.flat_g)
+        self.optimizer.step()
+        return loss.detach()
+
+
+def train_epoch(total_epochs, epoch, dataloader, trainer: Trainer, device, scheduler=None, log_every: int = 0):
+    """Epoch loop over the reference's 7-tuple batches (util/dataset.py:294-302)."""
+    trainer.model.train()
+    running = torch.zeros((), device=device)
+    n = 0
+    for step, batch in enumerate(dataloader):
+        _pid, image, dna, input_ids, token_type_ids, attention_mask, label = batch
+        text = None
+        if trainer.model.language_encoder is not None:
+            text = {"input_ids": input_ids.to(device), "token_type_ids": token_type_ids.to(device), "attention_mask": attention_mask.to(device)}
+        loss = trainer.step(image.to(device), dna.to(device), text, label.to(device))
+        if scheduler is not None:
+            scheduler.step()
+        running += loss
+        n += 1
+        if log_every and (step + 1) % log_every == 0 and trainer.rank == 0:
+            print(f"Epoch {epoch}/{total_epochs} step {step + 1}: loss {loss.item():.4f}")
+    return (running / max(n, 1)).item()
