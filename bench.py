@@ -84,7 +84,10 @@ def cpu_baseline(batch: int):
     """Oracle (CPU restatement of the reference's fp32 path) training step: fwd + loss + bwd + AdamW, full-size towers."""
     from oracle import clibd_oracle as O
 
-    torch.set_num_threads(os.cpu_count())
+    # a few dozen threads is where this ~60 GFLOP/sample fp32 step stops scaling on the host (all 256 hardware threads
+    # of the GPU box made it >10x slower: tiny per-thread GEMM panels + NUMA traffic), so the thread count is capped
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     torch.manual_seed(42)
     model = O.build_image_dna_model()
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
@@ -95,7 +98,7 @@ def cpu_baseline(batch: int):
     t0 = time.time()
     loss = O.train_step(model, opt, image, dna, labels)
     dt = time.time() - t0
-    return {"value": batch / dt, "unit": "paired samples/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": batch / dt, "unit": "paired samples/s", "cores": threads, "kind": "port",
             "sample": f"1 training step (fwd+loss+bwd+AdamW), batch {batch}, fp32, ViT-B/16 + BERT-base(133 tok) LoRA r=4, torch {torch.__version__} CPU, "
                       f"{torch.get_num_threads()} threads, {dt:.1f} s, loss {float(loss):.4f}"}
 

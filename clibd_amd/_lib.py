@@ -83,6 +83,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's): it must be the one HIP runtime of the
+    # process, or device pointers / streams handed over from torch would belong to a different runtime instance.
+    import torch  # noqa: F401  (loads libtorch_hip -> the bundled HIP runtime first)
+
     if not LIB_PATH.exists():
         raise ClibdHipError(
             f"{LIB_PATH} not found: build it with `python -m clibd_amd.build` (hipcc, gfx950). "

@@ -24,8 +24,11 @@ class FusedAdamW(torch.optim.Optimizer):
         dev = ps[0].device
         if not all(p.is_cuda and p.dtype == torch.float32 and p.device == dev for p in ps):
             raise ValueError("FusedAdamW: parameters must be fp32 tensors on one GPU")
-        n = sum(p.numel() for p in ps)
-        self.flat_p = torch.empty((n,), dtype=torch.float32, device=dev)
+        align = 64  # every parameter view starts on a 256-byte boundary (16-byte vector loads in the cast / pack kernels)
+        pad = lambda k: (k + align - 1) // align * align
+        n = sum(pad(p.numel()) for p in ps)
+        self._offsets = []
+        self.flat_p = torch.zeros((n,), dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros((n,), dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
@@ -36,19 +39,18 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.flat_p[off : off + k].copy_(p.reshape(-1))
                 p.data = self.flat_p[off : off + k].view(p.shape)
                 p.grad = self.flat_g[off : off + k].view(p.shape)
-                off += k
+                self._offsets.append(off)
+                off += pad(k)
         self.step_count = 0
         self.grad_scale = 1.0  # e.g. 1/world_size after a SUM all-reduce (DDP's mean)
 
     def zero_grad(self, set_to_none: bool = False):
         # gradients stay resident as views of the flat bucket (autograd accumulates in place)
         self.flat_g.zero_()
-        off = 0
-        for p in self.param_groups[0]["params"]:
+        for p, off in zip(self.param_groups[0]["params"], self._offsets):
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off : off + k].view(p.shape)
-            off += k
 
     @torch.no_grad()
     def step(self, closure=None):
