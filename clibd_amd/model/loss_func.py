@@ -86,7 +86,7 @@ class _SoftCEFn(torch.autograd.Function):
         if world > 1:
             packed = torch.stack(ys, dim=0)                             # [M, b, D]
             gathered = torch.empty((world, M, b, D), dtype=F32, device=dev)
-            dist.all_gather_into_tensor(gathered, packed)
+            dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1))   # flat views: valid for RCCL and gloo alike
             all_y = [gathered[:, m].reshape(world * b, D).contiguous() for m in range(M)]
             all_labels = torch.empty((world * b,), dtype=torch.int64, device=dev)
             dist.all_gather_into_tensor(all_labels, labels)
@@ -127,7 +127,7 @@ class _SoftCEFn(torch.autograd.Function):
         if world > 1:
             send = dall.view(M, world, b, D).permute(1, 0, 2, 3).contiguous()   # [W, M, b, D]
             recv = torch.empty((M, b, D), dtype=F32, device=dev)
-            dist.reduce_scatter_tensor(recv, send)
+            dist.reduce_scatter_tensor(recv.view(-1), send.view(-1))
             dlocal = dlocal + recv
         grads = [ops.l2norm_bwd(dlocal[m], ys[m], invs[m]) for m in range(M)]
         ctx.saved = None
