@@ -11,8 +11,7 @@
 // row m.  W rows are additionally permuted when they are placed in LDS (row n_local = 16g+4t+r sits at
 // LDS row 16t+4g+r) so the 4 n-tiles of a lane are 16 CONTIGUOUS output columns: 32-byte bf16 /
 // 64-byte fp32 stores per lane, and full 128-B lines per row across a wave.
-#include "common.h"
-#include "../../include/clibd_hip.h"
+#include "gemm_common.h"
 #include "host_util.h"
 
 namespace clibd {
@@ -21,19 +20,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 constexpr int GEMM_THREADS = 256;
 
-struct GemmParams {
-    const unsigned short* A;
-    const unsigned short* W;
-    int M, N, K, lda, ldw;
-    int tiles_m, tiles_n, ktiles_per_split;
-    clibd_gemm_epilogue ep;
-};
-
 // LDS row r (0..127) of the W tile holds tile-local output column perm(r)
 __device__ __forceinline__ int w_row_perm(int r) {
-    int r6 = r & 63;
-    int t = r6 >> 4, i = r6 & 15;
-    return (r & 64) + 16 * (i >> 2) + 4 * t + (i & 3);
+    const int r6 = r & 63;
+    return (r & 64) + w_col_of(r6 >> 4, r6 & 15);
 }
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(GemmParams p) {
@@ -49,19 +39,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(GemmParam
     int bid = blockIdx.x;
     const int split = bid / ntiles;
     bid -= split * ntiles;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // group 8 m-tiles per band so a band's W reads repeat while its A panels are hot
-    const int band = 8;
-    const int band_id = bid / (band * p.tiles_n);
-    const int band_m0 = band_id * band;
-    const int band_h = min(band, p.tiles_m - band_m0);
-    const int in_band = bid - band_id * band * p.tiles_n;
-    const int tile_m = band_m0 + in_band % band_h;
-    const int tile_n = in_band / band_h;
+    int tile_m, tile_n;
+    tile_coords(bid, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int kt0 = split * p.ktiles_per_split;
@@ -156,15 +135,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(GemmParam
     const int nb = n0 + wn * 64 + 16 * fch;
     if (nb >= p.N) return;  // N % 16 == 0, so a lane's 16 columns are all in or all out
     float bias[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) bias[e] = 0.f;
-    if (ep.bias != nullptr && split == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *(const f32x4*)(ep.bias + nb + 4 * q);
-            bias[4 * q + 0] = b4[0]; bias[4 * q + 1] = b4[1]; bias[4 * q + 2] = b4[2]; bias[4 * q + 3] = b4[3];
-        }
-    }
+    load_bias16(ep, nb, split == 0, bias);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + 16 * i + frow;
@@ -174,55 +145,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(GemmParam
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
-
-        if (ep.split_k > 1) {
-            float* o = ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) atomicAdd(o + e, v[e]);
-            continue;
-        }
-        if (ep.out_pre_bf16 != nullptr) {
-            uint4 lo, hi;
-            lo.x = pack2bf(v[0], v[1]);   lo.y = pack2bf(v[2], v[3]);   lo.z = pack2bf(v[4], v[5]);   lo.w = pack2bf(v[6], v[7]);
-            hi.x = pack2bf(v[8], v[9]);   hi.y = pack2bf(v[10], v[11]); hi.z = pack2bf(v[12], v[13]); hi.w = pack2bf(v[14], v[15]);
-            uint4* o = (uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb);
-            o[0] = lo; o[1] = hi;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = bfround(v[e]);
-        }
-        if (ep.act == CLIBD_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
-        } else if (ep.act == CLIBD_ACT_GELU_GRAD) {
-            const uint4* ax = (const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
-            const uint4 x0 = ax[0], x1 = ax[1];
-            const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[2 * e] *= gelu_grad_f(bf2f((unsigned short)(xs[e] & 0xffffu)));
-                v[2 * e + 1] *= gelu_grad_f(bf2f((unsigned short)(xs[e] >> 16)));
-            }
-        }
-        if (ep.residual_f32 != nullptr) {
-            const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 r4 = rs[q];
-                v[4 * q + 0] += r4[0]; v[4 * q + 1] += r4[1]; v[4 * q + 2] += r4[2]; v[4 * q + 3] += r4[3];
-            }
-        }
-        if (ep.out_f32 != nullptr) {
-            f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-        }
-        if (ep.out_bf16 != nullptr) {
-            uint4 lo, hi;
-            lo.x = pack2bf(v[0], v[1]);   lo.y = pack2bf(v[2], v[3]);   lo.z = pack2bf(v[4], v[5]);   lo.w = pack2bf(v[6], v[7]);
-            hi.x = pack2bf(v[8], v[9]);   hi.y = pack2bf(v[10], v[11]); hi.z = pack2bf(v[12], v[13]); hi.w = pack2bf(v[14], v[15]);
-            uint4* o = (uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb);
-            o[0] = lo; o[1] = hi;
-        }
+        store_row16(ep, m, nb, v);
     }
 }
 
@@ -312,6 +235,7 @@ extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw
     p.ktiles_per_split = (ktiles + split - 1) / split;
     p.ep = *ep;
     p.ep.split_k = split;
+    if (gemm256_try_launch(p, (hipStream_t)stream)) return check_launch("gemm256_bf16_nt");
     const long long nblocks = (long long)p.tiles_m * p.tiles_n * split;
     if (nblocks > 0x7fffffffLL) return set_error(CLIBD_EINVAL, "gemm: grid too large");
     static const bool attr_ok = [] {

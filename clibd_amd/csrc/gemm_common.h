@@ -1,0 +1,105 @@
+// Shared pieces of the bf16 NT GEMM kernels (gemm.hip: 128x128 tile; gemm256.hip: 256x256 8-phase tile).
+#pragma once
+#include "common.h"
+#include "../../include/clibd_hip.h"
+
+namespace clibd {
+
+struct GemmParams {
+    const unsigned short* A;
+    const unsigned short* W;
+    int M, N, K, lda, ldw;
+    int tiles_m, tiles_n, ktiles_per_split;
+    clibd_gemm_epilogue ep;
+};
+
+// Inside a wave's 64 output columns, MFMA n-tile t (0..3), MFMA row i (0..15) carries tile-local column
+// 16*(i>>2) + 4*t + (i&3): lane group g = lane>>4 then owns the 16 CONTIGUOUS columns 16g .. 16g+15 (e = 4t + reg).
+__device__ __forceinline__ int w_col_of(int t, int i) { return 16 * (i >> 2) + 4 * t + (i & 3); }
+
+// LDS tile addressing: 128-byte rows (64 bf16), 16-byte chunk index XOR (row & 7): conflict-free ds_read_b128 fragments
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// XCD-aware, L2-friendly tile order: blocks sharing an XCD (id % 8) walk a contiguous range of tile ids; ids run
+// m-fastest inside bands of `band` m-tiles, so a band's A panels stay hot while its W panels stream through.
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int band, int& tile_m, int& tile_n) {
+    const int ntiles = tiles_m * tiles_n;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int band_id = bid / (band * tiles_n);
+    const int band_m0 = band_id * band;
+    const int band_h = min(band, tiles_m - band_m0);
+    const int in_band = bid - band_id * band * tiles_n;
+    tile_m = band_m0 + in_band % band_h;
+    tile_n = in_band / band_h;
+}
+
+__device__ __forceinline__ void load_bias16(const clibd_gemm_epilogue& ep, int nb, bool on, float bias[16]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias[e] = 0.f;
+    if (ep.bias != nullptr && on) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *(const f32x4*)(ep.bias + nb + 4 * q);
+            bias[4 * q + 0] = b4[0]; bias[4 * q + 1] = b4[1]; bias[4 * q + 2] = b4[2]; bias[4 * q + 3] = b4[3];
+        }
+    }
+}
+
+// One output row m, 16 contiguous columns nb..nb+15 held by this lane: v = acc + bias already applied by the caller.
+__device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m, int nb, float v[16]) {
+    if (ep.split_k > 1) {
+        float* o = ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) atomicAdd(o + e, v[e]);
+        return;
+    }
+    if (ep.out_pre_bf16 != nullptr) {
+        uint4 lo, hi;
+        lo.x = pack2bf(v[0], v[1]);   lo.y = pack2bf(v[2], v[3]);   lo.z = pack2bf(v[4], v[5]);   lo.w = pack2bf(v[6], v[7]);
+        hi.x = pack2bf(v[8], v[9]);   hi.y = pack2bf(v[10], v[11]); hi.z = pack2bf(v[12], v[13]); hi.w = pack2bf(v[14], v[15]);
+        uint4* o = (uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb);
+        o[0] = lo; o[1] = hi;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = bfround(v[e]);
+    }
+    if (ep.act == CLIBD_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+    } else if (ep.act == CLIBD_ACT_GELU_GRAD) {
+        const uint4* ax = (const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        const uint4 x0 = ax[0], x1 = ax[1];
+        const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[2 * e] *= gelu_grad_f(bf2f((unsigned short)(xs[e] & 0xffffu)));
+            v[2 * e + 1] *= gelu_grad_f(bf2f((unsigned short)(xs[e] >> 16)));
+        }
+    }
+    if (ep.residual_f32 != nullptr) {
+        const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 r4 = rs[q];
+            v[4 * q + 0] += r4[0]; v[4 * q + 1] += r4[1]; v[4 * q + 2] += r4[2]; v[4 * q + 3] += r4[3];
+        }
+    }
+    if (ep.out_f32 != nullptr) {
+        f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    }
+    if (ep.out_bf16 != nullptr) {
+        uint4 lo, hi;
+        lo.x = pack2bf(v[0], v[1]);   lo.y = pack2bf(v[2], v[3]);   lo.z = pack2bf(v[4], v[5]);   lo.w = pack2bf(v[6], v[7]);
+        hi.x = pack2bf(v[8], v[9]);   hi.y = pack2bf(v[10], v[11]); hi.z = pack2bf(v[12], v[13]); hi.w = pack2bf(v[14], v[15]);
+        uint4* o = (uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb);
+        o[0] = lo; o[1] = hi;
+    }
+}
+
+// host side (gemm256.hip): returns true when the 256x256 kernel took the launch
+bool gemm256_try_launch(const GemmParams& p, hipStream_t stream);
+
+}  // namespace clibd

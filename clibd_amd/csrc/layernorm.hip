@@ -37,7 +37,9 @@ __device__ __forceinline__ float wave_reduce8(float v[8], int lane) {
     return w1;  // index = 4*b5 + 2*b4 + b3
 }
 
-template <int NCH>
+// LORA: the adapter matrix A_cat [8,H] sits in LDS as fp32 (conflict-free 16-byte reads), so the kernel stays at
+// high occupancy (HBM-bound: what matters is bytes in flight per CU, i.e. resident waves).
+template <int NCH, bool LORA>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int M, int H,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
@@ -45,11 +47,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             float* __restrict__ y_f32, float* __restrict__ stats,
                                                             const unsigned short* __restrict__ lora_a,
                                                             unsigned short* __restrict__ t_bf16) {
+    extern __shared__ __attribute__((aligned(16))) float a_lds[];  // [8][H] when LORA
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
-    const int nchunks = H >> 8;  // full 64-lane chunk groups: H/256 (H % 256 may leave a partial group)
-    (void)nchunks;
+    if (LORA) {
+        for (int i = threadIdx.x; i < 8 * H; i += 256) a_lds[i] = bf2f(lora_a[i]);
+        __syncthreads();
+    }
     f32x4 g[NCH], b[NCH];
     bool act[NCH];
 #pragma unroll
@@ -58,18 +63,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         act[j] = c < H;
         g[j] = act[j] ? *(const f32x4*)(gamma + c) : (f32x4){0, 0, 0, 0};
         b[j] = act[j] ? *(const f32x4*)(beta + c) : (f32x4){0, 0, 0, 0};
-    }
-    // LoRA A_cat[8,H] bf16: this lane's columns, packed 2 bf16 per dword: la[r][j] = 4 values
-    uint2 la[8][NCH];
-    const bool lora = (lora_a != nullptr);
-    if (lora) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int c = 4 * (lane + 64 * j);
-                la[r][j] = act[j] ? *(const uint2*)(lora_a + (size_t)r * H + c) : make_uint2(0, 0);
-            }
     }
     const float invH = 1.0f / (float)H;
     for (int row = wave_in_grid; row < M; row += nwaves) {
@@ -95,10 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         }
         const float var = wave_sum(q) * invH;
         const float rstd = rsqrtf(var + eps);
-        if (stats != nullptr && lane == 0) {
-            stats[2 * (size_t)row] = mean;
-            stats[2 * (size_t)row + 1] = rstd;
-        }
+        if (stats != nullptr && lane == 0) *(float2*)(stats + 2 * (size_t)row) = make_float2(mean, rstd);
         float tp[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) tp[r] = 0.f;
@@ -114,18 +104,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             pk.x = pack2bf(y[0], y[1]);
             pk.y = pack2bf(y[2], y[3]);
             if (y_bf16 != nullptr) *(uint2*)(y_bf16 + (size_t)row * H + c) = pk;
-            if (lora) {
+            if (LORA) {
                 const float y0 = bf2f((unsigned short)(pk.x & 0xffff)), y1 = bf2f((unsigned short)(pk.x >> 16));
                 const float y2 = bf2f((unsigned short)(pk.y & 0xffff)), y3 = bf2f((unsigned short)(pk.y >> 16));
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const uint2 a = la[r][j];
-                    tp[r] += y0 * bf2f((unsigned short)(a.x & 0xffff)) + y1 * bf2f((unsigned short)(a.x >> 16)) +
-                             y2 * bf2f((unsigned short)(a.y & 0xffff)) + y3 * bf2f((unsigned short)(a.y >> 16));
+                    const f32x4 a = *(const f32x4*)(a_lds + r * H + c);
+                    tp[r] += (y0 * a[0] + y1 * a[1]) + (y2 * a[2] + y3 * a[3]);
                 }
             }
         }
-        if (lora) {
+        if (LORA) {
             const float tv = wave_reduce8(tp, lane);
             if ((lane & 7) == 0) t_bf16[(size_t)row * 8 + (lane >> 3)] = f2bf(tv);
         }
@@ -208,7 +197,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
 
 static inline int ln_grid(int M) {
     int blocks = (M + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2048) blocks = 2048;  // 8 blocks x 4 waves per CU: every wave slot of the chip, grid-stride over rows
     return blocks < 1 ? 1 : blocks;
 }
 
@@ -229,10 +218,19 @@ extern "C" int clibd_layernorm_fwd(const float* x, int M, int H, const float* ga
     const int nch = (H + 255) / 256;
     dim3 grid(ln_grid(M)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const bool lora = lora_a_bf16 != nullptr;
+    const size_t lds = lora ? (size_t)8 * H * sizeof(float) : 0;
 #define LAUNCH(N)                                                                                              \
-    hipLaunchKernelGGL(layernorm_fwd_kernel<N>, grid, block, 0, st, x, M, H, gamma, beta, eps,                 \
-                       (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)lora_a_bf16,              \
-                       (unsigned short*)t_bf16)
+    do {                                                                                                       \
+        if (lora)                                                                                              \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<N, true>), grid, block, lds, st, x, M, H, gamma, beta, eps, \
+                               (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)lora_a_bf16,      \
+                               (unsigned short*)t_bf16);                                                       \
+        else                                                                                                   \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<N, false>), grid, block, 0, st, x, M, H, gamma, beta, eps, \
+                               (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)nullptr,          \
+                               (unsigned short*)nullptr);                                                      \
+    } while (0)
     switch (nch) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -251,7 +249,7 @@ extern "C" int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, con
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_bwd: H must be a multiple of 64, <= 1024");
     if (!dx_f32 && !dx_bf16) return set_error(CLIBD_EINVAL, "layernorm_bwd: no output");
     const int nch = (H + 255) / 256;
-    dim3 grid(ln_grid(M)), block(256);
+    dim3 grid(min((M + 3) / 4, 4096)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(N)                                                                                              \
     hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \

@@ -46,10 +46,14 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const float* __restrict_
     }
 }
 
-// cross-group (4 row groups) reduction of one 4x4 accumulator family through LDS, then one atomic per value.
+// cross-group (4 row groups) reduction of one 4x4 accumulator family through LDS; the reduced 4H values are then laid
+// out in OUTPUT order in LDS (padded against bank conflicts) and added to global memory with wave-contiguous atomics
+// (256 B per wave-instruction: scattered float atomics run an order of magnitude slower on gfx950).
 // IS_A: output layout dA[r, k] (k = c + e) else dB[n, r] (n = c + e).
+__device__ __forceinline__ int lw_pad(int i) { return i + (i >> 5); }
+
 template <bool IS_A>
-__device__ __forceinline__ void lw_reduce_emit(float (&acc)[4][4], float* red, int grp, int ct, int cthreads,
+__device__ __forceinline__ void lw_reduce_emit(float (&acc)[4][4], float* red, float* outl, int grp, int ct, int cthreads,
                                                float* __restrict__ out, int c, int H) {
     if (grp > 0) {
         float* dst = red + ((size_t)(grp - 1) * cthreads + ct) * 16;
@@ -70,11 +74,10 @@ __device__ __forceinline__ void lw_reduce_emit(float (&acc)[4][4], float* red, i
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (IS_A) atomicAdd(out + (size_t)r * H + c + e, acc[e][r]);
-                else atomicAdd(out + (size_t)(c + e) * 4 + r, acc[e][r]);
-            }
+            for (int r = 0; r < 4; ++r) outl[lw_pad(IS_A ? r * H + c + e : (c + e) * 4 + r)] = acc[e][r];
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) atomicAdd(out + i, outl[lw_pad(i)]);
     __syncthreads();
 }
 
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(1024) void lora_wgrad_kernel(const unsigned short* 
                                                           const unsigned short* __restrict__ dt, int ld_dt, int M, int H,
                                                           float* __restrict__ dA_q, float* __restrict__ dA_v,
                                                           float* __restrict__ dB_q, float* __restrict__ dB_v) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [3][H/4][16]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [3][H/4][16] reduction slabs, then [4H + 4H/32] output image
+    float* outl = red + 3 * (H >> 2) * 16;
     const int cthreads = H >> 2;
     const int grp = threadIdx.x / cthreads;
     const int ct = threadIdx.x - grp * cthreads;
@@ -102,12 +106,25 @@ __global__ __launch_bounds__(1024) void lora_wgrad_kernel(const unsigned short* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) { accBq[e][r] = 0.f; accBv[e][r] = 0.f; accAq[e][r] = 0.f; accAv[e][r] = 0.f; }
 
-    for (int m = m0 + grp; m < m1; m += 4) {
-        const uint2 dq2 = *(const uint2*)(dqkv + (size_t)m * ld + c);
-        const uint2 dv2 = *(const uint2*)(dqkv + (size_t)m * ld + 2 * H + c);
-        const uint2 x2 = *(const uint2*)(x + (size_t)m * H + c);
-        const uint4 t4 = *(const uint4*)(t + (size_t)m * 8);
-        const uint4 d4 = *(const uint4*)(dt + (size_t)m * ld_dt);
+    // 4 rows in flight per thread (independent loads issued before any use): the kernel is pure HBM streaming
+    constexpr int UNR = 4;
+    for (int mb = m0 + grp; mb < m1; mb += 4 * UNR) {
+      uint2 dq2u[UNR], dv2u[UNR], x2u[UNR];
+      uint4 t4u[UNR], d4u[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int m = min(mb + 4 * u, m1 - 1);  // clamped rows are skipped below
+        dq2u[u] = *(const uint2*)(dqkv + (size_t)m * ld + c);
+        dv2u[u] = *(const uint2*)(dqkv + (size_t)m * ld + 2 * H + c);
+        x2u[u] = *(const uint2*)(x + (size_t)m * H + c);
+        t4u[u] = *(const uint4*)(t + (size_t)m * 8);
+        d4u[u] = *(const uint4*)(dt + (size_t)m * ld_dt);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (mb + 4 * u >= m1) break;
+        const uint2 dq2 = dq2u[u], dv2 = dv2u[u], x2 = x2u[u];
+        const uint4 t4 = t4u[u], d4 = d4u[u];
         const float dq[4] = {bf2f((unsigned short)(dq2.x & 0xffff)), bf2f((unsigned short)(dq2.x >> 16)),
                              bf2f((unsigned short)(dq2.y & 0xffff)), bf2f((unsigned short)(dq2.y >> 16))};
         const float dv[4] = {bf2f((unsigned short)(dv2.x & 0xffff)), bf2f((unsigned short)(dv2.x >> 16)),
@@ -131,11 +148,12 @@ __global__ __launch_bounds__(1024) void lora_wgrad_kernel(const unsigned short* 
                 accAq[e][r] += gq[r] * xv[e];
                 accAv[e][r] += gv[r] * xv[e];
             }
+      }
     }
-    lw_reduce_emit<false>(accBq, red, grp, ct, cthreads, dB_q, c, H);
-    lw_reduce_emit<false>(accBv, red, grp, ct, cthreads, dB_v, c, H);
-    lw_reduce_emit<true>(accAq, red, grp, ct, cthreads, dA_q, c, H);
-    lw_reduce_emit<true>(accAv, red, grp, ct, cthreads, dA_v, c, H);
+    lw_reduce_emit<false>(accBq, red, outl, grp, ct, cthreads, dB_q, c, H);
+    lw_reduce_emit<false>(accBv, red, outl, grp, ct, cthreads, dB_v, c, H);
+    lw_reduce_emit<true>(accAq, red, outl, grp, ct, cthreads, dA_q, c, H);
+    lw_reduce_emit<true>(accAv, red, outl, grp, ct, cthreads, dA_v, c, H);
 }
 
 }  // namespace clibd
@@ -162,7 +180,7 @@ extern "C" int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf1
     if (!aligned16(dqkv) || !aligned16(x_bf16) || !aligned16(t_bf16) || !aligned16(dt_bf16))
         return set_error(CLIBD_EINVAL, "lora_wgrad: alignment");
     const int blocks = (M + LW_ROWS - 1) / LW_ROWS;
-    const size_t lds = (size_t)3 * (H / 4) * 16 * sizeof(float);
+    const size_t lds = ((size_t)3 * (H / 4) * 16 + (size_t)4 * H + (size_t)(4 * H) / 32 + 32) * sizeof(float);
     hipLaunchKernelGGL(lora_wgrad_kernel, dim3(blocks), dim3(H), lds, (hipStream_t)stream, (const unsigned short*)dqkv, ld_dqkv,
                        (const unsigned short*)x_bf16, (const unsigned short*)t_bf16, (const unsigned short*)dt_bf16, ld_dt, M, H,
                        dA_q, dA_v, dB_q, dB_v);

@@ -418,3 +418,52 @@ def test_adamw_matches_torch(ops, dev):
         ops.adamw_step(p, (gr * 4).to(dev), m, v, 3e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=0.25)
     torch.cuda.synchronize()
     assert (p.cpu() - pt.detach()).abs().max().item() < 2e-6
+
+
+# ----------------------------------------------------------------------------------------------- GEMM, 256x256 8-phase kernel
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 128), (2000, 4096, 256), (4096, 2048, 768), (1500, 6144, 3072), (50432, 768, 768)])
+def test_gemm256_exact_integers(ops, dev, M, N, K):
+    """Shapes the dispatcher routes to gemm256_bf16_nt_kernel (>=128 tiles of 256x256, K % 128 == 0): exact integer products,
+    asymmetric operands, ragged M; repeated launches must be bit-identical (LDS-DMA pipeline races show up as flaky tiles)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    a[:, 0] += (torch.arange(M) % 5).float()
+    w[:, 1] += (torch.arange(N) % 7).float()
+    ad, wd = a.to(dev, BF16), w.to(dev, BF16)
+    ref = (ad.float() @ wd.float().T)  # exact in fp32: |values| small, K <= 3072
+    out = torch.empty((M, N), dtype=F32, device=dev)
+    for _ in range(3):
+        out.fill_(float("nan"))
+        ops.gemm_nt(ad, wd, out_f32=out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
+def test_gemm256_epilogues(ops, dev):
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 4096, 2304, 768
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    u, v = torch.randn(M, 8, generator=g), torch.randn(N, 8, generator=g) * 0.1
+    res = torch.randn(M, N, generator=g)
+    ad, wd = a.to(dev, BF16), w.to(dev, BF16)
+    base = ad.float() @ wd.float().T
+    # bias + rank-8 -> bf16
+    out = torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(ad, wd, bias=b.to(dev), rank_u=u.to(dev, BF16), rank_v=v.to(dev, BF16), out_bf16=out)
+    ref = base + (bfr(u) @ bfr(v).T).to(dev) + b.to(dev)
+    assert rel_err(out.float().cpu(), ref.cpu()) < 4e-3
+    # bias + GELU with saved pre-activation
+    pre = torch.empty((M, N), dtype=BF16, device=dev)
+    act = torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(ad, wd, bias=b.to(dev), act=ops.ACT_GELU, out_pre=pre, out_bf16=act)
+    pre_ref = bfr((base + b.to(dev)).cpu())
+    assert rel_err(pre.float().cpu(), pre_ref) < 3e-3
+    assert rel_err(act.float().cpu(), gelu(pre_ref)) < 5e-3
+    # residual fp32 + GELU' aux
+    aux = torch.randn(M, N, generator=g)
+    outf = torch.empty((M, N), dtype=F32, device=dev)
+    ops.gemm_nt(ad, wd, act=ops.ACT_GELU_GRAD, aux=aux.to(dev, BF16), residual=res.to(dev), out_f32=outf)
+    ref = base.cpu() * gelu_grad(bfr(aux)) + res
+    assert rel_err(outf.cpu(), ref) < 1e-4
