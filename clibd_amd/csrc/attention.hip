@@ -91,20 +91,23 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
     const int H = nheads * DH;
     const size_t ld = (size_t)3 * H;
     const unsigned short* qbase = qkv + (size_t)b * S * ld + h * DH;
+    const int g = lane >> 4, i = lane & 15;
+    const int nqt = (S + 15) >> 4;
+    const float c2 = scale * 1.4426950408889634f;  // p = exp2(c2 * s - c2 * max): one FMA + one v_exp per score
+    // this wave's first Q fragment rides along with the K/V staging; later ones are prefetched a tile ahead
+    bf16x8 qf[2];
+    {
+        const int qc0 = min(wave * 16 + i, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (size_t)qc0 * ld + 32 * ks + 8 * g);
+    }
     stage_head_tile(kt_lds, qbase + H, ld, S, S_pad, wave, lane);
     stage_head_tile(vt_lds, qbase + 2 * H, ld, S, S_pad, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int g = lane >> 4, i = lane & 15;
-    // per-lane key validity for keys 16*kt + 4*g + r
-    const int nqt = (S + 15) >> 4;
     for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
         const int q = qt * 16 + i;
-        const int qc = min(q, S - 1);
-        bf16x8 qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (size_t)qc * ld + 32 * ks + 8 * g);
         f32x4 sc[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -113,25 +116,34 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
             for (int ks = 0; ks < 2; ++ks)
                 sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(kt_lds, kt * 16 + i, ks, g), qf[ks], sc[kt], 0, 0, 0);
         }
+        {   // prefetch the next tile's Q fragment (clamped; unused after the last tile)
+            const int qn = min((qt + ATT_WAVES) * 16 + i, S - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (size_t)qn * ld + 32 * ks + 8 * g);
+        }
         float mx = NEG_BIG;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt * 16 + 15 >= S || key_mask != nullptr) {  // only tiles that can hold masked keys pay for the test
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + 4 * g + r;
-                bool ok = key < S;
-                if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
-                const float v = ok ? sc[kt][r] * scale : NEG_BIG;
-                sc[kt][r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    bool ok = key < S;
+                    if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+                    if (!ok) sc[kt][r] = NEG_BIG;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+        }
         mx = group4_max(mx);
+        const float mc = mx * c2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(sc[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c2, -mc));  // masked scores underflow to exactly 0
                 sc[kt][r] = e;
                 sum += e;
             }
@@ -142,10 +154,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < NKT / 2; ++s) {
-            f32x4 p0 = sc[2 * s], p1 = sc[2 * s + 1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { p0[r] *= inv; p1[r] *= inv; }
-            const bf16x8 pf = pack_frag(p0, p1);
+            const bf16x8 pf = pack_frag(sc[2 * s], sc[2 * s + 1]);  // un-normalised probabilities (<= 1); 1/sum is applied to O
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(vt_lds, s, dt, lane), pf, o[dt], 0, 0, 0);
@@ -155,8 +164,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 pk;
-                pk.x = pack2bf(o[dt][0], o[dt][1]);
-                pk.y = pack2bf(o[dt][2], o[dt][3]);
+                pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+                pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
                 *(uint2*)(orow + 16 * dt + 4 * g) = pk;
             }
         }
@@ -186,6 +195,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     unsigned short* dqbase = dqkv + (size_t)b * S * ld + h * DH;
     const int g = lane >> 4, i = lane & 15;
 
+    const float c2 = scale * 1.4426950408889634f;
+    bf16x8 qf[2], dof[2];
+    {
+        const int qc0 = min(wave * 16 + i, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = *(const bf16x8*)(qbase + (size_t)qc0 * ld + 32 * ks + 8 * g);
+            dof[ks] = *(const bf16x8*)(dobase + (size_t)qc0 * H + 32 * ks + 8 * g);
+        }
+    }
     stage_head_tile(t0, qbase + H, ld, S, S_pad, wave, lane);
     stage_head_tile(t1, qbase + 2 * H, ld, S, S_pad, wave, lane);
     for (int r = threadIdx.x; r < S_pad; r += ATT_THREADS) { st_m[r] = 0.f; st_il[r] = 0.f; st_d[r] = 0.f; }
@@ -196,13 +215,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     const int nqt = (S + 15) >> 4;
     for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
         const int q = qt * 16 + i;
-        const int qc = min(q, S - 1);
-        bf16x8 qf[2], dof[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = *(const bf16x8*)(qbase + (size_t)qc * ld + 32 * ks + 8 * g);
-            dof[ks] = *(const bf16x8*)(dobase + (size_t)qc * H + 32 * ks + 8 * g);
-        }
         f32x4 sc[NKT], dp[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -214,41 +226,47 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                 dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t1, kt * 16 + i, ks, g), dof[ks], dp[kt], 0, 0, 0);
             }
         }
+        {   // prefetch the next tile's Q / dO fragments
+            const int qn = min((qt + ATT_WAVES) * 16 + i, S - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                qf[ks] = *(const bf16x8*)(qbase + (size_t)qn * ld + 32 * ks + 8 * g);
+                dof[ks] = *(const bf16x8*)(dobase + (size_t)qn * H + 32 * ks + 8 * g);
+            }
+        }
         float mx = NEG_BIG;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt * 16 + 15 >= S || key_mask != nullptr) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + 4 * g + r;
-                bool ok = key < S;
-                if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
-                const float v = ok ? sc[kt][r] * scale : NEG_BIG;
-                sc[kt][r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    bool ok = key < S;
+                    if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+                    if (!ok) sc[kt][r] = NEG_BIG;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+        }
         mx = group4_max(mx);
-        float sum = 0.f;
+        const float mc = mx * c2;
+        float sum = 0.f, dl = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(sc[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c2, -mc));  // un-normalised probability
                 sc[kt][r] = e;
                 sum += e;
+                dl += e * dp[kt][r];
             }
         sum = group4_sum(sum);
-        const float inv = 1.0f / sum;
-        float dl = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = sc[kt][r] * inv;  // fp32 softmax output (autograd differentiates the fp32 softmax)
-                sc[kt][r] = p;
-                dl += p * dp[kt][r];
-            }
         dl = group4_sum(dl);
-        if (g == 0) { st_m[q] = mx; st_il[q] = inv; st_d[q] = dl; }  // q < S_pad always
+        const float inv = 1.0f / sum;
+        dl *= inv;                                   // delta = sum_k P dP with P = e / sum (the fp32 softmax output)
+        const float sinv = scale * inv;              // dS = P (dP - delta) scale = e (dP - delta) (scale / sum)
+        if (g == 0) { st_m[q] = mc; st_il[q] = inv; st_d[q] = dl; }  // q < S_pad always
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0, 0, 0, 0};
@@ -257,8 +275,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
             f32x4 d0, d1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                d0[r] = sc[2 * s][r] * (dp[2 * s][r] - dl) * scale;
-                d1[r] = sc[2 * s + 1][r] * (dp[2 * s + 1][r] - dl) * scale;
+                d0[r] = sc[2 * s][r] * (dp[2 * s][r] - dl) * sinv;
+                d1[r] = sc[2 * s + 1][r] * (dp[2 * s + 1][r] - dl) * sinv;
             }
             const bf16x8 dsf = pack_frag(d0, d1);
 #pragma unroll
@@ -279,6 +297,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     __syncthreads();  // every wave is done reading K/V tiles; statistics are visible
 
     // ---------------- phase 2: per 16-key tile: dV, dK (query on the MFMA row, key on the lane) ----------------
+    bf16x8 kf[2], vf[2], kfn[2], vfn[2];
+    {
+        const int kc0 = min(wave * 16 + i, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[ks] = *(const bf16x8*)(qbase + H + (size_t)kc0 * ld + 32 * ks + 8 * g);
+            vf[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kc0 * ld + 32 * ks + 8 * g);
+        }
+    }
     stage_head_tile(t0, qbase, ld, S, S_pad, wave, lane);
     stage_head_tile(t1, dobase, (size_t)H, S, S_pad, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -287,14 +314,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     const int nkt = (S + 15) >> 4;
     for (int kt = wave; kt < nkt; kt += ATT_WAVES) {
         const int key = kt * 16 + i;
-        const int kc = min(key, S - 1);
         bool key_ok = key < S;
         if (key_ok && key_mask != nullptr) key_ok = key_mask[(size_t)b * S + key] != 0;
-        bf16x8 kf[2], vf[2];
+        {   // next key tile's K / V fragments fly during this tile's sweep over the queries
+            const int kn = min((kt + ATT_WAVES) * 16 + i, S - 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kf[ks] = *(const bf16x8*)(qbase + H + (size_t)kc * ld + 32 * ks + 8 * g);
-            vf[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kc * ld + 32 * ks + 8 * g);
+            for (int ks = 0; ks < 2; ++ks) {
+                kfn[ks] = *(const bf16x8*)(qbase + H + (size_t)kn * ld + 32 * ks + 8 * g);
+                vfn[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kn * ld + 32 * ks + 8 * g);
+            }
         }
         f32x4 dv[4], dk[4];
 #pragma unroll
@@ -316,7 +344,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                     const int qq = qt * 16 + 4 * g + r;
                     const bool ok = key_ok && (qq < S);
                     const float m = st_m[qq], il = st_il[qq], dl = st_d[qq];
-                    const float p = ok ? __expf(sv[r] * scale - m) * il : 0.f;  // rounded to bf16 only inside dV's operand
+                    const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -m)) * il : 0.f;  // rounded to bf16 only inside dV's operand
                     pp[hq][r] = p;
                     dd[hq][r] = p * (dpv[r] - dl) * scale;
                 }
@@ -343,6 +371,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                 *(uint2*)(vrow + 16 * dt + 4 * g) = pk;
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
     }
 }
 

@@ -30,6 +30,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
+// 16-byte store with the non-temporal hint: GEMM outputs are written once and re-read by a later kernel, long after
+// they would have been evicted; keeping them out of the way leaves the XCD L2 to the A / W panels other workgroups share
+__device__ __forceinline__ void store16_stream(void* p, uint4 v) {
+#ifdef CLIBD_NT_STORES
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, (u32x4_t*)p);
+#else
+    *(uint4*)p = v;
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -52,6 +63,17 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 __device__ __forceinline__ float gelu_f(float x) {
     return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f));
+}
+// gelu(x) and gelu'(x) from ONE erf evaluation: exp(-(x/sqrt2)^2) inside the erf is also the Gaussian of phi(x)
+__device__ __forceinline__ void gelu_and_grad_f(float x, float& y, float& dy) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = __expf(-ax * ax);                       // = exp(-x^2 / 2)
+    const float erfv = copysignf(1.0f - poly * e, x);
+    const float cdf = 0.5f * (1.0f + erfv);
+    y = x * cdf;
+    dy = cdf + x * (0.3989422804014327f * e);
 }
 // d/dx gelu(x) = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad_f(float x) {

@@ -55,12 +55,21 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
         for (int e = 0; e < 16; ++e) atomicAdd(o + e, v[e]);
         return;
     }
-    if (ep.out_pre_bf16 != nullptr) {
+    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
+        float dg[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gelu_and_grad_f(bfround(v[e]), v[e], dg[e]);
+        uint4 lo, hi;
+        lo.x = pack2bf(dg[0], dg[1]);   lo.y = pack2bf(dg[2], dg[3]);   lo.z = pack2bf(dg[4], dg[5]);   lo.w = pack2bf(dg[6], dg[7]);
+        hi.x = pack2bf(dg[8], dg[9]);   hi.y = pack2bf(dg[10], dg[11]); hi.z = pack2bf(dg[12], dg[13]); hi.w = pack2bf(dg[14], dg[15]);
+        uint4* o = (uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb);
+        store16_stream(o, lo); store16_stream(o + 1, hi);
+    } else if (ep.out_pre_bf16 != nullptr) {
         uint4 lo, hi;
         lo.x = pack2bf(v[0], v[1]);   lo.y = pack2bf(v[2], v[3]);   lo.z = pack2bf(v[4], v[5]);   lo.w = pack2bf(v[6], v[7]);
         hi.x = pack2bf(v[8], v[9]);   hi.y = pack2bf(v[10], v[11]); hi.z = pack2bf(v[12], v[13]); hi.w = pack2bf(v[14], v[15]);
         uint4* o = (uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb);
-        o[0] = lo; o[1] = hi;
+        store16_stream(o, lo); store16_stream(o + 1, hi);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = bfround(v[e]);
     }
@@ -77,6 +86,16 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
             v[2 * e + 1] *= gelu_grad_f(bf2f((unsigned short)(xs[e] >> 16)));
         }
     }
+    if (ep.act == CLIBD_ACT_MUL_AUX) {
+        const uint4* ax = (const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        const uint4 x0 = ax[0], x1 = ax[1];
+        const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[2 * e] *= bf2f((unsigned short)(xs[e] & 0xffffu));
+            v[2 * e + 1] *= bf2f((unsigned short)(xs[e] >> 16));
+        }
+    }
     if (ep.residual_f32 != nullptr) {
         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
 #pragma unroll
@@ -88,14 +107,14 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
     if (ep.out_f32 != nullptr) {
         f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        for (int q = 0; q < 4; ++q) store16_stream(o + q, __builtin_bit_cast(uint4, (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}));
     }
     if (ep.out_bf16 != nullptr) {
         uint4 lo, hi;
         lo.x = pack2bf(v[0], v[1]);   lo.y = pack2bf(v[2], v[3]);   lo.z = pack2bf(v[4], v[5]);   lo.w = pack2bf(v[6], v[7]);
         hi.x = pack2bf(v[8], v[9]);   hi.y = pack2bf(v[10], v[11]); hi.z = pack2bf(v[12], v[13]); hi.w = pack2bf(v[14], v[15]);
         uint4* o = (uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb);
-        o[0] = lo; o[1] = hi;
+        store16_stream(o, lo); store16_stream(o + 1, hi);
     }
 }
 

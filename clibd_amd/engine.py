@@ -169,8 +169,8 @@ class TransformerStack:
                 ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
                 ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
-                h = new(FF, BF16)
-                ops.gemm_nt(xn2, c.w1, bias=c.b1, act=ops.ACT_GELU, out_pre=h, out_bf16=a)
+                h = new(FF, BF16) if save else None      # holds gelu'(fc1 out): all the backward needs
+                ops.gemm_nt(xn2, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                 x2 = new(H, F32)
                 ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1, out_f32=x2)
                 if save:
@@ -186,8 +186,8 @@ class TransformerStack:
                 x1_f32, x1_bf16 = new(H, F32), new(H, BF16)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
                 ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_bf16=x1_bf16, y_f32=x1_f32, stats=st1)
-                h = new(FF, BF16)
-                ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU, out_pre=h, out_bf16=a)
+                h = new(FF, BF16) if save else None
+                ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                 s2 = new(H, F32)
                 ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1_f32, out_f32=s2)
                 x2_f32, x2_bf16 = new(H, F32), new(H, BF16)
@@ -219,7 +219,7 @@ class TransformerStack:
             if i < first_lora:
                 break  # nothing trainable at or below this layer
             if self.pre_ln:
-                ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_GELU_GRAD, aux=rec["h"], out_bf16=dh)          # d(fc1 out)
+                ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)          # d(fc1 out)
                 ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
                 dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16)
@@ -235,7 +235,7 @@ class TransformerStack:
             else:
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16)
-                ops.gemm_nt(ds2_bf16, c.w2_t, act=ops.ACT_GELU_GRAD, aux=rec["h"], out_bf16=dh)
+                ops.gemm_nt(ds2_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)
                 dx1 = new(H, F32)
                 ops.gemm_nt(dh, c.w1_t, residual=ds2_f32, out_f32=dx1)
                 ds1_f32, ds1_bf16 = new(H, F32), new(H, BF16)

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import GemmEpilogue, check
 
-ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
 
 

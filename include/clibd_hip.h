@@ -45,12 +45,15 @@ int clibd_abi_version(void);
  *   if out_pre_bf16:  out_pre_bf16[m,n] = bf16(v); v = float(bf16(v))           (pre-activation, saved for bwd)
  *   if act == CLIBD_ACT_GELU:       v = gelu_erf(v)                             (timm Mlp.act / HF "gelu")
  *   if act == CLIBD_ACT_GELU_GRAD:  v = v * gelu'(aux_bf16[m,n])                (dgrad through GELU)
+ *   if act == CLIBD_ACT_GELU_SAVE_GRAD (needs out_pre_bf16): x = float(bf16(v)); out_pre_bf16[m,n] = bf16(gelu'(x));
+ *                                   v = gelu_erf(x)    (training forward: the backward then needs no transcendental)
+ *   if act == CLIBD_ACT_MUL_AUX:    v = v * aux_bf16[m,n]                       (dgrad through GELU with saved gelu')
  *   if residual_f32:  v += residual_f32[m,n]
  *   out_bf16[m,n] = bf16(v) ; out_f32[m,n] = v   (either or both)
  *   split_k > 1: only out_f32 allowed; partial sums are atomically added into a caller-zeroed out_f32.
  * Constraints: K % 64 == 0, lda/ldw % 8 == 0, N % 16 == 0, all ld_* % 8 == 0, 16-byte aligned pointers.
  * ------------------------------------------------------------------------------------------------ */
-enum { CLIBD_ACT_NONE = 0, CLIBD_ACT_GELU = 1, CLIBD_ACT_GELU_GRAD = 2 };
+enum { CLIBD_ACT_NONE = 0, CLIBD_ACT_GELU = 1, CLIBD_ACT_GELU_GRAD = 2, CLIBD_ACT_GELU_SAVE_GRAD = 3, CLIBD_ACT_MUL_AUX = 4 };
 
 typedef struct clibd_gemm_epilogue {
     const float* bias;          /* [N] fp32 */

@@ -113,8 +113,12 @@ def attention_core(q, k, v, mask_add=None):
     s = (_r(q) @ _r(k).transpose(-1, -2)) * (q.shape[-1] ** -0.5)
     if mask_add is not None:
         s = s + mask_add
-    p = torch.softmax(s, dim=-1)
-    return _rg(_r(_r(p) @ _r(v)))
+    if _PRECISION == "fp32":
+        return torch.softmax(s, dim=-1) @ v
+    # kernel rounding points: the UN-normalised exp(s - max) is what gets rounded to bf16 for the P·V product,
+    # and the fp32 row sum divides the fp32 result (same function as softmax, same relative rounding error)
+    e = torch.exp(s - s.max(dim=-1, keepdim=True).values.detach())
+    return _rg(_r((_r(e) @ _r(v)) / e.sum(dim=-1, keepdim=True)))
 
 
 class Attention(nn.Module):

@@ -467,3 +467,21 @@ def test_gemm256_epilogues(ops, dev):
     ops.gemm_nt(ad, wd, act=ops.ACT_GELU_GRAD, aux=aux.to(dev, BF16), residual=res.to(dev), out_f32=outf)
     ref = base.cpu() * gelu_grad(bfr(aux)) + res
     assert rel_err(outf.cpu(), ref) < 1e-4
+
+
+def test_gemm_gelu_save_grad_and_mul_aux(ops, dev):
+    g = torch.Generator().manual_seed(91)
+    M, N, K = 300, 256, 128
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    pre_ref = bfr(bfr(a) @ bfr(w).T + b)
+    dg = torch.empty((M, N), dtype=BF16, device=dev)
+    act = torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), bias=b.to(dev), act=ops.ACT_GELU_SAVE_GRAD, out_pre=dg, out_bf16=act)
+    torch.cuda.synchronize()
+    assert rel_err(act.cpu().float(), gelu(pre_ref)) < 5e-3
+    assert rel_err(dg.cpu().float(), gelu_grad(pre_ref)) < 5e-3
+    aux = bfr(torch.randn(M, N, generator=g))
+    out = torch.empty((M, N), dtype=F32, device=dev)
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), act=ops.ACT_MUL_AUX, aux=aux.to(dev, BF16), out_f32=out)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), (bfr(a) @ bfr(w).T) * aux) < 1e-5
