@@ -11,6 +11,8 @@
 // row m.  W rows are additionally permuted when they are placed in LDS (row n_local = 16g+4t+r sits at
 // LDS row 16t+4g+r) so the 4 n-tiles of a lane are 16 CONTIGUOUS output columns: 32-byte bf16 /
 // 64-byte fp32 stores per lane, and full 128-B lines per row across a wave.
+#include <stdlib.h>
+
 #include "gemm_common.h"
 #include "host_util.h"
 
@@ -236,7 +238,11 @@ extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw
     p.ktiles_per_split = (ktiles + split - 1) / split;
     p.ep = *ep;
     p.ep.split_k = split;
-    if (gemm256_try_launch(p, (hipStream_t)stream)) return check_launch("gemm256_bf16_nt");
+    // kernel choice (CLIBD_GEMM_KERNEL=1 forces the 128x128 kernel: tuning aid).  A third shape — 256x128x32 tiles, 3-stage
+    // ring, two workgroups per CU so epilogues overlap across workgroups — was built and measured: 800 TF at K=768 and
+    // 920 TF at K=3072 against 944 / 1300 TF for the 256x256 8-phase kernel, so it was dropped.
+    static const int forced = [] { const char* e = getenv("CLIBD_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
+    if (forced != 1 && gemm256_try_launch(p, (hipStream_t)stream)) return check_launch("gemm256_bf16_nt");
     const long long nblocks = (long long)p.tiles_m * p.tiles_n * split;
     if (nblocks > 0x7fffffffLL) return set_error(CLIBD_EINVAL, "gemm: grid too large");
     static const bool attr_ok = [] {

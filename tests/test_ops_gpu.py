@@ -421,7 +421,7 @@ def test_adamw_matches_torch(ops, dev):
 
 
 # ----------------------------------------------------------------------------------------------- GEMM, 256x256 8-phase kernel
-@pytest.mark.parametrize("M,N,K", [(2048, 4096, 128), (2000, 4096, 256), (4096, 2048, 768), (1500, 6144, 3072), (50432, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 128), (2000, 4096, 256), (4096, 2048, 768), (1500, 6144, 3072), (50432, 768, 768), (2048, 4096, 1536), (3000, 2304, 64 * 7)])
 def test_gemm256_exact_integers(ops, dev, M, N, K):
     """Shapes the dispatcher routes to gemm256_bf16_nt_kernel (>=128 tiles of 256x256, K % 128 == 0): exact integer products,
     asymmetric operands, ragged M; repeated launches must be bit-identical (LDS-DMA pipeline races show up as flaky tiles)."""
