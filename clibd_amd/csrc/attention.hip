@@ -80,7 +80,8 @@ constexpr float NEG_BIG = -1.0e30f;
 template <int NKT>  // number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32)
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
-                                                                    unsigned short* __restrict__ out, float scale) {
+                                                                    unsigned short* __restrict__ out, float scale,
+                                                                    int nq, int out_seq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
     char* kt_lds = smem;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
     const size_t ld = (size_t)3 * H;
     const unsigned short* qbase = qkv + (size_t)b * S * ld + h * DH;
     const int g = lane >> 4, i = lane & 15;
-    const int nqt = (S + 15) >> 4;
+    const int nqt = (nq + 15) >> 4;  // only the first nq query rows are evaluated (nq = S normally; 1 = [CLS]-only last ViT block)
     const float c2 = scale * 1.4426950408889634f;  // p = exp2(c2 * s - c2 * max): one FMA + one v_exp per score
     // this wave's first Q fragment rides along with the K/V staging; later ones are prefetched a tile ahead
     bf16x8 qf[2];
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
             for (int dt = 0; dt < 4; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(vt_lds, s, dt, lane), pf, o[dt], 0, 0, 0);
         }
-        if (q < S) {
-            unsigned short* orow = out + ((size_t)b * S + q) * H + h * DH;
+        if (q < nq) {
+            unsigned short* orow = out + ((size_t)b * out_seq + q) * H + h * DH;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 pk;
@@ -177,7 +178,8 @@ template <int NKT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                                     const unsigned short* __restrict__ dout, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
-                                                                    unsigned short* __restrict__ dqkv, float scale) {
+                                                                    unsigned short* __restrict__ dqkv, float scale,
+                                                                    int nq, int dout_seq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
     char* t0 = smem;                      // phase 1: K   | phase 2: Q
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     const int H = nheads * DH;
     const size_t ld = (size_t)3 * H;
     const unsigned short* qbase = qkv + (size_t)b * S * ld + h * DH;
-    const unsigned short* dobase = dout + (size_t)b * S * H + h * DH;
+    const unsigned short* dobase = dout + (size_t)b * dout_seq * H + h * DH;  // dO holds rows [0, nq) of every sequence
     unsigned short* dqbase = dqkv + (size_t)b * S * ld + h * DH;
     const int g = lane >> 4, i = lane & 15;
 
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             qf[ks] = *(const bf16x8*)(qbase + (size_t)qc0 * ld + 32 * ks + 8 * g);
-            dof[ks] = *(const bf16x8*)(dobase + (size_t)qc0 * H + 32 * ks + 8 * g);
+            dof[ks] = *(const bf16x8*)(dobase + (size_t)min(qc0, nq - 1) * H + 32 * ks + 8 * g);
         }
     }
     stage_head_tile(t0, qbase + H, ld, S, S_pad, wave, lane);
@@ -212,9 +214,22 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     __syncthreads();
 
     // ---------------- phase 1: per 16-query tile: softmax statistics, dS, dQ ----------------
-    const int nqt = (S + 15) >> 4;
+    const int nqt = (nq + 15) >> 4;      // query tiles that carry a gradient (rows >= nq have dO = 0)
+    const int nqt_all = (S + 15) >> 4;
+    for (int qt = nqt + wave; qt < nqt_all; qt += ATT_WAVES) {  // dQ of the inactive query rows is exactly zero
+        const int q = qt * 16 + i;
+        if (q < S) {
+            unsigned short* orow = dqbase + (size_t)q * ld;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(uint2*)(orow + 16 * dt + 4 * g) = make_uint2(0u, 0u);
+        }
+    }
     for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
         const int q = qt * 16 + i;
+        if (q >= nq) {  // rows of an active tile beyond nq: their dO is zero
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dof[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
         f32x4 sc[NKT], dp[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 qf[ks] = *(const bf16x8*)(qbase + (size_t)qn * ld + 32 * ks + 8 * g);
-                dof[ks] = *(const bf16x8*)(dobase + (size_t)qn * H + 32 * ks + 8 * g);
+                dof[ks] = *(const bf16x8*)(dobase + (size_t)min(qn, nq - 1) * H + 32 * ks + 8 * g);
             }
         }
         float mx = NEG_BIG;
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
         }
     }
     stage_head_tile(t0, qbase, ld, S, S_pad, wave, lane);
-    stage_head_tile(t1, dobase, (size_t)H, S, S_pad, wave, lane);
+    stage_head_tile(t1, dobase, (size_t)H, nq, S_pad, wave, lane);  // rows >= nq are clamped copies, masked below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
 #pragma unroll 1
-        for (int s = 0; s < NKT / 2; ++s) {
+        for (int s = 0; s < (nqt + 1) / 2; ++s) {  // only query tiles that carry a gradient
             f32x4 pp[2], dd[2];
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = qt * 16 + 4 * g + r;
-                    const bool ok = key_ok && (qq < S);
+                    const bool ok = key_ok && (qq < nq);
                     const float m = st_m[qq], il = st_il[qq], dl = st_d[qq];
                     const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -m)) * il : 0.f;  // rounded to bf16 only inside dV's operand
                     pp[hq][r] = p;
@@ -403,9 +418,10 @@ using namespace clibd;
     }
 
 extern "C" int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
-                                   void* stream) {
+                                   int nq, int out_seq, void* stream) {
     if (int e = att_check(qkv, B, S, nheads, "fwd")) return e;
     if (!out) return set_error(CLIBD_EINVAL, "attention_fwd: null out");
+    if (nq < 1 || nq > S || out_seq < nq) return set_error(CLIBD_EINVAL, "attention_fwd: need 1 <= nq <= S and out_seq >= nq");
     const int nkt = 2 * ((S + 31) / 32);
     const size_t lds = (size_t)2 * nkt * 16 * 128;
     const float scale = 0.125f;  // 1/sqrt(64)
@@ -414,7 +430,7 @@ extern "C" int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, co
     do {                                                                                                          \
         hipFuncSetAttribute((const void*)attention_fwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(attention_fwd_kernel<N>, dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
-                           (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale); \
+                           (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq); \
     } while (0)
     ATT_DISPATCH(nkt, LAUNCH)
 #undef LAUNCH
@@ -422,9 +438,10 @@ extern "C" int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, co
 }
 
 extern "C" int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
-                                   void* dqkv, void* stream) {
+                                   void* dqkv, int nq, int dout_seq, void* stream) {
     if (int e = att_check(qkv, B, S, nheads, "bwd")) return e;
     if (!dout || !dqkv) return set_error(CLIBD_EINVAL, "attention_bwd: null pointer");
+    if (nq < 1 || nq > S || dout_seq < nq) return set_error(CLIBD_EINVAL, "attention_bwd: need 1 <= nq <= S and dout_seq >= nq");
     if (!aligned16(dout) || !aligned16(dqkv)) return set_error(CLIBD_EINVAL, "attention_bwd: alignment");
     const int nkt = 2 * ((S + 31) / 32);
     const size_t lds = (size_t)2 * nkt * 16 * 128 + (size_t)3 * nkt * 16 * sizeof(float);
@@ -435,7 +452,7 @@ extern "C" int clibd_attention_bwd(const void* qkv, const void* dout, int B, int
         hipFuncSetAttribute((const void*)attention_bwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(attention_bwd_kernel<N>, dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
                            (const unsigned short*)qkv, (const unsigned short*)dout, S, nheads, (const int*)key_mask, \
-                           (unsigned short*)dqkv, scale);                                                         \
+                           (unsigned short*)dqkv, scale, nq, dout_seq);                                           \
     } while (0)
     ATT_DISPATCH(nkt, LAUNCH)
 #undef LAUNCH

@@ -142,9 +142,12 @@ class TransformerStack:
         return self._cache[i].a_cat
 
     # ---- forward ------------------------------------------------------------------------------------------------
-    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool):
+    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool, cls_only_last: bool = False):
         """x_f32 [M,H] residual stream entering layer 0.  Post-LN stacks also pass its bf16 image and the layer-0
-        adapter down-projection t0 (both produced by the embedding LayerNorm).  Returns (x_f32, x_bf16, saved)."""
+        adapter down-projection t0 (both produced by the embedding LayerNorm).  Returns (x_f32, x_bf16, saved).
+        cls_only_last (pre-LN only): the caller consumes token 0 only, so the LAST block evaluates attention for that
+        query, and projection + MLP for that row, per sequence — the returned x_f32 is then [B,H] (the other rows of
+        the last block are dead code the reference computes and discards)."""
         H, FF, M = self.H, self.FF, B * S
         dev = x_f32.device
         saved = []
@@ -156,7 +159,31 @@ class TransformerStack:
         for i, (L, c) in enumerate(zip(self.layers, self._cache)):
             has_lora = L.lora is not None
             rec = {}
-            if self.pre_ln:
+            if self.pre_ln and cls_only_last and i == len(self.layers) - 1:
+                xn = new(H, BF16)
+                st1 = torch.empty((M, 2), dtype=F32, device=dev)
+                t = torch.empty((M, 8), dtype=BF16, device=dev) if has_lora else None
+                ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
+                qkv = new(3 * H, BF16)
+                ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
+                newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
+                o_cls = newB(H, BF16)
+                ops.attention_fwd(qkv, B, S, self.heads, key_mask, o_cls, nq=1)
+                x_cls = ops.gather_rows(x_f32.view(B, S, H))
+                x1 = newB(H, F32)
+                ops.gemm_nt(o_cls, c.wo, bias=c.bo, residual=x_cls, out_f32=x1)
+                st2 = torch.empty((B, 2), dtype=F32, device=dev)
+                xn2c = newB(H, BF16)
+                ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2c, stats=st2)
+                h = newB(FF, BF16) if save else None
+                ac = newB(FF, BF16)
+                ops.gemm_nt(xn2c, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h, out_bf16=ac)
+                x2 = newB(H, F32)
+                ops.gemm_nt(ac, c.w2, bias=c.b2, residual=x1, out_f32=x2)
+                if save:
+                    rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h, cls_only=True)
+                x_f32 = x2
+            elif self.pre_ln:
                 # xn = LN1(x) (+ t = xn·A^T);  qkv = xn Wqkv^T + b + t·B^T
                 xn = new(H, BF16)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
@@ -218,7 +245,25 @@ class TransformerStack:
             has_lora = L.lora is not None
             if i < first_lora:
                 break  # nothing trainable at or below this layer
-            if self.pre_ln:
+            if self.pre_ln and rec.get("cls_only"):
+                # dx_f32 / dx_bf16 are [B,H]: the gradient of the class-token row of this block's output
+                newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
+                dhc, dtc = newB(FF, BF16), newB(H, BF16)
+                ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dhc)
+                ops.gemm_nt(dhc, c.w1_t, out_bf16=dtc)
+                dx1_f32, dx1_bf16 = newB(H, F32), newB(H, BF16)
+                ops.layernorm_bwd(dtc, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16)
+                ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtc)                                              # d(attn out), class rows
+                ops.attention_bwd(rec["qkv"], dtc, B, S, self.heads, key_mask, dqkv, nq=1)
+                if has_lora:
+                    self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads)
+                if i > first_lora:
+                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
+                    _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)            # residual path: class rows only
+                    ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
+                    ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16)
+                    dx_f32, dx_bf16 = ndx_f32, ndx_bf16
+            elif self.pre_ln:
                 ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)          # d(fc1 out)
                 ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
                 dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)

@@ -166,29 +166,34 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None) 
                                           _p(dx_bf16), _stream()), "layernorm_bwd")
 
 
-def attention_fwd(qkv: torch.Tensor, B: int, S: int, nheads: int, key_mask: Optional[torch.Tensor], out: torch.Tensor) -> None:
+def attention_fwd(qkv: torch.Tensor, B: int, S: int, nheads: int, key_mask: Optional[torch.Tensor], out: torch.Tensor,
+                  nq: Optional[int] = None) -> None:
+    """nq: evaluate only the first nq query rows of every sequence; `out` is then [B*nq, H]."""
     _chk(qkv, BF16, "qkv")
     _chk(out, BF16, "out")
     H = nheads * 64
-    if tuple(qkv.shape) != (B * S, 3 * H) or tuple(out.shape) != (B * S, H):
-        raise ValueError("attention_fwd: qkv must be [B*S,3H], out [B*S,H] with H = 64*nheads")
+    nq = S if nq is None else nq
+    if tuple(qkv.shape) != (B * S, 3 * H) or tuple(out.shape) != (B * nq, H):
+        raise ValueError("attention_fwd: qkv must be [B*S,3H], out [B*nq,H] with H = 64*nheads")
     if key_mask is not None:
         _chk(key_mask, I32, "key_mask")
         if tuple(key_mask.shape) != (B, S):
             raise ValueError("attention_fwd: key_mask must be [B,S]")
-    check(_lib.load().clibd_attention_fwd(qkv.data_ptr(), B, S, nheads, _p(key_mask), out.data_ptr(), _stream()), "attention_fwd")
+    check(_lib.load().clibd_attention_fwd(qkv.data_ptr(), B, S, nheads, _p(key_mask), out.data_ptr(), nq, nq, _stream()), "attention_fwd")
 
 
-def attention_bwd(qkv, dout, B, S, nheads, key_mask, dqkv) -> None:
+def attention_bwd(qkv, dout, B, S, nheads, key_mask, dqkv, nq: Optional[int] = None) -> None:
+    """nq: `dout` is [B*nq, H] — the gradient of the first nq query rows of every sequence (the rest is zero)."""
     _chk(qkv, BF16, "qkv")
     _chk(dout, BF16, "dout")
     _chk(dqkv, BF16, "dqkv")
     H = nheads * 64
-    if tuple(qkv.shape) != (B * S, 3 * H) or tuple(dout.shape) != (B * S, H) or tuple(dqkv.shape) != (B * S, 3 * H):
+    nq = S if nq is None else nq
+    if tuple(qkv.shape) != (B * S, 3 * H) or tuple(dout.shape) != (B * nq, H) or tuple(dqkv.shape) != (B * S, 3 * H):
         raise ValueError("attention_bwd: shapes")
     if key_mask is not None:
         _chk(key_mask, I32, "key_mask")
-    check(_lib.load().clibd_attention_bwd(qkv.data_ptr(), dout.data_ptr(), B, S, nheads, _p(key_mask), dqkv.data_ptr(), _stream()),
+    check(_lib.load().clibd_attention_bwd(qkv.data_ptr(), dout.data_ptr(), B, S, nheads, _p(key_mask), dqkv.data_ptr(), nq, nq, _stream()),
           "attention_bwd")
 
 

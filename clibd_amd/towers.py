@@ -129,9 +129,10 @@ class ViTTower(_Tower):
         proj = torch.empty((B * 196, H), dtype=F32, device=img.device)
         ops.gemm_nt(patches, self._patch_w, bias=_f32c(v.patch_embed.proj.bias), out_f32=proj)
         tok = ops.vit_assemble_tokens(proj, _f32c(v.cls_token).reshape(H), _f32c(v.pos_embed).reshape(S * H), B)
-        x, _, saved = self.stack.forward(tok.view(B * S, H), None, None, B, S, None, save)
+        # timm pools token 0 (global_pool='token'): only the class row of the last block is live
+        xcls, _, saved = self.stack.forward(tok.view(B * S, H), None, None, B, S, None, save, cls_only_last=True)
+        x = xcls
         # final norm on the class token only (LayerNorm is per token), then the trainable head
-        xcls = ops.gather_rows(x.view(B, S, H))
         st = torch.empty((B, 2), dtype=F32, device=x.device)
         xn = torch.empty((B, H), dtype=BF16, device=x.device)
         ops.layernorm_fwd(xcls, _f32c(v.norm.weight), _f32c(v.norm.bias), float(v.norm.eps), y_bf16=xn, stats=st)
@@ -153,9 +154,9 @@ class ViTTower(_Tower):
         else:
             dxn = ops.cast_bf16(dout)
         dxcls = torch.empty((B, H), dtype=F32, device=dout.device)
-        ops.layernorm_bwd(dxn, state["xcls"], state["st"], _f32c(v.norm.weight), dx_f32=dxcls)
-        dx_bf16, dx_f32 = ops.scatter_rows(dxcls, S, bf16=True, f32=True)
-        self.stack.backward(dx_f32, dx_bf16, state["saved"], B, S, None, grads)
+        dxcls_b = torch.empty((B, H), dtype=BF16, device=dout.device)
+        ops.layernorm_bwd(dxn, state["xcls"], state["st"], _f32c(v.norm.weight), dx_f32=dxcls, dx_bf16=dxcls_b)
+        self.stack.backward(dxcls, dxcls_b, state["saved"], B, S, None, grads)  # [B,H]: the last block runs class-row-only
 
 
 # =========================================================================================================

@@ -104,11 +104,15 @@ int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x
  * image_encoder.py:20-24; HF BertSelfAttention with q/k/v weights concatenated).
  * key_mask (optional) int32 [B,S], 1 = attend, 0 = masked (HF extended attention mask,
  * language_encoder.py:89 via BertModel).  out bf16 [B*S, H].
+ * Query prefix: only query rows [0, nq) of every sequence are evaluated (nq = S: everything; nq = 1: the [CLS]-only
+ * attention of the last ViT block, whose other outputs the reference computes and discards, image_encoder.py:107 ->
+ * timm pools token 0).  out / dout hold `out_seq` (>= nq) rows per sequence: row (b*out_seq + q).  The backward writes
+ * the full dqkv [B*S,3H]: dq of rows >= nq is zero, dk/dv collect the active queries only.
  * ------------------------------------------------------------------------------------------------ */
 int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
-                        void* stream);
+                        int nq, int out_seq, void* stream);
 int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
-                        void* dqkv, void* stream);
+                        void* dqkv, int nq, int dout_seq, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K6: LoRA (rank 4 on q and v; reference image_encoder.py:13-46, dna_encoder.py:68-77,

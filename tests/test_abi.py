@@ -59,7 +59,7 @@ def test_host_side_validation_needs_no_gpu(lib):
     ep = _lib.GemmEpilogue()
     assert L.clibd_gemm_bf16_nt(None, 64, None, 64, 8, 16, 64, ctypes.byref(ep), None) == -1
     assert b"null" in L.clibd_last_error()
-    assert L.clibd_attention_fwd(ctypes.c_void_p(16), 1, 300, 1, None, ctypes.c_void_p(16), None) == -1
+    assert L.clibd_attention_fwd(ctypes.c_void_p(16), 1, 300, 1, None, ctypes.c_void_p(16), 300, 300, None) == -1
     assert L.clibd_softce_workspace_bytes(32, 32, 768) > 32 * 32 * 4
 
 

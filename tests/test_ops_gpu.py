@@ -485,3 +485,27 @@ def test_gemm_gelu_save_grad_and_mul_aux(ops, dev):
     ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), act=ops.ACT_MUL_AUX, aux=aux.to(dev, BF16), out_f32=out)
     torch.cuda.synchronize()
     assert rel_err(out.cpu(), (bfr(a) @ bfr(w).T) * aux) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,nh,nq", [(3, 197, 2, 1), (2, 133, 1, 20), (2, 64, 1, 17)])
+def test_attention_query_prefix(ops, dev, B, S, nh, nq):
+    """nq < S: only the first nq queries are evaluated; backward with dO given for those rows only."""
+    g = torch.Generator().manual_seed(S + nq)
+    H = nh * 64
+    qkv = bfr(torch.randn(B * S, 3 * H, generator=g))
+    qd = qkv.double().requires_grad_(True)
+    oref = _attn_ref(qd, B, S, nh, None).view(B, S, H)[:, :nq].reshape(B * nq, H)
+    out = torch.empty((B * nq, H), dtype=BF16, device=dev)
+    ops.attention_fwd(qkv.to(dev, BF16), B, S, nh, None, out, nq=nq)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().float(), oref.detach()) < 5e-3
+    do = bfr(torch.randn(B * nq, H, generator=g))
+    (gref,) = torch.autograd.grad(oref, qd, do.double())
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=BF16, device=dev)
+    ops.attention_bwd(qkv.to(dev, BF16), do.to(dev, BF16), B, S, nh, None, dqkv, nq=nq)
+    torch.cuda.synchronize()
+    got = dqkv.cpu().float()
+    assert torch.isfinite(got).all()
+    assert rel_err(got, gref) < 1.5e-2
+    dq = got[:, :H].view(B, S, H)
+    assert torch.equal(dq[:, nq:], torch.zeros(B, S - nq, H))
