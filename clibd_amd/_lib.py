@@ -35,6 +35,10 @@ class GemmEpilogue(C.Structure):
         ("ld_out_bf16", C.c_int32),
         ("ld_out_f32", C.c_int32),
         ("split_k", C.c_int32),
+        ("drop_seed", C.c_uint32),
+        ("drop_thr16", C.c_int32),
+        ("drop_scale", C.c_float),
+        ("drop_ld", C.c_int32),
     ]
 
 
@@ -48,6 +52,10 @@ SIGNATURES = {
     "clibd_cast_transpose_f32_to_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "clibd_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clibd_layernorm_fwd_drop": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),
+    "clibd_layernorm_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),
+    "clibd_attention_fwd_drop": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),
+    "clibd_attention_bwd_drop": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),
     "clibd_attention_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "clibd_attention_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "clibd_lora_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -81,7 +81,8 @@ template <int NKT>  // number of 16-key tiles, even (S_pad = 16*NKT, multiple of
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ out, float scale,
-                                                                    int nq, int out_seq) {
+                                                                    int nq, int out_seq, unsigned drop_seed,
+                                                                    int drop_thr16, float drop_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
     char* kt_lds = smem;
@@ -155,7 +156,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < NKT / 2; ++s) {
-            const bf16x8 pf = pack_frag(sc[2 * s], sc[2 * s + 1]);  // un-normalised probabilities (<= 1); 1/sum is applied to O
+            if (drop_thr16 > 0) {  // dropout on the probabilities (HF BertSelfAttention.dropout); index ((b*nh+h)*S+q)*256+key
+                const unsigned base = (((unsigned)blockIdx.x * (unsigned)S + (unsigned)q) << 8) + 32u * s + 4u * g;
+                float f0, f1, f2, f3;
+                drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
+                drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
+                sc[2 * s][0] *= f0; sc[2 * s][1] *= f1; sc[2 * s][2] *= f2; sc[2 * s][3] *= f3;
+                drop_pair(drop_seed, base + 16, (unsigned)drop_thr16, drop_scale, f0, f1);
+                drop_pair(drop_seed, base + 18, (unsigned)drop_thr16, drop_scale, f2, f3);
+                sc[2 * s + 1][0] *= f0; sc[2 * s + 1][1] *= f1; sc[2 * s + 1][2] *= f2; sc[2 * s + 1][3] *= f3;
+            }
+            const bf16x8 pf = pack_frag(sc[2 * s], sc[2 * s + 1]);  // un-normalised probabilities (<= 1/(1-p)); 1/sum is applied to O
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(vt_lds, s, dt, lane), pf, o[dt], 0, 0, 0);
@@ -179,7 +190,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                                                                     const unsigned short* __restrict__ dout, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ dqkv, float scale,
-                                                                    int nq, int dout_seq) {
+                                                                    int nq, int dout_seq, unsigned drop_seed,
+                                                                    int drop_thr16, float drop_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
     char* t0 = smem;                      // phase 1: K   | phase 2: Q
@@ -239,6 +251,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
             for (int ks = 0; ks < 2; ++ks) {
                 sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t0, kt * 16 + i, ks, g), qf[ks], sc[kt], 0, 0, 0);
                 dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t1, kt * 16 + i, ks, g), dof[ks], dp[kt], 0, 0, 0);
+            }
+        }
+        if (drop_thr16 > 0) {  // O = (P o M / (1-p)) V  =>  dP = (dO V^T) o M / (1-p)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const unsigned base = (((unsigned)blockIdx.x * (unsigned)S + (unsigned)q) << 8) + 16u * kt + 4u * g;
+                float f0, f1, f2, f3;
+                drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
+                drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
+                dp[kt][0] *= f0; dp[kt][1] *= f1; dp[kt][2] *= f2; dp[kt][3] *= f3;
             }
         }
         {   // prefetch the next tile's Q / dO fragments
@@ -360,8 +382,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                     const bool ok = key_ok && (qq < nq);
                     const float m = st_m[qq], il = st_il[qq], dl = st_d[qq];
                     const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -m)) * il : 0.f;  // rounded to bf16 only inside dV's operand
-                    pp[hq][r] = p;
-                    dd[hq][r] = p * (dpv[r] - dl) * scale;
+                    float fm = 1.0f;
+                    if (drop_thr16 > 0)
+                        fm = drop_one(drop_seed, (((unsigned)blockIdx.x * (unsigned)S + (unsigned)qq) << 8) + (unsigned)key, (unsigned)drop_thr16, drop_scale);
+                    pp[hq][r] = p * fm;                       // dV = (P o M/(1-p))^T dO
+                    dd[hq][r] = p * (dpv[r] * fm - dl) * scale;  // dS = P o (dP - delta), dP masked as in phase 1
                 }
             }
             const bf16x8 pf = pack_frag(pp[0], pp[1]);
@@ -417,8 +442,10 @@ using namespace clibd;
         default: MACRO(16); break;    \
     }
 
-extern "C" int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
-                                   int nq, int out_seq, void* stream) {
+extern "C" int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
+                                        int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+    if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "attention_fwd: bad dropout threshold");
+    if (drop_thr16 > 0 && (unsigned long long)B * nheads * S * 256ull >= (1ull << 32)) return set_error(CLIBD_EINVAL, "attention_fwd: dropout index overflow");
     if (int e = att_check(qkv, B, S, nheads, "fwd")) return e;
     if (!out) return set_error(CLIBD_EINVAL, "attention_fwd: null out");
     if (nq < 1 || nq > S || out_seq < nq) return set_error(CLIBD_EINVAL, "attention_fwd: need 1 <= nq <= S and out_seq >= nq");
@@ -430,15 +457,24 @@ extern "C" int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, co
     do {                                                                                                          \
         hipFuncSetAttribute((const void*)attention_fwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(attention_fwd_kernel<N>, dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
-                           (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq); \
+                           (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
+                           drop_seed, drop_thr16, drop_scale);                                                    \
     } while (0)
     ATT_DISPATCH(nkt, LAUNCH)
 #undef LAUNCH
     return check_launch("attention_fwd");
 }
 
-extern "C" int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
-                                   void* dqkv, int nq, int dout_seq, void* stream) {
+extern "C" int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
+                                   int nq, int out_seq, void* stream) {
+    return clibd_attention_fwd_drop(qkv, B, S, nheads, key_mask, out, nq, out_seq, 0u, 0, 1.0f, stream);
+}
+
+extern "C" int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
+                                        void* dqkv, int nq, int dout_seq, uint32_t drop_seed, int drop_thr16, float drop_scale,
+                                        void* stream) {
+    if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "attention_bwd: bad dropout threshold");
+    if (drop_thr16 > 0 && (unsigned long long)B * nheads * S * 256ull >= (1ull << 32)) return set_error(CLIBD_EINVAL, "attention_bwd: dropout index overflow");
     if (int e = att_check(qkv, B, S, nheads, "bwd")) return e;
     if (!dout || !dqkv) return set_error(CLIBD_EINVAL, "attention_bwd: null pointer");
     if (nq < 1 || nq > S || dout_seq < nq) return set_error(CLIBD_EINVAL, "attention_bwd: need 1 <= nq <= S and dout_seq >= nq");
@@ -452,9 +488,14 @@ extern "C" int clibd_attention_bwd(const void* qkv, const void* dout, int B, int
         hipFuncSetAttribute((const void*)attention_bwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(attention_bwd_kernel<N>, dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
                            (const unsigned short*)qkv, (const unsigned short*)dout, S, nheads, (const int*)key_mask, \
-                           (unsigned short*)dqkv, scale, nq, dout_seq);                                           \
+                           (unsigned short*)dqkv, scale, nq, dout_seq, drop_seed, drop_thr16, drop_scale);        \
     } while (0)
     ATT_DISPATCH(nkt, LAUNCH)
 #undef LAUNCH
     return check_launch("attention_bwd");
+}
+
+extern "C" int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
+                                   void* dqkv, int nq, int dout_seq, void* stream) {
+    return clibd_attention_bwd_drop(qkv, dout, B, S, nheads, key_mask, dqkv, nq, dout_seq, 0u, 0, 1.0f, stream);
 }

@@ -41,6 +41,25 @@ __device__ __forceinline__ void store16_stream(void* p, uint4 v) {
 #endif
 }
 
+// ---- counter-based dropout (HF BERT hidden / attention-probability dropout in train mode) --------------------------------
+// One 32-bit hash (lowbias32) of (element index >> 1) ^ seed serves an even/odd element PAIR with 16 bits each:
+// keep iff bits >= thr16 = round(p * 65536).  The mask is a pure function of (seed, index): the backward recomputes it.
+__device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned pair) {
+    unsigned x = pair ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// scale factors (0 or 1/(1-p)) of elements idx (even) and idx+1
+__device__ __forceinline__ void drop_pair(unsigned seed, unsigned idx_even, unsigned thr16, float scale, float& f0, float& f1) {
+    const unsigned h = drop_hash(seed, idx_even >> 1);
+    f0 = (h & 0xffffu) >= thr16 ? scale : 0.f;
+    f1 = (h >> 16) >= thr16 ? scale : 0.f;
+}
+__device__ __forceinline__ float drop_one(unsigned seed, unsigned idx, unsigned thr16, float scale) {
+    const unsigned h = drop_hash(seed, idx >> 1);
+    return (((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16) ? scale : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -221,6 +221,8 @@ extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw
     if (ep->out_pre_bf16 && (ep->ld_pre % 8 || ep->ld_pre < N)) return set_error(CLIBD_EINVAL, "gemm: ld_pre");
     if (ep->out_bf16 && (ep->ld_out_bf16 % 8 || ep->ld_out_bf16 < N)) return set_error(CLIBD_EINVAL, "gemm: ld_out_bf16");
     if (ep->out_f32 && (ep->ld_out_f32 % 4 || ep->ld_out_f32 < N)) return set_error(CLIBD_EINVAL, "gemm: ld_out_f32");
+    if (ep->drop_thr16 < 0 || ep->drop_thr16 > 65535 || (ep->drop_thr16 > 0 && (ep->drop_ld < N || (ep->drop_ld & 1) || ep->split_k > 1)))
+        return set_error(CLIBD_EINVAL, "gemm: bad dropout parameters");
     const int split = ep->split_k < 1 ? 1 : ep->split_k;
     if (split > 1 && (ep->out_bf16 || ep->out_pre_bf16 || ep->act != CLIBD_ACT_NONE || ep->residual_f32 || !ep->out_f32))
         return set_error(CLIBD_EINVAL, "gemm: split_k > 1 supports only a plain fp32 accumulate output");

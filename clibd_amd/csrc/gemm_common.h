@@ -55,6 +55,16 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
         for (int e = 0; e < 16; ++e) atomicAdd(o + e, v[e]);
         return;
     }
+    if (ep.drop_thr16 > 0) {
+        const unsigned base = (unsigned)m * (unsigned)ep.drop_ld + (unsigned)nb;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            float f0, f1;
+            drop_pair(ep.drop_seed, base + e, (unsigned)ep.drop_thr16, ep.drop_scale, f0, f1);
+            v[e] *= f0;
+            v[e + 1] *= f1;
+        }
+    }
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
         float dg[16];
 #pragma unroll

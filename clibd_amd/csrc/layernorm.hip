@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             unsigned short* __restrict__ y_bf16,
                                                             float* __restrict__ y_f32, float* __restrict__ stats,
                                                             const unsigned short* __restrict__ lora_a,
-                                                            unsigned short* __restrict__ t_bf16) {
+                                                            unsigned short* __restrict__ t_bf16, unsigned drop_seed,
+                                                            int drop_thr16, float drop_scale) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[];  // [8][H] when LORA
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -99,6 +100,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mean) * rstd * g[j][e] + b[j][e];
             const int c = 4 * (lane + 64 * j);
+            if (drop_thr16 > 0) {  // y = dropout(LN(x)): HF BertEmbeddings
+                const unsigned base = (unsigned)row * (unsigned)H + (unsigned)c;
+                float f0, f1, f2, f3;
+                drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
+                drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
+                y[0] *= f0; y[1] *= f1; y[2] *= f2; y[3] *= f3;
+            }
             if (y_f32 != nullptr) *(f32x4*)(y_f32 + (size_t)row * H + c) = y;
             uint2 pk;
             pk.x = pack2bf(y[0], y[1]);
@@ -130,7 +138,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                                                             const float* __restrict__ gamma, int M, int H,
                                                             const float* __restrict__ dres,
                                                             float* __restrict__ dx_f32,
-                                                            unsigned short* __restrict__ dx_bf16) {
+                                                            unsigned short* __restrict__ dx_bf16, unsigned drop_seed,
+                                                            int drop_thr16, float drop_scale) {
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
@@ -186,6 +195,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             }
             if (dx_f32 != nullptr) *(f32x4*)(dx_f32 + (size_t)row * H + c) = o;
             if (dx_bf16 != nullptr) {
+                if (drop_thr16 > 0) {  // this copy is d(dense out) = d(sum) * mask / (1-p) of the forward's hidden dropout
+                    const unsigned base = (unsigned)row * (unsigned)H + (unsigned)c;
+                    float f0, f1, f2, f3;
+                    drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
+                    drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
+                    o[0] *= f0; o[1] *= f1; o[2] *= f2; o[3] *= f3;
+                }
                 uint2 pk;
                 pk.x = pack2bf(o[0], o[1]);
                 pk.y = pack2bf(o[2], o[3]);
@@ -205,9 +221,10 @@ static inline int ln_grid(int M) {
 
 using namespace clibd;
 
-extern "C" int clibd_layernorm_fwd(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
-                                   void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16,
-                                   void* t_bf16, void* stream) {
+extern "C" int clibd_layernorm_fwd_drop(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                                        void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
+                                        uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+    if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "layernorm_fwd: bad dropout threshold");
     if (!x || !gamma || !beta) return set_error(CLIBD_EINVAL, "layernorm_fwd: null pointer");
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_fwd: H must be a multiple of 64, <= 1024");
     if (!y_bf16 && !y_f32) return set_error(CLIBD_EINVAL, "layernorm_fwd: no output");
@@ -225,11 +242,11 @@ extern "C" int clibd_layernorm_fwd(const float* x, int M, int H, const float* ga
         if (lora)                                                                                              \
             hipLaunchKernelGGL((layernorm_fwd_kernel<N, true>), grid, block, lds, st, x, M, H, gamma, beta, eps, \
                                (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)lora_a_bf16,      \
-                               (unsigned short*)t_bf16);                                                       \
+                               (unsigned short*)t_bf16, drop_seed, drop_thr16, drop_scale);                    \
         else                                                                                                   \
             hipLaunchKernelGGL((layernorm_fwd_kernel<N, false>), grid, block, 0, st, x, M, H, gamma, beta, eps, \
                                (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)nullptr,          \
-                               (unsigned short*)nullptr);                                                      \
+                               (unsigned short*)nullptr, drop_seed, drop_thr16, drop_scale);                   \
     } while (0)
     switch (nch) {
         case 1: LAUNCH(1); break;
@@ -241,9 +258,16 @@ extern "C" int clibd_layernorm_fwd(const float* x, int M, int H, const float* ga
     return check_launch("layernorm_fwd");
 }
 
-extern "C" int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
-                                   const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
-                                   void* dx_bf16, void* stream) {
+extern "C" int clibd_layernorm_fwd(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                                   void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16,
+                                   void* t_bf16, void* stream) {
+    return clibd_layernorm_fwd_drop(x, M, H, gamma, beta, eps, y_bf16, y_f32, stats, lora_a_bf16, t_bf16, 0u, 0, 1.0f, stream);
+}
+
+extern "C" int clibd_layernorm_bwd_drop(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
+                                        const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
+                                        void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+    if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "layernorm_bwd: bad dropout threshold");
     if (!x || !stats || !gamma) return set_error(CLIBD_EINVAL, "layernorm_bwd: null pointer");
     if ((dy_bf16 == nullptr) == (dy_f32 == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: exactly one of dy_bf16/dy_f32");
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_bwd: H must be a multiple of 64, <= 1024");
@@ -253,7 +277,7 @@ extern "C" int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, con
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(N)                                                                                              \
     hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
-                       stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16)
+                       stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale)
     switch (nch) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -262,4 +286,10 @@ extern "C" int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, con
     }
 #undef LAUNCH
     return check_launch("layernorm_bwd");
+}
+
+extern "C" int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
+                                   const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
+                                   void* dx_bf16, void* stream) {
+    return clibd_layernorm_bwd_drop(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, 0u, 0, 1.0f, stream);
 }

@@ -142,12 +142,13 @@ class TransformerStack:
         return self._cache[i].a_cat
 
     # ---- forward ------------------------------------------------------------------------------------------------
-    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool, cls_only_last: bool = False):
+    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool, cls_only_last: bool = False, drop=None):
         """x_f32 [M,H] residual stream entering layer 0.  Post-LN stacks also pass its bf16 image and the layer-0
         adapter down-projection t0 (both produced by the embedding LayerNorm).  Returns (x_f32, x_bf16, saved).
         cls_only_last (pre-LN only): the caller consumes token 0 only, so the LAST block evaluates attention for that
         query, and projection + MLP for that row, per sequence — the returned x_f32 is then [B,H] (the other rows of
-        the last block are dead code the reference computes and discards)."""
+        the last block are dead code the reference computes and discards).
+        drop (post-LN only): (p_hidden, p_attention, base_seed) — HF BERT train-mode dropout; site seeds via ops.derive_seed."""
         H, FF, M = self.H, self.FF, B * S
         dev = x_f32.device
         saved = []
@@ -204,26 +205,33 @@ class TransformerStack:
                     rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h)
                 x_f32 = x2
             else:
+                d_att = d_h1 = d_h2 = None
+                if drop is not None:
+                    p_h, p_a, base = drop
+                    d_att = ops.Drop(p_a, ops.derive_seed(base, i, 0))
+                    d_h1 = ops.Drop(p_h, ops.derive_seed(base, i, 1))
+                    d_h2 = ops.Drop(p_h, ops.derive_seed(base, i, 2))
                 qkv = new(3 * H, BF16)
                 ops.gemm_nt(x_bf16, c.wqkv, bias=c.bqkv, rank_u=t if has_lora else None, rank_v=c.v_fwd if has_lora else None,
                             out_bf16=qkv)
-                ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
+                ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att)
                 s1 = new(H, F32)
-                ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=s1)
+                ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=s1, drop=d_h1)
                 x1_f32, x1_bf16 = new(H, F32), new(H, BF16)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
                 ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_bf16=x1_bf16, y_f32=x1_f32, stats=st1)
                 h = new(FF, BF16) if save else None
                 ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                 s2 = new(H, F32)
-                ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1_f32, out_f32=s2)
+                ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1_f32, out_f32=s2, drop=d_h2)
                 x2_f32, x2_bf16 = new(H, F32), new(H, BF16)
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
                 nxt = self.lora_a(i + 1)
                 t_next = torch.empty((M, 8), dtype=BF16, device=dev) if nxt is not None else None
                 ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next)
                 if save:
-                    rec = dict(x_bf16=x_bf16, t=t if has_lora else None, qkv=qkv, s1=s1, st1=st1, h=h, s2=s2, st2=st2)
+                    rec = dict(x_bf16=x_bf16, t=t if has_lora else None, qkv=qkv, s1=s1, st1=st1, h=h, s2=s2, st2=st2,
+                               d_att=d_att, d_h1=d_h1, d_h2=d_h2)
                 x_f32, x_bf16, t = x2_f32, x2_bf16, t_next
             saved.append(rec)
         return x_f32, x_bf16, saved
@@ -279,14 +287,14 @@ class TransformerStack:
                     dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             else:
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
-                ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16)
+                ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"])
                 ops.gemm_nt(ds2_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)
                 dx1 = new(H, F32)
                 ops.gemm_nt(dh, c.w1_t, residual=ds2_f32, out_f32=dx1)
                 ds1_f32, ds1_bf16 = new(H, F32), new(H, BF16)
-                ops.layernorm_bwd(dx1, rec["s1"], rec["st1"], c.g1, dx_f32=ds1_f32, dx_bf16=ds1_bf16)
+                ops.layernorm_bwd(dx1, rec["s1"], rec["st1"], c.g1, dx_f32=ds1_f32, dx_bf16=ds1_bf16, drop=rec["d_h1"])
                 ops.gemm_nt(ds1_bf16, c.wo_t, out_bf16=dtmp)
-                ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv)
+                ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv, drop=rec["d_att"])
                 if has_lora:
                     self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads)
                 if i > first_lora:

@@ -22,10 +22,12 @@ from .image_encoder import _ParamOnly
 # ---------------------------------------------------------------------------------------------------------
 class BertConfigLite:
     def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
-                 max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, **unused):
+                 max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_dropout_prob=0.1,
+                 attention_probs_dropout_prob=0.1, **unused):
         self.vocab_size, self.hidden_size, self.num_hidden_layers = vocab_size, hidden_size, num_hidden_layers
         self.num_attention_heads, self.intermediate_size = num_attention_heads, intermediate_size
         self.max_position_embeddings, self.type_vocab_size, self.layer_norm_eps = max_position_embeddings, type_vocab_size, layer_norm_eps
+        self.hidden_dropout_prob, self.attention_probs_dropout_prob = hidden_dropout_prob, attention_probs_dropout_prob
 
 
 class _Embeddings(_ParamOnly):
@@ -241,7 +243,9 @@ class CLIBDDNAEncoder(nn.Module):
         return self._tower
 
     def forward(self, sequence) -> torch.Tensor:
-        return self.tower()(sequence, None, None)
+        tw = self.tower()
+        tw.training = self.training  # HF BERT applies dropout (p = 0.1) in train mode (model.train() in train_epoch.py:19)
+        return tw(sequence, None, None)
 
 
 class Freeze_DNA_Encoder(nn.Module):

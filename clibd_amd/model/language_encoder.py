@@ -64,4 +64,6 @@ class CLIBDLanguageEncoder(nn.Module):
         return self._tower
 
     def forward(self, x) -> torch.Tensor:
-        return self.tower()(x["input_ids"], x.get("token_type_ids"), x.get("attention_mask"))
+        tw = self.tower()
+        tw.training = self.training
+        return tw(x["input_ids"], x.get("token_type_ids"), x.get("attention_mask"))

@@ -41,6 +41,29 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
     return t.stride(0)
 
 
+class Drop:
+    """Dropout site: probability p and a 32-bit seed; the mask is hash(seed, element index), see include/clibd_hip.h."""
+    __slots__ = ("seed", "thr16", "scale")
+
+    def __init__(self, p: float, seed: int):
+        self.thr16 = int(round(p * 65536.0))
+        if not 0 <= self.thr16 < 65536:
+            raise ValueError("dropout p must be in [0, 1)")
+        self.seed = seed & 0xFFFFFFFF
+        self.scale = 1.0 / (1.0 - self.thr16 / 65536.0)
+
+
+def derive_seed(base: int, layer: int, site: int) -> int:
+    """site seeds of one tower call (site: 0 attention probs, 1 attention-output dropout, 2 output dropout, 3 embeddings)"""
+    x = (base ^ ((layer * 8 + site + 1) * 0x9E3779B1)) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
 def gemm_nt(
     a: torch.Tensor,
     w: torch.Tensor,
@@ -55,6 +78,7 @@ def gemm_nt(
     out_bf16: Optional[torch.Tensor] = None,
     out_f32: Optional[torch.Tensor] = None,
     split_k: int = 1,
+    drop: Optional["Drop"] = None,
 ) -> None:
     """out = epilogue(a[M,K] @ w[N,K]^T); see clibd_gemm_bf16_nt in include/clibd_hip.h."""
     _chk(a, BF16, "a", contiguous=False)
@@ -67,6 +91,8 @@ def gemm_nt(
     ep = GemmEpilogue()
     ep.act = act
     ep.split_k = split_k
+    if drop is not None and drop.thr16 > 0:
+        ep.drop_seed, ep.drop_thr16, ep.drop_scale, ep.drop_ld = drop.seed, drop.thr16, drop.scale, N
     if bias is not None:
         _chk(bias, F32, "bias")
         if bias.numel() != N:
@@ -129,7 +155,7 @@ def cast_transpose_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, lora_a=None, t_out=None) -> None:
+def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, lora_a=None, t_out=None, drop=None) -> None:
     _chk(x, F32, "x")
     M, H = x.shape
     _chk(gamma, F32, "gamma")
@@ -140,11 +166,16 @@ def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, l
             _chk(t, dt, nm)
             if tuple(t.shape) != shape:
                 raise ValueError(f"layernorm_fwd: {nm} must be {shape}, got {tuple(t.shape)}")
+    if drop is not None and drop.thr16 > 0:
+        check(_lib.load().clibd_layernorm_fwd_drop(x.data_ptr(), M, H, gamma.data_ptr(), beta.data_ptr(), float(eps), _p(y_bf16), _p(y_f32),
+                                                   _p(stats), _p(lora_a), _p(t_out), drop.seed, drop.thr16, drop.scale, _stream()),
+              "layernorm_fwd_drop")
+        return
     check(_lib.load().clibd_layernorm_fwd(x.data_ptr(), M, H, gamma.data_ptr(), beta.data_ptr(), float(eps), _p(y_bf16), _p(y_f32),
                                           _p(stats), _p(lora_a), _p(t_out), _stream()), "layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None) -> None:
+def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, drop=None) -> None:
     _chk(x, F32, "x")
     M, H = x.shape
     if dy.dtype == BF16:
@@ -162,12 +193,16 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None) 
             _chk(t, dt, nm)
             if tuple(t.shape) != (M, H):
                 raise ValueError(f"layernorm_bwd: {nm} shape")
+    if drop is not None and drop.thr16 > 0:
+        check(_lib.load().clibd_layernorm_bwd_drop(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres), _p(dx_f32),
+                                                   _p(dx_bf16), drop.seed, drop.thr16, drop.scale, _stream()), "layernorm_bwd_drop")
+        return
     check(_lib.load().clibd_layernorm_bwd(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres), _p(dx_f32),
                                           _p(dx_bf16), _stream()), "layernorm_bwd")
 
 
 def attention_fwd(qkv: torch.Tensor, B: int, S: int, nheads: int, key_mask: Optional[torch.Tensor], out: torch.Tensor,
-                  nq: Optional[int] = None) -> None:
+                  nq: Optional[int] = None, drop=None) -> None:
     """nq: evaluate only the first nq query rows of every sequence; `out` is then [B*nq, H]."""
     _chk(qkv, BF16, "qkv")
     _chk(out, BF16, "out")
@@ -179,10 +214,14 @@ def attention_fwd(qkv: torch.Tensor, B: int, S: int, nheads: int, key_mask: Opti
         _chk(key_mask, I32, "key_mask")
         if tuple(key_mask.shape) != (B, S):
             raise ValueError("attention_fwd: key_mask must be [B,S]")
+    if drop is not None and drop.thr16 > 0:
+        check(_lib.load().clibd_attention_fwd_drop(qkv.data_ptr(), B, S, nheads, _p(key_mask), out.data_ptr(), nq, nq, drop.seed, drop.thr16,
+                                                   drop.scale, _stream()), "attention_fwd_drop")
+        return
     check(_lib.load().clibd_attention_fwd(qkv.data_ptr(), B, S, nheads, _p(key_mask), out.data_ptr(), nq, nq, _stream()), "attention_fwd")
 
 
-def attention_bwd(qkv, dout, B, S, nheads, key_mask, dqkv, nq: Optional[int] = None) -> None:
+def attention_bwd(qkv, dout, B, S, nheads, key_mask, dqkv, nq: Optional[int] = None, drop=None) -> None:
     """nq: `dout` is [B*nq, H] — the gradient of the first nq query rows of every sequence (the rest is zero)."""
     _chk(qkv, BF16, "qkv")
     _chk(dout, BF16, "dout")
@@ -193,6 +232,10 @@ def attention_bwd(qkv, dout, B, S, nheads, key_mask, dqkv, nq: Optional[int] = N
         raise ValueError("attention_bwd: shapes")
     if key_mask is not None:
         _chk(key_mask, I32, "key_mask")
+    if drop is not None and drop.thr16 > 0:
+        check(_lib.load().clibd_attention_bwd_drop(qkv.data_ptr(), dout.data_ptr(), B, S, nheads, _p(key_mask), dqkv.data_ptr(), nq, nq,
+                                                   drop.seed, drop.thr16, drop.scale, _stream()), "attention_bwd_drop")
+        return
     check(_lib.load().clibd_attention_bwd(qkv.data_ptr(), dout.data_ptr(), B, S, nheads, _p(key_mask), dqkv.data_ptr(), nq, nq, _stream()),
           "attention_bwd")
 

@@ -54,6 +54,8 @@ class _Tower:
     def trainable_params(self) -> List[torch.nn.Parameter]:
         raise NotImplementedError
 
+    training = False  # set by the owning nn.Module before each call (module.training)
+
     def __call__(self, *inputs):
         params = _trainable(self.trainable_params())
         save = torch.is_grad_enabled() and len(params) > 0
@@ -186,6 +188,9 @@ class BertTower(_Tower):
         self.H = H
         self.stack = TransformerStack(layers, H, int(heads), pre_ln=False, eps=float(bert.encoder.layer[0].output.LayerNorm.eps))
         self._head_key, self._head_cache = None, None
+        cfg = getattr(bert, "config", None)
+        self.p_hidden = float(getattr(cfg, "hidden_dropout_prob", 0.1))
+        self.p_attn = float(getattr(cfg, "attention_probs_dropout_prob", 0.1))
 
     def trainable_params(self):
         ps = []
@@ -241,9 +246,15 @@ class BertTower(_Tower):
         x_f32, x_bf16 = torch.empty((M, H), dtype=F32, device=dev), torch.empty((M, H), dtype=BF16, device=dev)
         a0 = self.stack.lora_a(0)
         t0 = torch.empty((M, 8), dtype=BF16, device=dev) if a0 is not None else None
+        # HF BERT dropout (train mode only): embeddings, attention probabilities, both dense outputs of every layer
+        drop, d_emb = None, None
+        if self.training and (self.p_hidden > 0 or self.p_attn > 0):
+            base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())  # CPU generator: reproducible under torch.manual_seed, no device sync
+            drop = (self.p_hidden, self.p_attn, base)
+            d_emb = ops.Drop(self.p_hidden, ops.derive_seed(base, 255, 3))
         ops.layernorm_fwd(e, _f32c(emb.LayerNorm.weight), _f32c(emb.LayerNorm.bias), float(emb.LayerNorm.eps), y_bf16=x_bf16, y_f32=x_f32,
-                          lora_a=a0, t_out=t0)
-        x_f32, x_bf16, saved = self.stack.forward(x_f32, x_bf16, t0, B, S, key_mask, save)
+                          lora_a=a0, t_out=t0, drop=d_emb)
+        x_f32, x_bf16, saved = self.stack.forward(x_f32, x_bf16, t0, B, S, key_mask, save, drop=drop)
         state = dict(saved=saved, B=B, S=S, key_mask=key_mask) if save else None
         if self.head_kind == "mlm":
             wt, _ = self._head_images()

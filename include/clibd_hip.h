@@ -67,6 +67,12 @@ typedef struct clibd_gemm_epilogue {
     int32_t act;
     int32_t ld_rank_u, ld_aux, ld_res, ld_pre, ld_out_bf16, ld_out_f32;
     int32_t split_k;            /* >= 1 */
+    /* dropout on (acc + rank update + bias), before activation / residual: v *= keep(seed, m*drop_ld + n) / (1-p);
+     * drop_thr16 = round(p * 65536) (0 = off), drop_scale = 1/(1-p), drop_ld = N of the forward GEMM.  See clibd_dropout_*. */
+    uint32_t drop_seed;
+    int32_t drop_thr16;
+    float drop_scale;
+    int32_t drop_ld;
 } clibd_gemm_epilogue;
 
 int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
@@ -92,11 +98,23 @@ int clibd_cast_transpose_f32_to_bf16(const float* in, int R, int C, void* out, v
 int clibd_layernorm_fwd(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
                         void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
                         void* stream);
+/* Dropout (HF BERT train mode, p = 0.1: BertEmbeddings.dropout, BertSelfOutput.dropout, BertOutput.dropout,
+ * BertSelfAttention.dropout on the probabilities).  Masks are a pure function of (seed, element index) — lowbias32 hash of
+ * (index >> 1) ^ seed, 16 bits per element, keep iff bits >= round(p*65536) — so nothing is stored and the backward
+ * recomputes them.  Element index: row*H + col for [M,H] activations; ((b*heads+h)*S + q)*256 + key for attention.
+ * _drop variants: y = dropout(LN(x)) (embeddings);  backward: the bf16 output only is masked (it is the gradient that
+ * enters the dgrad GEMM of the dropped dense output; the fp32 output is the residual-path gradient). */
+int clibd_layernorm_fwd_drop(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                             void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
+                             uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
 /* dx = LN'(dy) [+ dres]; dy is bf16 (dy_bf16) or fp32 (dy_f32), exactly one non-null.
  * Outputs dx_f32 and/or dx_bf16. gamma is frozen on the LoRA path, so no dgamma/dbeta here. */
 int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
                         const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
                         void* dx_bf16, void* stream);
+int clibd_layernorm_bwd_drop(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
+                             const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
+                             void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3: multi-head attention, head dim 64, whole sequence per workgroup (S <= 256: ViT 197, BarcodeBERT 133,
@@ -113,6 +131,12 @@ int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t
                         int nq, int out_seq, void* stream);
 int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
                         void* dqkv, int nq, int dout_seq, void* stream);
+/* same with dropout on the attention probabilities (see clibd_layernorm_fwd_drop for the mask definition) */
+int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
+                             int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
+int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
+                             void* dqkv, int nq, int dout_seq, uint32_t drop_seed, int drop_thr16, float drop_scale,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K6: LoRA (rank 4 on q and v; reference image_encoder.py:13-46, dna_encoder.py:68-77,

@@ -75,6 +75,54 @@ def _rg(x: torch.Tensor) -> torch.Tensor:
     return _G.apply(x)
 
 
+# ---- dropout with the kernels' counter-based masks (include/clibd_hip.h "Dropout") --------------------------------------
+_DROPOUT = None  # (p_hidden, p_attention, base_seed) while active
+
+
+@contextlib.contextmanager
+def dropout(p_hidden: float, p_attention: float, base_seed: int):
+    """HF BERT train-mode dropout, evaluated with the same (seed, element index) hash masks as the HIP kernels."""
+    global _DROPOUT
+    old, _DROPOUT = _DROPOUT, (p_hidden, p_attention, base_seed)
+    try:
+        yield
+    finally:
+        _DROPOUT = old
+
+
+def _lowbias32(x):
+    m = 0xFFFFFFFF
+    x = x & m
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & m
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & m
+    return x ^ (x >> 16)
+
+
+def derive_seed(base: int, layer: int, site: int) -> int:
+    return int(_lowbias32(torch.tensor((base ^ ((layer * 8 + site + 1) * 0x9E3779B1)) & 0xFFFFFFFF, dtype=torch.int64)))
+
+
+def drop_factor(seed: int, idx: torch.Tensor, p: float) -> torch.Tensor:
+    """0 or 1/(1-p) per element index (int64 tensor): 16 bits of lowbias32((idx >> 1) ^ seed), low half for even idx."""
+    thr = int(round(p * 65536.0))
+    if thr == 0:
+        return torch.ones(idx.shape)
+    h = _lowbias32((idx >> 1) ^ seed)
+    bits = torch.where((idx & 1) == 1, h >> 16, h & 0xFFFF)
+    return (bits >= thr).float() * (1.0 / (1.0 - thr / 65536.0))
+
+
+def _hidden_drop(y, layer, site):
+    """dropout on a [B,S,H] activation, element index (b*S+s)*H + col"""
+    if _DROPOUT is None:
+        return y
+    p_h, _, base = _DROPOUT
+    idx = torch.arange(y.numel(), dtype=torch.int64).view(y.shape)
+    return y * drop_factor(derive_seed(base, layer, site), idx, p_h).to(y.dtype)
+
+
 def olinear(x, weight, bias=None, round_out=True):
     """nn.Linear with the kernels' rounding points: bf16 operands, fp32 accumulate, fp32 bias, bf16 output.
     round_out=False: the GEMM epilogue keeps fp32 (residual add / fp32 head output fused before any rounding);
@@ -108,17 +156,31 @@ class PatchEmbed(nn.Module):
         return olinear(cols, w, self.proj.bias, round_out=False).reshape(B, self.num_patches, -1)
 
 
-def attention_core(q, k, v, mask_add=None):
+def _attn_drop(shape, layer):
+    if _DROPOUT is None or layer is None:
+        return None
+    _, p_a, base = _DROPOUT
+    B, nh, Sq, Sk = shape
+    bh = torch.arange(B * nh, dtype=torch.int64).view(B, nh, 1, 1)
+    q = torch.arange(Sq, dtype=torch.int64).view(1, 1, Sq, 1)
+    key = torch.arange(Sk, dtype=torch.int64).view(1, 1, 1, Sk)
+    return drop_factor(derive_seed(base, layer, 0), ((bh * Sq + q) << 8) + key, p_a)
+
+
+def attention_core(q, k, v, mask_add=None, layer=None):
     """q,k,v [B,h,S,dh]; scores and softmax in fp32, probabilities rounded to bf16 before P·V (bf16 mode)."""
     s = (_r(q) @ _r(k).transpose(-1, -2)) * (q.shape[-1] ** -0.5)
     if mask_add is not None:
         s = s + mask_add
+    fm = _attn_drop(s.shape, layer)
     if _PRECISION == "fp32":
-        return torch.softmax(s, dim=-1) @ v
+        p = torch.softmax(s, dim=-1)
+        return (p if fm is None else p * fm.to(p.dtype)) @ v
     # kernel rounding points: the UN-normalised exp(s - max) is what gets rounded to bf16 for the P·V product,
     # and the fp32 row sum divides the fp32 result (same function as softmax, same relative rounding error)
     e = torch.exp(s - s.max(dim=-1, keepdim=True).values.detach())
-    return _rg(_r((_r(e) @ _r(v)) / e.sum(dim=-1, keepdim=True)))
+    em = e if fm is None else e * fm.to(e.dtype)
+    return _rg(_r((_r(em) @ _r(v)) / e.sum(dim=-1, keepdim=True)))
 
 
 class Attention(nn.Module):
@@ -278,7 +340,7 @@ class BertEmbeddings(nn.Module):
         S = ids.shape[1]
         tt = token_type_ids if token_type_ids is not None else torch.zeros_like(ids)
         pos = torch.arange(S, device=ids.device)[None, :]
-        return self.LayerNorm(self.word_embeddings(ids) + self.token_type_embeddings(tt) + self.position_embeddings(pos))
+        return _hidden_drop(self.LayerNorm(self.word_embeddings(ids) + self.token_type_embeddings(tt) + self.position_embeddings(pos)), 255, 3)
 
 
 class _SelfAttn(nn.Module):
@@ -287,10 +349,10 @@ class _SelfAttn(nn.Module):
         self.query, self.key, self.value = nn.Linear(hidden, hidden), nn.Linear(hidden, hidden), nn.Linear(hidden, hidden)
         self.heads = heads
 
-    def forward(self, x, mask_add):
+    def forward(self, x, mask_add, layer=None):
         B, S, Hd = x.shape
         sp = lambda t: t.view(B, S, self.heads, Hd // self.heads).transpose(1, 2)
-        o = attention_core(sp(_lin(self.query, x)), sp(_lin(self.key, x)), sp(_lin(self.value, x)), mask_add)
+        o = attention_core(sp(_lin(self.query, x)), sp(_lin(self.key, x)), sp(_lin(self.value, x)), mask_add, layer)
         return o.transpose(1, 2).reshape(B, S, Hd)
 
 
@@ -300,8 +362,11 @@ class _DenseLN(nn.Module):
         self.dense = nn.Linear(din, dout)
         self.LayerNorm = nn.LayerNorm(dout, eps=eps)
 
-    def forward(self, x, residual):
-        return self.LayerNorm(olinear(x, self.dense.weight, self.dense.bias, round_out=False) + residual)
+    def forward(self, x, residual, layer=None, site=None):
+        y = olinear(x, self.dense.weight, self.dense.bias, round_out=False)
+        if layer is not None:
+            y = _hidden_drop(y, layer, site)
+        return self.LayerNorm(y + residual)
 
 
 class _Attn(nn.Module):
@@ -324,10 +389,10 @@ class BertLayer(nn.Module):
         self.intermediate = _Inter(hidden, ff)
         self.output = _DenseLN(ff, hidden, eps)
 
-    def forward(self, x, mask_add=None):
-        a = self.attention.output(self.attention.self(x, mask_add), x)
+    def forward(self, x, mask_add=None, layer=None):
+        a = self.attention.output(self.attention.self(x, mask_add, layer), x, layer, 1)
         h = olinear(a, self.intermediate.dense.weight, self.intermediate.dense.bias)
-        return self.output(_rg(_r(gelu_erf(h))), a)
+        return self.output(_rg(_r(gelu_erf(h))), a, layer, 2)
 
 
 class _Encoder(nn.Module):
@@ -355,8 +420,8 @@ class BertModel(nn.Module):
         mask_add = None
         if attention_mask is not None:
             mask_add = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
-        for layer in self.encoder.layer:
-            x = layer(x, mask_add)
+        for i, layer in enumerate(self.encoder.layer):
+            x = layer(x, mask_add, i)
         return x  # last_hidden_state
 
 

@@ -44,11 +44,11 @@ def test_python_binding_covers_every_declared_symbol(lib):
 def test_epilogue_struct_layout_matches_header():
     from clibd_amd._lib import GemmEpilogue
 
-    # 8 pointers + 8 int32 (header order): 8*8 + 8*4 = 96 bytes
-    assert ctypes.sizeof(GemmEpilogue) == 96
+    # 8 pointers + 8 int32 + 4 dropout words (header order): 8*8 + 12*4 = 112 bytes
+    assert ctypes.sizeof(GemmEpilogue) == 112
     assert [f[0] for f in GemmEpilogue._fields_] == ["bias", "rank_u", "rank_v", "aux_bf16", "residual_f32", "out_pre_bf16", "out_bf16",
                                                      "out_f32", "act", "ld_rank_u", "ld_aux", "ld_res", "ld_pre", "ld_out_bf16",
-                                                     "ld_out_f32", "split_k"]
+                                                     "ld_out_f32", "split_k", "drop_seed", "drop_thr16", "drop_scale", "drop_ld"]
 
 
 def test_host_side_validation_needs_no_gpu(lib):

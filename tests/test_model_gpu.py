@@ -50,7 +50,7 @@ def hip_dna(gd, dev):
     c = gd["config"]
     m = CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, **c)), r=4, num_classes=128)
     m.load_state_dict(gd["state_dict"], strict=True)
-    return m.to(dev)
+    return m.to(dev).eval()  # goldens: dropout off (eval); train-mode dropout has its own tests below
 
 
 def hip_text(gt, dev):
@@ -58,7 +58,7 @@ def hip_text(gt, dev):
 
     m = CLIBDLanguageEncoder(BertModel(BertConfigLite(vocab_size=gt["vocab"], **gt["config"])), r=4, num_classes=128)
     m.load_state_dict(gt["state_dict"], strict=True)
-    return m.to(dev)
+    return m.to(dev).eval()
 
 
 def hip_image(gi, dev):
@@ -67,7 +67,7 @@ def hip_image(gi, dev):
     c = gi["config"]
     m = CLIBDImageEncoder(VisionTransformer(embed_dim=c["dim"], depth=c["depth"], num_heads=c["heads"], num_classes=10), r=4, num_classes=128)
     m.load_state_dict(gi["state_dict"], strict=True)
-    return m.to(dev)
+    return m.to(dev).eval()
 
 
 def oracle_models():
@@ -143,7 +143,7 @@ def test_image_tower_parity(dev):
 
 def test_towers_eval_mode_and_no_grad(dev):
     gd = load("dna_tiny_golden.pt")
-    m = hip_dna(gd, dev).eval()
+    m = hip_dna(gd, dev)
     with torch.no_grad():
         y = m(gd["ids"].to(dev))
     assert not y.requires_grad and rel(y.cpu(), gd["out"]) < 2e-2
@@ -242,3 +242,74 @@ def test_full_step_matches_reference(dev, tag, use_text):
     assert_grads(got, gs[f"grads_{tag}"], rel_tol=0.25, cos_tol=0.97, what="step vs reference fp32")
     allr = torch.cat([gs[f"grads_{tag}"][n].flatten() for n in sorted(go)])
     assert rel(allg, allr) < 0.1 and cos(allg, allr) > 0.995
+
+
+# ------------------------------------------------------------------------------------------ dropout (train mode)
+def test_bert_train_mode_dropout_matches_oracle_masks(dev):
+    """HF BERT applies dropout (p = 0.1) in train mode (train_epoch.py:19 model.train()).  The HIP masks are a pure function
+    of (seed, element index); the oracle evaluates the same function, so train-mode parity is exact up to bf16 rounding."""
+    from oracle import clibd_oracle as O
+
+    gd = load("dna_tiny_golden.pt")
+    m = hip_dna(gd, dev).train()
+    torch.manual_seed(1234)
+    base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    torch.manual_seed(1234)  # the tower draws the same base seed from the CPU generator
+    y = m(gd["ids"].to(dev))
+    got = grads_named(m, (y * gd["cot"].to(dev)).sum())
+    build_dna, _, _ = oracle_models()
+    om = build_dna(gd)
+    with O.precision("bf16"), O.dropout(0.1, 0.1, base):
+        yo = om(gd["ids"])
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * gd["cot"]).sum(), [p for _, p in ps])))
+    assert rel(y.cpu(), yo.detach()) < 4e-3
+    assert_grads(got, go, rel_tol=3e-2, cos_tol=0.999, what="dna train-mode vs oracle with identical masks")
+    # and it really is different from eval mode
+    with torch.no_grad():
+        ye = m.eval()(gd["ids"].to(dev))
+    assert rel(ye.cpu(), y.detach().cpu()) > 1e-4  # (the DNA head output is a near-uniform softmax mean: small but real change)
+    # different seed -> different masks; same seed -> bit-identical output
+    m.train()
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        y2 = m(gd["ids"].to(dev))
+        y3 = m(gd["ids"].to(dev))
+    # (the no_grad forward evaluates GELU through a different but equivalent expression: last-bit differences only)
+    assert torch.allclose(y2, y.detach(), rtol=1e-4, atol=1e-7) and not torch.allclose(y3, y2, rtol=1e-4, atol=1e-7)
+
+
+def test_text_tower_train_mode_dropout_with_mask(dev):
+    from oracle import clibd_oracle as O
+
+    gt = load("text_tiny_golden.pt")
+    m = hip_text(gt, dev).train()
+    x = {k: v.to(dev) for k, v in gt["inputs"].items()}
+    torch.manual_seed(77)
+    base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    torch.manual_seed(77)
+    y = m(x)
+    got = grads_named(m, (y * gt["cot"].to(dev)).sum())
+    _, build_text, _ = oracle_models()
+    om = build_text(gt)
+    with O.precision("bf16"), O.dropout(0.1, 0.1, base):
+        yo = om(gt["inputs"])
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * gt["cot"]).sum(), [p for _, p in ps])))
+    assert rel(y.cpu(), yo.detach()) < 4e-3
+    assert_grads(got, go, rel_tol=3e-2, cos_tol=0.999, what="text train-mode vs oracle with identical masks")
+
+
+def test_dropout_keep_rate(dev):
+    from clibd_amd import ops
+
+    M, N, K = 512, 256, 64
+    a = torch.zeros((M, K), dtype=torch.bfloat16, device=dev)
+    w = torch.zeros((N, K), dtype=torch.bfloat16, device=dev)
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    ops.gemm_nt(a, w, bias=torch.ones(N, device=dev), out_f32=out, drop=ops.Drop(0.1, 12345))
+    torch.cuda.synchronize()
+    o = out.cpu()
+    keep = (o != 0).float().mean().item()
+    assert abs(keep - 0.9) < 5e-3
+    assert torch.allclose(o[o != 0], torch.tensor(1.0 / (1.0 - round(0.1 * 65536) / 65536)))
