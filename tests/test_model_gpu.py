@@ -276,7 +276,8 @@ def test_bert_train_mode_dropout_matches_oracle_masks(dev):
         y2 = m(gd["ids"].to(dev))
         y3 = m(gd["ids"].to(dev))
     # (the no_grad forward evaluates GELU through a different but equivalent expression: last-bit differences only)
-    assert torch.allclose(y2, y.detach(), rtol=1e-4, atol=1e-7) and not torch.allclose(y3, y2, rtol=1e-4, atol=1e-7)
+    # flips an occasional bf16 rounding downstream): same masks -> ~1e-4 apart; fresh masks -> percent-level change
+    assert rel(y2.cpu(), y.detach().cpu()) < 2e-3 and rel(y3.cpu(), y2.cpu()) > 5e-3
 
 
 def test_text_tower_train_mode_dropout_with_mask(dev):
