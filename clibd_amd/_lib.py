@@ -76,6 +76,9 @@ SIGNATURES = {
     "clibd_softce_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "clibd_softce_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_softce_rows_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "clibd_topk_ip_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "clibd_topk_ip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "clibd_kmer_tokenize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "clibd_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
 }
 

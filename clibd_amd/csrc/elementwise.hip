@@ -252,6 +252,34 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     }
 }
 
+// ---- f1: 5-mer tokenisation of padded nucleotide strings (model/dna_encoder.py:53-63, util/util.py:77-98) ----------------
+// seq uint8 [B,L] ('N'-padded / truncated by the host), out int64 [B, 1 + L/k]: out[b,0] = 0 (<MASK> id leads every
+// sequence in the reference pipeline), out[b,1+t] = 3 + base-4 value of chars [k*t, k*t+k) with A0 C1 G2 T3, or 2 (<UNK>)
+// when any char is not ACGT.
+__global__ __launch_bounds__(256) void kmer_tokenize_kernel(const unsigned char* __restrict__ seq, int B, int L, int k,
+                                                            long long* __restrict__ out) {
+    const int T = L / k;
+    const size_t total = (size_t)B * (T + 1);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % (T + 1));
+        const size_t b = i / (T + 1);
+        long long id = 0;
+        if (t > 0) {
+            const unsigned char* c = seq + b * L + (size_t)(t - 1) * k;
+            int v = 0;
+            bool ok = true;
+            for (int j = 0; j < k; ++j) {
+                const unsigned char ch = c[j];
+                const int d = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
+                ok = ok && d >= 0;
+                v = v * 4 + (d < 0 ? 0 : d);
+            }
+            id = ok ? 3 + v : 2;
+        }
+        out[i] = id;
+    }
+}
+
 // ---- K8: y = x / max(||x||, eps) -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int N, int D,
                                                          float* __restrict__ y, float* __restrict__ inv_norm) {
@@ -397,6 +425,13 @@ extern "C" int clibd_scatter_rows_bf16(const float* dcls, int B, int S, int H, v
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((size_t)B * S * H)), dim3(256), 0, (hipStream_t)stream, dcls, B, S, H,
                        (unsigned short*)dx_bf16, dx_f32);
     return check_launch("scatter_rows");
+}
+
+extern "C" int clibd_kmer_tokenize(const void* seq_u8, int B, int L, int k, int64_t* out, void* stream) {
+    if (!seq_u8 || !out || B <= 0 || L <= 0 || k <= 0 || k > 12 || L % k != 0) return set_error(CLIBD_EINVAL, "kmer_tokenize: bad args (L % k == 0, k <= 12)");
+    hipLaunchKernelGGL(kmer_tokenize_kernel, dim3(grid_for((size_t)B * (L / k + 1))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)seq_u8, B, L, k, (long long*)out);
+    return check_launch("kmer_tokenize");
 }
 
 extern "C" int clibd_l2norm_fwd(const float* x, int N, int D, float* y, float* inv_norm, void* stream) {

@@ -437,3 +437,31 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
         raise ValueError("adamw_step: size mismatch")
     check(_lib.load().clibd_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(lr), float(beta1), float(beta2),
                                        float(eps), float(weight_decay), int(step), float(grad_scale), _stream()), "adamw_step")
+
+
+def topk_ip(q: torch.Tensor, keys: torch.Tensor, k: int = 5, chunk: int = 8192):
+    """Exact fp32 inner-product top-k (faiss.IndexFlatIP.search): returns (similarities fp32 [Q,k], indices int64 [Q,k])."""
+    _chk(q, F32, "q")
+    _chk(keys, F32, "keys")
+    Q, D = q.shape
+    Nk = keys.shape[0]
+    if keys.shape[1] != D:
+        raise ValueError("topk_ip: dimension mismatch")
+    idx = torch.empty((Q, k), dtype=I64, device=q.device)
+    sim = torch.empty((Q, k), dtype=F32, device=q.device)
+    lib = _lib.load()
+    ws = torch.empty((lib.clibd_topk_ip_workspace_bytes(min(Q, chunk), Nk),), dtype=torch.uint8, device=q.device)
+    for s0 in range(0, Q, chunk):
+        n = min(chunk, Q - s0)
+        check(lib.clibd_topk_ip(q[s0:].data_ptr(), keys.data_ptr(), n, Nk, D, k, idx[s0:].data_ptr(), sim[s0:].data_ptr(), ws.data_ptr(),
+                                ws.numel(), _stream()), "topk_ip")
+    return sim, idx
+
+
+def kmer_tokenize(seq_u8: torch.Tensor, k: int = 5) -> torch.Tensor:
+    """uint8 [B,L] ('N'-padded ASCII) -> int64 [B, 1 + L/k] token ids."""
+    _chk(seq_u8, torch.uint8, "seq_u8")
+    B, L = seq_u8.shape
+    out = torch.empty((B, 1 + L // k), dtype=I64, device=seq_u8.device)
+    check(_lib.load().clibd_kmer_tokenize(seq_u8.data_ptr(), B, L, k, out.data_ptr(), _stream()), "kmer_tokenize")
+    return out

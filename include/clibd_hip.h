@@ -219,6 +219,21 @@ int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D, int row0,
                           const float* weight_scale /* optional device scalar multiplied into weight */, float* dx, float* dy, float* dscale, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K10 ("next" row §8f-2): exact fp32 inner-product top-k — faiss.IndexFlatIP.search(query, k) in the reference's eval
+ * path (util/util.py:521-528, make_prediction; callers L2-normalise first, clibd_l2norm_fwd).  q [Q,D], keys [Nk,D]
+ * fp32; out_idx int64 [Q,k] (ties -> lower key index), out_sim fp32 [Q,k]; 1 <= k <= 8; D % 4 == 0.  Scores use the
+ * fp32-input MFMA (exact fp32 products, fmaf chain).  workspace: clibd_topk_ip_workspace_bytes(Q, Nk) (the [Q,Nk] scores).
+ * ------------------------------------------------------------------------------------------------ */
+size_t clibd_topk_ip_workspace_bytes(int Q, int Nk);
+int clibd_topk_ip(const float* q, const float* keys, int Q, int Nk, int D, int k, int64_t* out_idx, float* out_sim,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* f1 batch contract: k-mer tokenisation (model/dna_encoder.py:53-63 get_sequence_pipeline, util/util.py:77-98).
+ * seq_u8 [B,L] ASCII, already truncated / 'N'-padded to L (660); out int64 [B, 1 + L/k]: leading 0, then 3 + base-4 value
+ * (A0 C1 G2 T3, product('ACGT', repeat=k) order) or 2 (<UNK>) for a k-mer with any other character. */
+int clibd_kmer_tokenize(const void* seq_u8, int B, int L, int k, int64_t* out, void* stream);
+
 /* fused AdamW step on a flat fp32 parameter bucket (torch.optim.AdamW semantics, scripts/train_cl.py:221):
  * p,g,m,v [n]; g is multiplied by grad_scale first (1/world_size folding etc.). */
 int clibd_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,

@@ -509,3 +509,59 @@ def test_attention_query_prefix(ops, dev, B, S, nh, nq):
     assert rel_err(got, gref) < 1.5e-2
     dq = got[:, :H].view(B, S, H)
     assert torch.equal(dq[:, nq:], torch.zeros(B, S - nq, H))
+
+
+# ----------------------------------------------------------------------------------------------- eval-side "next" rows
+@pytest.mark.parametrize("Q,Nk,D,k", [(37, 500, 768, 5), (130, 2048, 128, 5), (5, 9, 64, 3), (64, 21000, 768, 5)])
+def test_topk_inner_product_indices_bit_exact(ops, dev, Q, Nk, D, k):
+    """Integer top-k indices must equal the fp32 reference's (north-star: bit-exact); ties -> lower index."""
+    from oracle import clibd_oracle as O
+
+    g = torch.Generator().manual_seed(Q + Nk)
+    keys = torch.nn.functional.normalize(torch.randn(Nk, D, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g), dim=1)
+    q[0] = keys[Nk // 2]              # an exact match
+    sim, idx = ops.topk_ip(q.to(dev), keys.to(dev), k)
+    torch.cuda.synchronize()
+    s64 = q.double() @ keys.double().T
+    ref_idx = torch.argsort(-s64, dim=1, stable=True)[:, :k]
+    assert torch.equal(idx.cpu(), ref_idx)
+    assert torch.allclose(sim.cpu().double(), torch.gather(s64, 1, ref_idx), atol=2e-6)
+    if Nk <= 2048:
+        osim, oidx = O.topk_inner_product(q, keys, k)
+        assert torch.equal(idx.cpu(), oidx)
+
+
+def test_topk_ties_prefer_lower_index(ops, dev):
+    keys = torch.zeros(40, 64)
+    keys[:, 0] = 1.0                   # all keys identical -> all scores tie
+    q = torch.zeros(3, 64)
+    q[:, 0] = 1.0
+    _, idx = ops.topk_ip(q.to(dev), keys.to(dev), 4)
+    torch.cuda.synchronize()
+    assert idx.cpu().tolist() == [[0, 1, 2, 3]] * 3
+
+
+def test_kmer_tokenizer_matches_oracle(dev):
+    from clibd_amd.eval import tokenize_barcodes
+    from oracle import clibd_oracle as O
+    import random
+
+    rnd = random.Random(3)
+    seqs = ["".join(rnd.choice("ACGT") for _ in range(660)), "ACGTAC", "A" * 1000, "ACGTN" * 100, "", "acgta" * 10 + "ACGTT" * 50]
+    got = tokenize_barcodes(seqs, dev)
+    torch.cuda.synchronize()
+    ref = torch.tensor([O.kmer_tokenize(s) for s in seqs])
+    assert got.shape == (len(seqs), 133)
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_make_prediction_contract(dev):
+    from clibd_amd.eval import make_prediction, LEVELS
+
+    g = torch.Generator().manual_seed(5)
+    keys = torch.randn(30, 64, generator=g)
+    labels = [{lv: f"{lv}_{i}" for lv in LEVELS} for i in range(30)]
+    pred, sim, idx = make_prediction(keys[[4, 7]] * 3.0, keys, labels, with_similarity=True, with_indices=True, max_k=5, device=dev)
+    assert idx[:, 0].tolist() == [4, 7] and abs(sim[0, 0] - 1.0) < 1e-5
+    assert pred[0]["species"][0] == "species_4" and len(pred[1]["order"]) == 5
