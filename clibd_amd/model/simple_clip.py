@@ -131,3 +131,10 @@ def load_clip_model(args, device=None):
             for p in enc.parameters():
                 p.requires_grad = False
     return model
+
+
+def initialize_model_and_load_from_checkpoint(args, device=None):
+    """reference simple_clip.py:248-285 (local checkpoints only); see clibd_amd.checkpoint."""
+    from ..checkpoint import initialize_model_and_load_from_checkpoint as _impl
+
+    return _impl(args, device)

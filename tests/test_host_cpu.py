@@ -1,0 +1,112 @@
+"""CPU tests of the host-side mirror of the reference API (no GPU: construction, state-dict keys, checkpoint migration,
+factory flag semantics, tokenizer).  Compute calls are covered by the -m gpu suites."""
+import os
+import types
+
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _args(**mc):
+    a = types.SimpleNamespace()
+    a.model_config = types.SimpleNamespace(**mc)
+    return a
+
+
+def test_state_dict_keys_equal_the_reference_modules():
+    """keys captured from the reference's own SimpleCLIP(CLIBDImageEncoder, CLIBDDNAEncoder, CLIBDLanguageEncoder)"""
+    from clibd_amd.model import (BertConfigLite, BertForMaskedLM, BertModel, CLIBDDNAEncoder, CLIBDImageEncoder, CLIBDLanguageEncoder,
+                                 SimpleCLIP, VisionTransformer)
+
+    gs = torch.load(os.path.join(G, "step_tiny_golden.pt"), map_location="cpu", weights_only=False)
+    tiny = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+    m = SimpleCLIP(CLIBDImageEncoder(VisionTransformer(embed_dim=128, depth=2, num_heads=2, num_classes=10), 4, 128),
+                   CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, **tiny)), 4, 128),
+                   CLIBDLanguageEncoder(BertModel(BertConfigLite(vocab_size=1000, **tiny)), 4, 128))
+    assert list(m.state_dict().keys()) == gs["state_dict_keys"]
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert all(("linear_a_" in n or "linear_b_" in n or ".w_a." in n or ".w_b." in n or "head." in n or "decoder" in n or "proj." in n
+                or n == "logit_scale") for n in trainable)
+
+
+def test_trainable_parameter_counts_match_survey():
+    from clibd_amd.model import CLIBDDNAEncoder, CLIBDImageEncoder, SimpleCLIP, create_vit, load_pre_trained_bioscan_bert
+
+    m = SimpleCLIP(CLIBDImageEncoder(create_vit("vit_base_patch16_224"), 4, 768), CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), 4, 768), None)
+    n = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert n == 1_476_097  # 738,048 (image) + 738,048 (DNA) + logit_scale
+
+
+def test_lora_layer_quirks_and_rank():
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder, CLIBDImageEncoder, VisionTransformer
+    from clibd_amd.model.dna_encoder import _LoRALayer
+    from clibd_amd.model.image_encoder import _LoRA_qkv_timm
+
+    ie = CLIBDImageEncoder(VisionTransformer(embed_dim=64, depth=2, num_heads=1, num_classes=0), 4, 32, lora_layer=[])
+    assert all(isinstance(b.attn.qkv, _LoRA_qkv_timm) for b in ie.base_image_encoder.blocks)  # `if lora_layer:` quirk
+    de = CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, hidden_size=64, num_hidden_layers=2, num_attention_heads=1,
+                                                        intermediate_size=128)), 4, 32, lora_layer=[])
+    assert not any(isinstance(l.attention.self.query, _LoRALayer) for l in de.base_dna_encoder.bert.encoder.layer)
+    assert float(ie.base_image_encoder.blocks[0].attn.qkv.linear_b_q.weight.abs().sum()) == 0.0
+    with pytest.raises(AssertionError):
+        CLIBDImageEncoder(VisionTransformer(embed_dim=64, depth=1, num_heads=1), 0)
+    with pytest.raises(NotImplementedError):
+        CLIBDImageEncoder(VisionTransformer(embed_dim=64, depth=1, num_heads=1), 8)
+
+
+def test_load_clip_model_flag_semantics():
+    from clibd_amd.model import load_clip_model
+
+    a = _args(output_dim=768, image=types.SimpleNamespace(input_type="image", pre_train_model="vit_small_patch16_224"),
+              dna=types.SimpleNamespace(input_type="sequence"), disable_lora=False)
+    a.bioscan_bert_checkpoint = "/nonexistent/ckpt.pth"
+    m = load_clip_model(a)
+    assert m.language_encoder is None and m.image_encoder is not None and m.dna_encoder is not None
+    assert not m.image_encoder.base_image_encoder.blocks[0].mlp.fc1.weight.requires_grad
+    assert m.image_encoder.base_image_encoder.head.weight.requires_grad and m.logit_scale.requires_grad
+    # using_open_clip overwrites disable_lora (reference quirk, simple_clip.py:114-116)
+    b = _args(output_dim=768, dna=types.SimpleNamespace(input_type="sequence", freeze=True), disable_lora=True, using_open_clip=False)
+    b.bioscan_bert_checkpoint = None
+    m2 = load_clip_model(b)
+    assert not any(p.requires_grad for p in m2.dna_encoder.parameters())  # freeze
+    c = _args(output_dim=768, for_bio_clip=True)
+    with pytest.raises(NotImplementedError):
+        load_clip_model(c)
+
+
+def test_checkpoint_name_migration_and_roundtrip(tmp_path):
+    from clibd_amd.checkpoint import load_reference_checkpoint, update_checkpoint_param_names
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder, SimpleCLIP
+
+    tiny = dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128)
+    m = SimpleCLIP(None, CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, **tiny)), 4, 32), None)
+    sd = m.state_dict()
+    # a checkpoint as an old reference version + DDP would have written it
+    legacy = {"module." + k.replace("base_dna_encoder", "lora_barcode_bert"): v.clone() + 1.0 for k, v in sd.items()}
+    assert any("lora_barcode_bert" in k for k in legacy)
+    renamed = update_checkpoint_param_names({k[len("module."):]: v for k, v in legacy.items()})
+    assert sorted(renamed) == sorted(sd)
+    path = tmp_path / "best.pth"
+    torch.save(legacy, path)
+    res = load_reference_checkpoint(m, str(path))
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.allclose(m.state_dict()["logit_scale"], sd["logit_scale"] + 0)  # loaded in place
+    k0 = "dna_encoder.base_dna_encoder.bert.embeddings.word_embeddings.weight"
+    assert torch.equal(m.state_dict()[k0], legacy["module." + k0.replace("base_dna_encoder", "lora_barcode_bert")])
+
+
+def test_sequence_pipeline_matches_oracle():
+    from clibd_amd.model import get_sequence_pipeline
+    from oracle import clibd_oracle as O
+
+    pipe = get_sequence_pipeline()
+    for s in ("ACGTA" * 132, "ACGTAC", "A" * 1000, "ACGTN" * 100, ""):
+        assert pipe(s) == O.kmer_tokenize(s)
+
+
+def test_scale_learning_rate():
+    from clibd_amd.train import scale_learning_rate
+
+    assert scale_learning_rate(0.001, 500, world_size=4) == pytest.approx(0.004)
