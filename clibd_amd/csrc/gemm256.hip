@@ -2,13 +2,19 @@
 //
 //   out = epilogue(A[M,K] · W[N,K]^T), same contract and epilogue as gemm.hip (gemm_common.h).
 //
-// Geometry: wave (wm, wn) = (wave>>2, wave&3) owns a 128(M) x 64(N) sub-tile = 8 x 4 v_mfma_f32_16x16x32_bf16 tiles
-// (128 accumulator VGPRs).  A K-tile (BK = 64) is staged as FOUR 16-KiB half-tiles, cut along the *phase* structure
-// rather than along the wave grid:
-//     A_even : tile rows {128wm + 0..63}     (the "hm0" m-half of every wave)      needed at phase 0 of the K-tile
-//     W_hn0  : tile cols {64wn + n-tiles 0,1} (the "hn0" n-half of every wave)      needed at phase 0
-//     W_hn1  : tile cols {64wn + n-tiles 2,3}                                        needed at phase 1
-//     A_odd  : tile rows {128wm + 64..127}                                           needed at phase 2
+// Geometry: wave (wm, wn) = (wave>>2, wave&3) owns 128 output COLUMNS x 64 output ROWS = 8 x 4 v_mfma_f32_16x16x32_bf16
+// tiles (128 accumulator VGPRs).  The two operands are named by their role in the MFMA, not by the matrix:
+//     P ("column operand", MFMA B / D columns) = W rows  = output columns: 8 tiles per wave, two halves hm0 / hm1
+//     Q ("row operand",    MFMA A / D rows)    = A rows  = output rows   : 4 tiles per wave, two halves hn0 / hn1
+// so a lane (c = lane&15, g = lane>>4) ends up with D[4g + r][c] of every tile; P tile nt = 4hm + t carries tile-local
+// column 8c + nt, i.e. the lane owns 8 CONTIGUOUS output columns of rows 4g + r: one 16-byte bf16 store per row, and the
+// 16 lanes of a row group write 256 contiguous bytes (tools/micro/store_patterns: 68 B/clk/CU against 28 B/clk/CU for
+// the row-per-lane shape; adjacent LANES must be adjacent in memory for the store path to coalesce).
+// A K-tile (BK = 64) is staged as FOUR 16-KiB half-tiles, cut along the *phase* structure rather than the wave grid:
+//     P_hm0 : P tiles 0..3 of every wave (LDS rows 64wm + 16t + c)              needed at phase 0 of the K-tile
+//     Q_hn0 : Q tiles 0,1 of every wave  (tile rows 64wn + 0..31)               needed at phase 0
+//     Q_hn1 : Q tiles 2,3 of every wave  (tile rows 64wn + 32..63)              needed at phase 1
+//     P_hm1 : P tiles 4..7 of every wave                                        needed at phase 2
 // and a K-tile is computed as 4 phases of 16 MFMAs per wave — quadrants (hm0,hn0) (hm0,hn1) (hm1,hn1) (hm1,hn0) — so
 // each phase loads at most one new operand half into registers (12 / 4 / 8 / 0 ds_read_b128) and every half-tile is
 // dead in LDS right after the phase that read it.  With 2 stages (8 half-tile slots, 128 KiB) that early death lets
@@ -24,8 +30,8 @@
 // Persistent tiles: the grid is one workgroup per CU; each workgroup walks tiles id, id+grid, ...  Before the epilogue of
 // tile i it already issues the first six half-tiles of tile i+1 (LDS is idle during the epilogue), so the next tile's
 // HBM/L2 latency and this tile's output stores overlap; vmcnt counts stores too (in issue order), so the first four
-// phases of a tile wait with vmcnt(8 + stores of the previous epilogue) instead of vmcnt(8).  Workgroups start with a
-// small per-XCD-slot time skew so the chip's store bursts do not line up.
+// phases of a tile wait with vmcnt(8 + stores of the previous epilogue) instead of vmcnt(8).
+#include <cstdlib>
 #include "gemm_common.h"
 #include "host_util.h"
 
@@ -37,8 +43,16 @@ constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // 64 KiB
 constexpr int G256_THREADS = 512;
 constexpr int G256_LDS = 2 * STAGE_BYTES;      // 128 KiB
 
+#ifdef CLIBD_EXP_PNATURAL
+#define P_HM1_OFF 64
+#define P_PIECE_OFF 8
+#else
+#define P_HM1_OFF 4
+#define P_PIECE_OFF 64
+#endif
 #define CLIBD_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+template <int KIND, bool LORA, bool DIAG>
 __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -46,22 +60,28 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int nk = p.K / T_K;  // even, >= 2 (host-checked)
+    const int nk = p.K / T_K;  // even, >= 4 (host-checked)
     int tile = blockIdx.x;
     int m0, n0;          // tile being computed
     int nm0 = 0, nn0 = 0;  // tile whose loads are being issued (== m0,n0 until the last issue of the current tile)
 
-    // ---- per-lane LDS-DMA sources: half-tile type j (0 A_even, 1 W_hn0, 2 W_hn1, 3 A_odd) x this wave's 2 pieces
+    // ---- per-lane LDS-DMA sources: half-tile type j (0 P_hm0, 1 Q_hn0, 2 Q_hn1, 3 P_hm1) x this wave's 2 pieces
     const int prow = lane >> 3;
     const int chunk = (lane & 7) ^ prow;
     // Sources are NOT kept as pointers (8 x 64-bit per lane spilled): every half-tile piece of this lane derives from two
-    // tile-local rows + constants, and the 32-bit byte offset is rebuilt at issue time (3 VALU per LDS-DMA):
-    //   piece i (0/1) of A_even: tile row rowA + 8i        A_odd: + 64
-    //   piece i       of W_hn0 : tile col rowW + 32i       W_hn1: + 8
+    // tile-local rows + constants, and the 32-bit byte offset is rebuilt at issue time (3 VALU per LDS-DMA).
+    // This wave fills LDS rows 16*wave + 8i + prow (piece i = 0/1) of every half-tile:
+    //   P half: LDS row = 64wm' + 16t + c  ->  wm' = wave>>2, t = wave&3, c = 8i + prow;  tile col = 128wm' + 8c + 4hm + t
+    //           piece i of P_hm0: tile col rowP + 64i        P_hm1: + 4
+    //   Q half: LDS row = 32wn' + 16t + c  ->  wn' = wave>>1, t = wave&1, c = 8i + prow;  tile row = 64wn' + 32hn + 16t + c
+    //           piece i of Q_hn0: tile row rowQ + 8i         Q_hn1: + 32
     // (operands are < 4 GiB, host-checked, so base + 32-bit offset addresses them)
-    const int r0 = 16 * wave + prow;                              // LDS row of piece 0 inside a half-tile
-    const int rowA = (r0 & 63) + 128 * (r0 >> 6);
-    const int rowW = 64 * (wave >> 1) + w_col_of(wave & 1, prow);  // w_col_of(tq, iq): iq = prow (piece 0)
+#ifdef CLIBD_EXP_PNATURAL
+    const int rowP = 128 * (wave >> 2) + 16 * (wave & 3) + prow;
+#else
+    const int rowP = 128 * (wave >> 2) + 8 * prow + (wave & 3);
+#endif
+    const int rowQ = 64 * (wave >> 1) + 16 * (wave & 1) + prow;
     const unsigned chunk16 = (unsigned)chunk * 16u;
     const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.ldw * 2u;
     const char* const baseA = (const char*)p.A;
@@ -72,51 +92,56 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         nm0 = tm * T_M;
         nn0 = tn * T_N;
     };
-    // issue half-tile j (0 A_even, 1 W_hn0, 2 W_hn1, 3 A_odd) of K-tile u into stage (u & 1)
+    // issue half-tile j (0 P_hm0, 1 Q_hn0, 2 Q_hn1, 3 P_hm1) of K-tile u into stage (u & 1)
 #define ISSUE(u, j, stage)                                                                              \
     do {                                                                                                \
-        const unsigned koff_ = (unsigned)(u) * (T_K * 2) + chunk16;                                     \
         char* dst_ = smem + (stage) * STAGE_BYTES + (j) * HALF_BYTES + (2 * wave) * 1024;               \
-        int ra_ = rowA, rw_ = rowW;                                                                     \
-        asm volatile("" : "+v"(ra_), "+v"(rw_)); /* opaque: keeps the 8 per-tile offsets from being hoisted into (spilled) registers */ \
+        int rp_ = rowP, rq_ = rowQ;                                                                     \
+        unsigned kc_ = chunk16;                                                                         \
+        asm volatile("" : "+v"(rp_), "+v"(rq_), "+v"(kc_)); /* opaque: keeps per-tile / per-K-tile offset variants from being hoisted into (spilled) registers */ \
+        const unsigned koff_ = (unsigned)(u) * (T_K * 2) + kc_;                                         \
         if ((j) == 0 || (j) == 3) {                                                                     \
-            const int c_ = nm0 + ((j) == 3 ? 64 : 0);                                                   \
-            const unsigned g0_ = (unsigned)min(c_ + ra_, p.M - 1), g1_ = (unsigned)min(c_ + ra_ + 8, p.M - 1); \
-            glds16(baseA + (g0_ * lda2 + koff_), dst_);                                                 \
-            glds16(baseA + (g1_ * lda2 + koff_), dst_ + 1024);                                          \
-        } else {                                                                                        \
-            const int c_ = nn0 + ((j) == 2 ? 8 : 0);                                                    \
-            const unsigned g0_ = (unsigned)min(c_ + rw_, p.N - 1), g1_ = (unsigned)min(c_ + rw_ + 32, p.N - 1); \
+            const int c_ = nn0 + ((j) == 3 ? P_HM1_OFF : 0);                                            \
+            const unsigned g0_ = (unsigned)min(c_ + rp_, p.N - 1), g1_ = (unsigned)min(c_ + rp_ + P_PIECE_OFF, p.N - 1); \
             glds16(baseW + (g0_ * ldw2 + koff_), dst_);                                                 \
             glds16(baseW + (g1_ * ldw2 + koff_), dst_ + 1024);                                          \
+        } else {                                                                                        \
+            const int c_ = nm0 + ((j) == 2 ? 32 : 0);                                                   \
+            const unsigned g0_ = (unsigned)min(c_ + rq_, p.M - 1), g1_ = (unsigned)min(c_ + rq_ + 8, p.M - 1); \
+            glds16(baseA + (g0_ * lda2 + koff_), dst_);                                                 \
+            glds16(baseA + (g1_ * lda2 + koff_), dst_ + 1024);                                          \
         }                                                                                               \
     } while (0)
 
-    // ---- fragment read offsets inside a half-tile
+    // ---- fragment read offsets inside a half-tile: tile t of a wave sits 16 rows = 2048 bytes after tile 0 and the swizzle
+    // term (row & 7) does not depend on t, so ONE per-lane offset per operand (plus its ^64 twin for the second k-chunk)
+    // addresses every fragment as base + immediate.  The bases are passed through an opaque asm at every use: left alone,
+    // hipcc materialises ~20 stage/slot variants as loop-invariant VGPRs and spills them into the main loop.
     const int frow = lane & 15, fch = lane >> 4;
-    int a_off[4], w_off[2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a_off[t] = tile_off(64 * wm + 16 * t + frow, fch);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) w_off[t] = tile_off(32 * wn + 16 * t + frow, fch);
+    const int a_base = tile_off(64 * wm + frow, fch);
+    const int w_base = tile_off(32 * wn + frow, fch);
 
     f32x4 acc[2][4][2][2];  // [hm][mt][hn][nt]
     bf16x8 aF[4][2], w0F[2][2], w1F[2][2];  // [tile][kk]
 
 #define LOAD_A(stage, j)                                                                                     \
     do {                                                                                                     \
+        int o0_ = a_base, o1_ = a_base ^ 64;                                                                 \
+        asm volatile("" : "+v"(o0_), "+v"(o1_));                                                             \
         const char* b_ = smem + (stage) * STAGE_BYTES + (j) * HALF_BYTES;                                    \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                      \
-            aF[t][0] = *(const bf16x8*)(b_ + a_off[t]);                                                      \
-            aF[t][1] = *(const bf16x8*)(b_ + (a_off[t] ^ 64));                                               \
+            aF[t][0] = *(const bf16x8*)(b_ + o0_ + 2048 * t);                                                \
+            aF[t][1] = *(const bf16x8*)(b_ + o1_ + 2048 * t);                                                \
         }                                                                                                    \
     } while (0)
 #define LOAD_W(dstF, stage, j)                                                                               \
     do {                                                                                                     \
+        int o0_ = w_base, o1_ = w_base ^ 64;                                                                 \
+        asm volatile("" : "+v"(o0_), "+v"(o1_));                                                             \
         const char* b_ = smem + (stage) * STAGE_BYTES + (j) * HALF_BYTES;                                    \
         _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                      \
-            dstF[t][0] = *(const bf16x8*)(b_ + w_off[t]);                                                    \
-            dstF[t][1] = *(const bf16x8*)(b_ + (w_off[t] ^ 64));                                             \
+            dstF[t][0] = *(const bf16x8*)(b_ + o0_ + 2048 * t);                                              \
+            dstF[t][1] = *(const bf16x8*)(b_ + o1_ + 2048 * t);                                              \
         }                                                                                                    \
     } while (0)
 #define MMA(hm, hn, wF)                                                                                      \
@@ -168,12 +193,13 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         else if (allow_case == 3) CLIBD_WAIT_VMCNT(56);     \
         else CLIBD_WAIT_VMCNT(63);                          \
     } while (0)
-#define PHASE_HEAD(Q8)                                                                                       \
+#define PHASE_HEAD(Q8)  /* phase Q8 (0..7) of the first K-tile pair of a tile (kt = 0), store-aware wait */     \
     do {                                                                                                     \
+        constexpr int st_ = ((Q8) >> 2) & 1;                                                                 \
         constexpr int dl_ = (Q8) & 3;                                                                        \
-        if (dl_ == 0) { LOAD_W(w0F, 0, 1); LOAD_A(0, 0); }                                                   \
-        else if (dl_ == 1) { LOAD_W(w1F, 0, 2); }                                                            \
-        else if (dl_ == 2) { LOAD_A(0, 3); }                                                                 \
+        if (dl_ == 0) { LOAD_W(w0F, st_, 1); LOAD_A(st_, 0); }                                               \
+        else if (dl_ == 1) { LOAD_W(w1F, st_, 2); }                                                          \
+        else if (dl_ == 2) { LOAD_A(st_, 3); }                                                               \
         {                                                                                                    \
             constexpr int ju_ = ((Q8) + 2) & 3;                                                              \
             constexpr int du_ = ((Q8) + 6) >> 2;                                                             \
@@ -189,11 +215,16 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     } while (0)
 #define PROLOGUE_ISSUE()                                                     \
     do {                                                                     \
-        ISSUE(0, 0, 0); ISSUE(0, 1, 0); ISSUE(0, 2, 0); ISSUE(0, 3, 0);      \
-        ISSUE(1, 0, 1); ISSUE(1, 1, 1);                                      \
+        /* sched_barrier: one ISSUE's address arithmetic at a time (all six hoisted together cost ~24 VGPRs -> acc spills) */ \
+        ISSUE(0, 0, 0); __builtin_amdgcn_sched_barrier(0);                   \
+        ISSUE(0, 1, 0); __builtin_amdgcn_sched_barrier(0);                   \
+        ISSUE(0, 2, 0); __builtin_amdgcn_sched_barrier(0);                   \
+        ISSUE(0, 3, 0); __builtin_amdgcn_sched_barrier(0);                   \
+        ISSUE(1, 0, 1); __builtin_amdgcn_sched_barrier(0);                   \
+        ISSUE(1, 1, 1); __builtin_amdgcn_sched_barrier(0);                   \
     } while (0)
 
-    // ---- start-up skew (see header) and the first tile's prologue: L_0 .. L_5 = K-tile 0 + A_even, W_hn0 of K-tile 1
+    // ---- start-up skew (see header) and the first tile's prologue: L_0 .. L_5 = K-tile 0 + P_hm0, Q_hn0 of K-tile 1
     if (skew_ticks > 0) {
         const int cls = (blockIdx.x >> 3) & 3;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -209,7 +240,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     int tile_i = 0;
 #define STAMP(k)                                                                                         \
     do {                                                                                                 \
-        if (stamps != nullptr && tile_i < 16 && (wave == 0 || wave == 4) && lane == 0)                    \
+        if (DIAG && stamps != nullptr && tile_i < 16 && (wave == 0 || wave == 4) && lane == 0)                    \
             stamps[(((size_t)blockIdx.x * 16 + tile_i) * 2 + (wave >> 2)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
 
@@ -231,16 +262,15 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
 #pragma unroll
                     for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        int kt = 0;
-        if (nk >= 4) {
-            PHASE_HEAD(0); PHASE_HEAD(1); PHASE_HEAD(2); PHASE_HEAD(3);
-            STAMP(1);
+        int kt = 0;  // nk >= 4 (host-checked): the head phases always run and consume the literal-zero accumulators
+        PHASE_HEAD(0); PHASE_HEAD(1); PHASE_HEAD(2); PHASE_HEAD(3);
+        STAMP(1);
+        // from phase 4 on the awaited half-tile (L_6 ...) was issued AFTER the stores: in-order vmcnt => plain vmcnt(8)
+        PHASE(4, true, 8); PHASE(5, true, 8); PHASE(6, true, 8); PHASE(7, true, 8);
+        STAMP(2);
+        for (kt = 2; kt < nk - 2; kt += 2) {
+            PHASE(0, true, 8); PHASE(1, true, 8); PHASE(2, true, 8); PHASE(3, true, 8);
             PHASE(4, true, 8); PHASE(5, true, 8); PHASE(6, true, 8); PHASE(7, true, 8);
-            STAMP(2);
-            for (kt = 2; kt < nk - 2; kt += 2) {
-                PHASE(0, true, 8); PHASE(1, true, 8); PHASE(2, true, 8); PHASE(3, true, 8);
-                PHASE(4, true, 8); PHASE(5, true, 8); PHASE(6, true, 8); PHASE(7, true, 8);
-            }
         }
         // last iteration (kt = nk-2): only L_{4nk-2}, L_{4nk-1} are left to issue; drain with exact counts
         STAMP(3);
@@ -252,55 +282,104 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         STAMP(4);
         if (has_next) PROLOGUE_ISSUE();  // next tile's first six half-tiles fly while this tile's epilogue runs
 
+        // lane coordinates made opaque per tile: everything the epilogue derives from them (16 row offsets x several
+        // leading dimensions) is rebuilt here instead of being hoisted out of the persistent loop into spilled registers
+        int erow = frow, egrp = fch;
+        asm volatile("" : "+v"(erow), "+v"(egrp));
         // ---- LoRA rank-8 update: one extra zero-padded k-step (lanes with k-chunk 0 carry U[m,0:8] / V[n,0:8])
-        if (ep.rank_u != nullptr) {
-            bf16x8 vf[4];
+        // (compile-time flag: a run-time test here puts all 128 accumulators behind a phi the register allocator
+        //  cannot coalesce -> 26 spilled VGPRs and vmcnt(0) drains around their reloads)
+        if (LORA) {
+            bf16x8 uf[2][2];  // Q side (output rows): [hn][n]
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                vf[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (fch == 0) {
-                    const int gn = min(n0 + 64 * wn + w_col_of(t, frow), p.N - 1);
-                    vf[t] = *(const bf16x8*)((const unsigned short*)ep.rank_v + (size_t)gn * 8);
+            for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    uf[hn][n] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (egrp == 0) {
+                        const int gm = min(m0 + 64 * wn + 32 * hn + 16 * n + erow, p.M - 1);
+                        uf[hn][n] = *(const bf16x8*)((const unsigned short*)ep.rank_u + (size_t)gm * ep.ld_rank_u);
+                    }
                 }
-            }
 #pragma unroll
             for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    bf16x8 uf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                    if (fch == 0) {
-                        const int gm = min(m0 + 128 * wm + 64 * hm + 16 * t + frow, p.M - 1);
-                        uf = *(const bf16x8*)((const unsigned short*)ep.rank_u + (size_t)gm * ep.ld_rank_u);
+                    bf16x8 vf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};  // P side (output columns)
+                    if (egrp == 0) {
+                        const int gn = n0 + 128 * wm + 8 * erow + 4 * hm + t;
+                        vf = *(const bf16x8*)((const unsigned short*)ep.rank_v + (size_t)gn * 8);
                     }
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[hm][t][n >> 1][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[n], uf, acc[hm][t][n >> 1][n & 1], 0, 0, 0);
+                        acc[hm][t][n >> 1][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[n >> 1][n & 1], vf, acc[hm][t][n >> 1][n & 1], 0, 0, 0);
                 }
         }
 
-        // ---- epilogue: lane owns rows m0 + 128wm + 64hm + 16t + (lane&15), columns nb .. nb+15 (e = 4*ntile + reg)
+        // ---- epilogue: lane (c = frow, g = fch) owns rows m0 + 64wn + 32hn + 16n + 4g + r, columns nb .. nb+7 (e = 4hm + t)
         {
-            const int nb = n0 + 64 * wn + 16 * fch;  // < N: N % 256 == 0 (host-checked)
-            float bias[16];
-            load_bias16(ep, nb, true, bias);
-#pragma unroll
-            for (int hm = 0; hm < 2; ++hm)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int m = m0 + 128 * wm + 64 * hm + 16 * t + frow;
-                    if (m >= p.M) continue;
-                    float v[16];
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[4 * n + r] = acc[hm][t][n >> 1][n & 1][r] + bias[4 * n + r];
-                    store_row16(ep, m, nb, v);
-                }
+            const int nb = n0 + 128 * wm + 8 * erow;  // < N: N % 256 == 0 (host-checked)
+            const int mb = m0 + 64 * wn + 4 * egrp;
+            float bias[8];
+            load_bias8(ep, nb, bias);
+#define FOR_ROWS(...)                                                                                        \
+    _Pragma("unroll") for (int hn = 0; hn < 2; ++hn)                                                         \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                        \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                  \
+                const int m = mb + 32 * hn + 16 * n + r;                                                     \
+                __VA_ARGS__                                                                                  \
+            }
+            if (KIND == EPI_MUL_AUX || KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP) {
+                // Two passes so that no store sits between the epilogue's loads: vmcnt retires in order, and a load
+                // waited behind earlier stores would pay their HBM write latency once per row (16 serial round trips).
+                // Pass 1 folds bias / dropout / aux / residual into the accumulators in place (loads only, rows clamped),
+                // pass 2 only stores.
+                FOR_ROWS({
+                    const int mc = min(m, p.M - 1);
+                    float v[8];
+                    _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r] + bias[4 * hm + t];
+                    fold_row8<KIND>(ep, mc, nb, v);
+                    _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[hm][t][hn][n][r] = v[4 * hm + t];
+                    if (n == 1 && r == 3) {  // 8 rows (8 aux / 16 residual 16-B loads) in flight per group
+                        // pin the folded values here: left alone, LLVM sinks the adds / multiplies into pass 2's row
+                        // predicates and keeps all 32 loaded vectors (128 VGPRs) alive instead
+                        _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
+                            _Pragma("unroll") for (int t = 0; t < 4; ++t)
+                                _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) asm volatile("" : "+v"(acc[hm][t][hn][n2]));
+                    }
+                })
+                FOR_ROWS({
+                    if (m < p.M) {
+                        float v[8];
+                        _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
+                            _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r];
+                        if (KIND == EPI_MUL_AUX) {
+                            *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+                        } else {
+                            f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
+                            o[0] = (f32x4){v[0], v[1], v[2], v[3]};
+                            o[1] = (f32x4){v[4], v[5], v[6], v[7]};
+                        }
+                    }
+                })
+            } else {
+                FOR_ROWS({
+                    if (m < p.M) {
+                        float v[8];
+                        _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
+                            _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r] + bias[4 * hm + t];
+                        store_row8<KIND>(ep, m, nb, v);
+                    }
+                })
+            }
+#undef FOR_ROWS
         }
         STAMP(5);
-        ++tile_i;
+        if (DIAG) ++tile_i;
         if (!has_next) break;
-        // a full tile issued exactly 8 rows x (2*stores_case) stores per lane; a ragged one fewer: be conservative there
+        // a full tile issued exactly 16 rows x stores_case 16-B stores per lane; a ragged one fewer: be conservative there
         allow_case = (m0 + T_M <= p.M) ? stores_case : 0;
         tile = next;
     }
@@ -308,9 +387,29 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
 
 static long long* g_stamp_buffer = nullptr;  // diagnostic only (tools/), never set on the product path
 
+static int skew_env_value() {
+    static const int v = [] { const char* e = getenv("CLIBD_GEMM_SKEW"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+static const void* kernel_ptr(int kind, bool lora, bool diag) {
+#define K256(KIND)                                                                 \
+    (diag ? (const void*)gemm256_bf16_nt_kernel<KIND, false, true>                 \
+          : lora ? (const void*)gemm256_bf16_nt_kernel<KIND, true, false> : (const void*)gemm256_bf16_nt_kernel<KIND, false, false>)
+    switch (kind) {
+        case EPI_BF16: return K256(EPI_BF16);
+        case EPI_GELU_SAVE: return K256(EPI_GELU_SAVE);
+        case EPI_MUL_AUX: return K256(EPI_MUL_AUX);
+        case EPI_RES_F32: return K256(EPI_RES_F32);
+        case EPI_RES_F32_DROP: return K256(EPI_RES_F32_DROP);
+        default: return K256(EPI_GENERIC);
+    }
+#undef K256
+}
+
 bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     const int nk = p.K / T_K;
-    if (p.K % T_K != 0 || nk < 2 || (nk & 1)) return false;
+    if (p.K % T_K != 0 || nk < 4 || (nk & 1)) return false;
     if (p.N % T_N != 0) return false;
     if (p.ep.split_k > 1) return false;
     const long long tiles = (long long)((p.M + T_M - 1) / T_M) * (p.N / T_N);
@@ -318,8 +417,11 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     if (p.N < 1024 && p.K < 1536) return false;     // short-K, narrow-N (e.g. 768x768 projections): HBM-bound, two 128^2 blocks per CU overlap better (measured)
     if ((unsigned long long)p.M * p.lda * 2ull >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2ull >= (1ull << 32)) return false;  // too few 256x256 tiles to fill 256 CUs: the 128x128 kernel wins
     static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) ==
-               hipSuccess;
+        bool ok = true;
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < EPI_NUM_KINDS; ++k)
+                ok = ok && hipFuncSetAttribute(kernel_ptr(k, v == 1, v == 2), hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+        return ok;
     }();
     if (!attr_ok) return false;
     static const int num_cus = [] {
@@ -334,15 +436,16 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     q.tiles_m = (p.M + T_M - 1) / T_M;
     q.tiles_n = p.N / T_N;
     const int grid = (int)(tiles < num_cus ? tiles : num_cus);
-    // start-up skew between the 4 classes of workgroups: a quarter of a tile's duration each (s_memrealtime = 100 MHz);
-    // only worth it when a workgroup runs several tiles
-    const float tile_us = 1.4f * nk + 5.0f;
-    // Measured (tools/gemm_stamps.py): the epilogue of a 256x256 bf16 tile takes ~10-13k cycles = the per-CU store-path
-    // rate (~10.7 B/clk/CU), not a chip-wide burst: neither a start-up skew, a dynamic tile queue nor full-line-coalesced
-    // stores (lane exchange) shortened it, so the schedule stays static and the skew is off.
-    const int skew_ticks = 0;
-    (void)tile_us;
-    hipLaunchKernelGGL(gemm256_bf16_nt_kernel, dim3((unsigned)grid), dim3(G256_THREADS), G256_LDS, stream, q, (int)tiles, skew_ticks, g_stamp_buffer);
+    const int kind = epilogue_kind(p.ep);
+    int ntiles_i = (int)tiles;
+    int skew_arg = skew_env_value();
+    long long* stamp_arg = (p.ep.rank_u != nullptr) ? nullptr : g_stamp_buffer;
+    // Diagnostics (tools/gemm_stamps.py): a stamp buffer selects the instrumented instantiation; CLIBD_GEMM_SKEW=<ticks of
+    // the 100 MHz s_memrealtime> adds a start-up skew between 4 classes of workgroups there.  Never used on the product path.
+    const bool lora = p.ep.rank_u != nullptr;
+    const bool diag = g_stamp_buffer != nullptr && !lora;
+    void* args[] = {(void*)&q, (void*)&ntiles_i, (void*)&skew_arg, (void*)&stamp_arg};
+    if (hipLaunchKernel(kernel_ptr(kind, lora, diag), dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) != hipSuccess) return false;
     return true;
 }
 

@@ -128,6 +128,157 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
     }
 }
 
+__device__ __forceinline__ void load_bias8(const clibd_gemm_epilogue& ep, int nb, float bias[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (ep.bias != nullptr) {
+        const f32x4 b0 = *(const f32x4*)(ep.bias + nb), b1 = *(const f32x4*)(ep.bias + nb + 4);
+        bias[0] = b0[0]; bias[1] = b0[1]; bias[2] = b0[2]; bias[3] = b0[3];
+        bias[4] = b1[0]; bias[5] = b1[1]; bias[6] = b1[2]; bias[7] = b1[3];
+    }
+}
+
+__device__ __forceinline__ uint4 pack8bf(const float v[8]) {
+    uint4 o;
+    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+    return o;
+}
+
+// Epilogue kinds of the 256x256 kernel: the epilogue runs once per output row (16 rows per lane and tile), so the
+// wave-uniform flag tests of the generic form (~10 scalar branches per row) are resolved ONCE per launch on the host
+// and the common shapes get straight-line code.
+enum : int {
+    EPI_GENERIC = 0,    // anything (store_row8<EPI_GENERIC> tests every field)
+    EPI_BF16 = 1,       // [bias] -> out_bf16                                   (qkv + LoRA, dgrad outputs)
+    EPI_GELU_SAVE = 2,  // [bias] -> gelu -> out_bf16, gelu' -> out_pre_bf16    (fc1 forward)
+    EPI_MUL_AUX = 3,    // * aux_bf16 -> out_bf16                               (fc2 dgrad x gelu')
+    EPI_RES_F32 = 4,    // [bias] + residual_f32 -> out_f32                     (proj / fc2 forward)
+    EPI_RES_F32_DROP = 5,  // [bias] -> dropout -> + residual_f32 -> out_f32    (BERT proj / fc2 forward, train mode)
+    EPI_NUM_KINDS = 6,
+};
+
+__host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
+    if (ep.split_k > 1) return EPI_GENERIC;
+    const bool drop = ep.drop_thr16 > 0;
+    if (ep.act == CLIBD_ACT_NONE && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_BF16;
+    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE;
+    if (ep.act == CLIBD_ACT_MUL_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX;
+    if (ep.act == CLIBD_ACT_NONE && !ep.out_pre_bf16 && ep.residual_f32 && ep.out_f32 && !ep.out_bf16) return drop ? EPI_RES_F32_DROP : EPI_RES_F32;
+    return EPI_GENERIC;
+}
+
+// One output row m, 8 contiguous columns nb..nb+7 held by this lane (gemm256: the 16 lanes of a row cover 128 contiguous
+// columns): v = acc + bias already applied by the caller.  Same operation order as store_row16; no split-K.
+template <int KIND>
+__device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
+    if (KIND == EPI_BF16) {
+        *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
+    if (KIND == EPI_GELU_SAVE) {
+        float dg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gelu_and_grad_f(bfround(v[e]), v[e], dg[e]);
+        *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(dg);
+        *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
+    if (KIND == EPI_MUL_AUX) {
+        const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] *= bf2f((unsigned short)(xs[e] & 0xffffu));
+            v[2 * e + 1] *= bf2f((unsigned short)(xs[e] >> 16));
+        }
+        *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
+    if (KIND == EPI_GENERIC || KIND == EPI_RES_F32_DROP) {
+        if (KIND == EPI_RES_F32_DROP || ep.drop_thr16 > 0) {
+            const unsigned base = (unsigned)m * (unsigned)ep.drop_ld + (unsigned)nb;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                float f0, f1;
+                drop_pair(ep.drop_seed, base + e, (unsigned)ep.drop_thr16, ep.drop_scale, f0, f1);
+                v[e] *= f0;
+                v[e + 1] *= f1;
+            }
+        }
+    }
+    if (KIND == EPI_GENERIC) {
+        if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
+            float dg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gelu_and_grad_f(bfround(v[e]), v[e], dg[e]);
+            *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(dg);
+        } else if (ep.out_pre_bf16 != nullptr) {
+            *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bfround(v[e]);
+        }
+        if (ep.act == CLIBD_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (ep.act == CLIBD_ACT_GELU_GRAD || ep.act == CLIBD_ACT_MUL_AUX) {
+            const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+            const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = bf2f((unsigned short)(xs[e] & 0xffffu)), a1 = bf2f((unsigned short)(xs[e] >> 16));
+                if (ep.act == CLIBD_ACT_GELU_GRAD) {
+                    v[2 * e] *= gelu_grad_f(a0);
+                    v[2 * e + 1] *= gelu_grad_f(a1);
+                } else {
+                    v[2 * e] *= a0;
+                    v[2 * e + 1] *= a1;
+                }
+            }
+        }
+    }
+    if (KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP || ep.residual_f32 != nullptr) {
+        const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
+        const f32x4 r0 = rs[0], r1 = rs[1];
+        v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
+        v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
+    }
+    if (KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP || ep.out_f32 != nullptr) {
+        f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
+        o[0] = (f32x4){v[0], v[1], v[2], v[3]};
+        o[1] = (f32x4){v[4], v[5], v[6], v[7]};
+    }
+    if (KIND == EPI_GENERIC && ep.out_bf16 != nullptr) *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+}
+
+// Pass 1 of the two-pass epilogues (gemm256): everything of store_row8<KIND> up to, not including, the stores.
+template <int KIND>
+__device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
+    if (KIND == EPI_MUL_AUX) {
+        const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] *= bf2f((unsigned short)(xs[e] & 0xffffu));
+            v[2 * e + 1] *= bf2f((unsigned short)(xs[e] >> 16));
+        }
+    } else {  // EPI_RES_F32 / EPI_RES_F32_DROP
+        if (KIND == EPI_RES_F32_DROP) {
+            const unsigned base = (unsigned)m * (unsigned)ep.drop_ld + (unsigned)nb;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                float f0, f1;
+                drop_pair(ep.drop_seed, base + e, (unsigned)ep.drop_thr16, ep.drop_scale, f0, f1);
+                v[e] *= f0;
+                v[e + 1] *= f1;
+            }
+        }
+        const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
+        const f32x4 r0 = rs[0], r1 = rs[1];
+        v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
+        v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
+    }
+}
+
 // host side (gemm256.hip): returns true when the 256x256 kernel took the launch
 bool gemm256_try_launch(const GemmParams& p, hipStream_t stream);
 
