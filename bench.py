@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-gemm-timing", action="store_true")
+    ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
     return ap.parse_args()
 
 
@@ -49,7 +50,7 @@ class GemmTimer:
     """HIP-event brackets around every GEMM launch (same stream as the launch) + algorithmic FLOPs."""
 
     def __init__(self):
-        self.events, self.flops, self.enabled = [], 0.0, False
+        self.events, self.flops, self.enabled, self.shapes = [], 0.0, False, []
 
     def install(self):
         from clibd_amd import ops
@@ -66,6 +67,7 @@ class GemmTimer:
             e1.record()
             timer.events.append((e0, e1))
             timer.flops += 2.0 * a.shape[0] * w.shape[0] * a.shape[1]
+            timer.shapes.append((a.shape[0], w.shape[0], a.shape[1], "+".join(sorted(k for k, v in kw.items() if v is not None))))
 
         ops.gemm_nt = timed
         import clibd_amd.engine as eng
@@ -78,6 +80,16 @@ class GemmTimer:
             return None
         ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events)
         return {"launches": len(self.events), "total_ms": ms, "tflops": self.flops / (ms * 1e-3) / 1e12}
+
+    def breakdown(self, steps):
+        agg = {}
+        for (e0, e1), key in zip(self.events, self.shapes):
+            n, t = agg.get(key, (0, 0.0))
+            agg[key] = (n + 1, t + e0.elapsed_time(e1))
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        for (M, N, K, kinds), (n, t) in rows:
+            print(f"[gemm] M={M:6d} N={N:5d} K={K:5d} x{n // steps:3d}/step {t / steps:7.3f} ms/step {t / n * 1e3:7.1f} us each "
+                  f"{2.0 * M * N * K * n / (t * 1e-3) / 1e12:7.1f} TF  {kinds}", file=sys.stderr, flush=True)
 
 
 def cpu_baseline(batch: int):
@@ -173,6 +185,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         pairs_per_s = b * world * args.steps / elapsed
         gemm = timer.result()
+        if gemm and args.gemm_breakdown:
+            timer.breakdown(args.steps)
         step_frac = pairs_per_s * GF_PER_PAIR_TRAIN * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12)
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "kernel": "gemm_bf16_nt_kernel", "step_frac": step_frac,

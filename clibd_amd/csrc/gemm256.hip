@@ -414,7 +414,6 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     if (p.ep.split_k > 1) return false;
     const long long tiles = (long long)((p.M + T_M - 1) / T_M) * (p.N / T_N);
     if (p.M < 1024 || tiles < 128) return false;
-    if (p.N < 1024 && p.K < 1536) return false;     // short-K, narrow-N (e.g. 768x768 projections): HBM-bound, two 128^2 blocks per CU overlap better (measured)
     if ((unsigned long long)p.M * p.lda * 2ull >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2ull >= (1ull << 32)) return false;  // too few 256x256 tiles to fill 256 CUs: the 128x128 kernel wins
     static const bool attr_ok = [] {
         bool ok = true;

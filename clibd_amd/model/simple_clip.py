@@ -9,6 +9,7 @@ and raise.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np
@@ -59,15 +60,55 @@ class SimpleCLIP(nn.Module):
         else:
             self.logit_bias = None
 
+    # The towers are independent until the loss, so each one runs on its own HIP stream: the persistent GEMM grids are one
+    # workgroup per CU, and the CUs a kernel's last partial round leaves idle (up to ~25 % of a 591-tile projection GEMM)
+    # pick up the other tower's workgroups instead of waiting.  autograd replays each tower's backward on its forward
+    # stream, so the backward overlaps the same way.  CLIBD_TOWER_STREAMS=0 keeps everything on the current stream.
+    overlap_towers = os.environ.get("CLIBD_TOWER_STREAMS", "1") != "0"
+
+    def _side_streams(self, device):
+        cache = self.__dict__.setdefault("_streams", {})
+        if device not in cache:
+            cache[device] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return cache[device]
+
     def forward(self, image_input, dna_input, language_input):
-        image_output = dna_output = language_output = None
-        if self.dna_encoder is not None:
-            dna_output = l2_normalize(self.dna_encoder(dna_input))
-        if self.image_encoder is not None:
-            image_output = l2_normalize(self.image_encoder(image_input))
-        if self.language_encoder is not None:
-            language_output = l2_normalize(self.language_encoder(language_input))
+        towers = [(self.dna_encoder, dna_input), (self.image_encoder, image_input), (self.language_encoder, language_input)]
+        present = [i for i, (enc, x) in enumerate(towers) if enc is not None]
+        outs = [None, None, None]
+        dev = self.logit_scale.device
+        if not (self.overlap_towers and dev.type == "cuda" and len(present) > 1):
+            for i in present:
+                outs[i] = l2_normalize(towers[i][0](towers[i][1]))
+        else:
+            main = torch.cuda.current_stream(dev)
+            sides = self._side_streams(dev)
+            # the image tower (largest) stays on the current stream; DNA and text go to side streams
+            side_of = {0: sides[0], 2: sides[1]} if 1 in present else {present[1]: sides[0]}
+            for i in present:
+                st = side_of.get(i)
+                if st is None:
+                    continue
+                st.wait_stream(main)  # inputs, parameters (optimizer step) and weight caches were produced on `main`
+                with torch.cuda.stream(st):
+                    outs[i] = l2_normalize(towers[i][0](towers[i][1]))
+            for i in present:
+                if i not in side_of:
+                    outs[i] = l2_normalize(towers[i][0](towers[i][1]))
+            for i, st in side_of.items():
+                if i in present:
+                    main.wait_stream(st)
+                    outs[i].record_stream(main)
+        dna_output, image_output, language_output = outs
         return image_output, dna_output, language_output, self.logit_scale.exp(), self.logit_bias
+
+    def join_streams(self):
+        """Make the current stream wait for the towers' side streams (call after backward(): gradients written into the
+        fused optimizer's flat buffers by a tower's backward are produced on that tower's stream)."""
+        for dev, sides in self.__dict__.get("_streams", {}).items():
+            main = torch.cuda.current_stream(dev)
+            for st in sides:
+                main.wait_stream(st)
 
 
 def _get(cfg, name, default=None):

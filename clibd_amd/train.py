@@ -51,6 +51,8 @@ class Trainer:
             logit_scale = 1.0 / 0.07
         loss = self.criterion(image_out, dna_out, text_out, labels, logit_scale)
         loss.backward()
+        if hasattr(self.model, "join_streams"):
+            self.model.join_streams()  # tower backward passes ran on the towers' own streams
         if self.world_size > 1:
             dist.all_reduce(self.optimizer.flat_g)
         self.optimizer.step()
