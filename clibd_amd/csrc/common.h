@@ -20,8 +20,13 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 __device__ __forceinline__ float bf2f(unsigned short h) {
     return __builtin_bit_cast(float, ((unsigned)h) << 16);
 }
+// two f32 -> packed bf16 pair (lo in bits 0..15): the vector conversion lowers to ONE v_cvt_pk_bf16_f32; converting the
+// halves separately costs the same instruction twice plus and / shift / or
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t r = __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, r);
 }
 __device__ __forceinline__ float bfround(float x) { return bf2f(f2bf(x)); }
 

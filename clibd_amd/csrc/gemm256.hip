@@ -28,9 +28,10 @@
 //     load segment (ds_read + LDS-DMA issue), so the matrix pipe and the LDS/VMEM paths overlap inside one workgroup.
 //
 // Persistent tiles: the grid is one workgroup per CU; each workgroup walks tiles id, id+grid, ...  Before the epilogue of
-// tile i it already issues the first six half-tiles of tile i+1 (LDS is idle during the epilogue), so the next tile's
-// HBM/L2 latency and this tile's output stores overlap; vmcnt counts stores too (in issue order), so the first four
-// phases of a tile wait with vmcnt(8 + stores of the previous epilogue) instead of vmcnt(8).
+// tile i it already issues the first EIGHT half-tiles of tile i+1 (all slots are free at a tile boundary), so the next
+// tile's HBM/L2 latency and this tile's output stores overlap.  vmcnt retires in issue order and counts stores, so a wait
+// for a half-tile issued AFTER the stores (L_8, first needed at phase 6) also waits for the stores: the first six phases
+// of a tile wait with vmcnt(8 + stores of the previous epilogue) and the stores get six phases to drain.
 #include <cstdlib>
 #include "gemm_common.h"
 #include "host_util.h"
@@ -43,16 +44,9 @@ constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // 64 KiB
 constexpr int G256_THREADS = 512;
 constexpr int G256_LDS = 2 * STAGE_BYTES;      // 128 KiB
 
-#ifdef CLIBD_EXP_PNATURAL
-#define P_HM1_OFF 64
-#define P_PIECE_OFF 8
-#else
-#define P_HM1_OFF 4
-#define P_PIECE_OFF 64
-#endif
 #define CLIBD_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int KIND, bool LORA, bool DIAG>
+template <int KIND, bool LORA, bool BIAS, bool DIAG>
 __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -68,82 +62,88 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     // ---- per-lane LDS-DMA sources: half-tile type j (0 P_hm0, 1 Q_hn0, 2 Q_hn1, 3 P_hm1) x this wave's 2 pieces
     const int prow = lane >> 3;
     const int chunk = (lane & 7) ^ prow;
-    // Sources are NOT kept as pointers (8 x 64-bit per lane spilled): every half-tile piece of this lane derives from two
-    // tile-local rows + constants, and the 32-bit byte offset is rebuilt at issue time (3 VALU per LDS-DMA).
     // This wave fills LDS rows 16*wave + 8i + prow (piece i = 0/1) of every half-tile:
     //   P half: LDS row = 64wm' + 16t + c  ->  wm' = wave>>2, t = wave&3, c = 8i + prow;  tile col = 128wm' + 8c + 4hm + t
     //           piece i of P_hm0: tile col rowP + 64i        P_hm1: + 4
     //   Q half: LDS row = 32wn' + 16t + c  ->  wn' = wave>>1, t = wave&1, c = 8i + prow;  tile row = 64wn' + 32hn + 16t + c
     //           piece i of Q_hn0: tile row rowQ + 8i         Q_hn1: + 32
-    // (operands are < 4 GiB, host-checked, so base + 32-bit offset addresses them)
-#ifdef CLIBD_EXP_PNATURAL
-    const int rowP = 128 * (wave >> 2) + 16 * (wave & 3) + prow;
-#else
+    // The load segment of a phase is on the critical path (it must fit under the other wave group's 256-cycle MFMA burst),
+    // so it carries NO per-issue address arithmetic: the six per-lane byte offsets of a tile (row * ld + swizzled chunk;
+    // operands are < 4 GiB, host-checked) are computed once per tile, and the K offset rides in the scalar base address.
     const int rowP = 128 * (wave >> 2) + 8 * prow + (wave & 3);
-#endif
     const int rowQ = 64 * (wave >> 1) + 16 * (wave & 1) + prow;
     const unsigned chunk16 = (unsigned)chunk * 16u;
     const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.ldw * 2u;
     const char* const baseA = (const char*)p.A;
     const char* const baseW = (const char*)p.W;
+    unsigned offP0 = 0, offP1 = 0;                          // P_hm0 pieces (P_hm1 = + 4 rows: scalar)
+    unsigned offQ00 = 0, offQ01 = 0, offQ10 = 0, offQ11 = 0;  // Q_hn0 / Q_hn1 pieces (rows clamp individually on a ragged tile)
     auto set_sources = [&](int tile_id) {
         int tm, tn;
         tile_coords(tile_id, p.tiles_m, p.tiles_n, 4, tm, tn);
         nm0 = tm * T_M;
         nn0 = tn * T_N;
+        offP0 = (unsigned)(nn0 + rowP) * ldw2 + chunk16;
+        offP1 = (unsigned)(nn0 + rowP + 64) * ldw2 + chunk16;
+        offQ00 = (unsigned)min(nm0 + rowQ, p.M - 1) * lda2 + chunk16;
+        offQ01 = (unsigned)min(nm0 + rowQ + 8, p.M - 1) * lda2 + chunk16;
+        offQ10 = (unsigned)min(nm0 + rowQ + 32, p.M - 1) * lda2 + chunk16;
+        offQ11 = (unsigned)min(nm0 + rowQ + 40, p.M - 1) * lda2 + chunk16;
     };
-    // issue half-tile j (0 P_hm0, 1 Q_hn0, 2 Q_hn1, 3 P_hm1) of K-tile u into stage (u & 1)
+    // issue half-tile j (0 P_hm0, 1 Q_hn0, 2 Q_hn1, 3 P_hm1) of K-tile u into stage (u & 1): two LDS-DMA instructions in the
+    // scalar-base + 32-bit-VGPR-offset form (inline asm: left to the compiler, the loop-invariant per-lane parts become
+    // 64-bit VGPR pointers re-added every issue).  These loads are invisible to the compiler's waitcnt pass; every wait
+    // for them is an explicit CLIBD_WAIT_VMCNT (the counter still retires in issue order across asm and compiler ops).
+    const unsigned lds_dma0 = (unsigned)(size_t)(lds_void*)smem + (unsigned)(2 * wave) * 1024u;
+#define GLDS_PAIR(off0, off1, sbase, ldsdst)                                                            \
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"                   \
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                         \
+                 :: "v"(off0), "v"(off1), "s"(sbase), "s"(ldsdst), "s"((ldsdst) + 1024u) : "memory", "m0")
 #define ISSUE(u, j, stage)                                                                              \
     do {                                                                                                \
-        char* dst_ = smem + (stage) * STAGE_BYTES + (j) * HALF_BYTES + (2 * wave) * 1024;               \
-        int rp_ = rowP, rq_ = rowQ;                                                                     \
-        unsigned kc_ = chunk16;                                                                         \
-        asm volatile("" : "+v"(rp_), "+v"(rq_), "+v"(kc_)); /* opaque: keeps per-tile / per-K-tile offset variants from being hoisted into (spilled) registers */ \
-        const unsigned koff_ = (unsigned)(u) * (T_K * 2) + kc_;                                         \
-        if ((j) == 0 || (j) == 3) {                                                                     \
-            const int c_ = nn0 + ((j) == 3 ? P_HM1_OFF : 0);                                            \
-            const unsigned g0_ = (unsigned)min(c_ + rp_, p.N - 1), g1_ = (unsigned)min(c_ + rp_ + P_PIECE_OFF, p.N - 1); \
-            glds16(baseW + (g0_ * ldw2 + koff_), dst_);                                                 \
-            glds16(baseW + (g1_ * ldw2 + koff_), dst_ + 1024);                                          \
-        } else {                                                                                        \
-            const int c_ = nm0 + ((j) == 2 ? 32 : 0);                                                   \
-            const unsigned g0_ = (unsigned)min(c_ + rq_, p.M - 1), g1_ = (unsigned)min(c_ + rq_ + 8, p.M - 1); \
-            glds16(baseA + (g0_ * lda2 + koff_), dst_);                                                 \
-            glds16(baseA + (g1_ * lda2 + koff_), dst_ + 1024);                                          \
-        }                                                                                               \
+        const unsigned dst_ = lds_dma0 + (unsigned)((stage) * STAGE_BYTES + (j) * HALF_BYTES);          \
+        const size_t ks_ = (size_t)(unsigned)(u) * (T_K * 2);  /* wave-uniform: folded into the scalar base */ \
+        if ((j) == 0) GLDS_PAIR(offP0, offP1, baseW + ks_, dst_);                                       \
+        else if ((j) == 3) GLDS_PAIR(offP0, offP1, baseW + ks_ + (size_t)ldw2 * 4, dst_);               \
+        else if ((j) == 1) GLDS_PAIR(offQ00, offQ01, baseA + ks_, dst_);                                \
+        else GLDS_PAIR(offQ10, offQ11, baseA + ks_, dst_);                                              \
     } while (0)
 
-    // ---- fragment read offsets inside a half-tile: tile t of a wave sits 16 rows = 2048 bytes after tile 0 and the swizzle
-    // term (row & 7) does not depend on t, so ONE per-lane offset per operand (plus its ^64 twin for the second k-chunk)
-    // addresses every fragment as base + immediate.  The bases are passed through an opaque asm at every use: left alone,
-    // hipcc materialises ~20 stage/slot variants as loop-invariant VGPRs and spills them into the main loop.
+    // ---- fragment reads: tile t of a wave sits 16 rows = 2048 bytes after tile 0 and the swizzle term (row & 7) does not
+    // depend on t, so one per-lane LDS address per (operand, stage, k-chunk) - 8 VGPRs - addresses every fragment as
+    // base + IMMEDIATE offset.  The reads are inline asm: hipcc otherwise materialises ~20 slot variants of these addresses
+    // as loop-invariant VGPRs (spilled), or re-adds constants in the load segment.  asm results are invisible to the
+    // compiler's waitcnt pass, so every consumer is preceded by WAIT_FRAGS (s_waitcnt lgkmcnt(0) carrying the fragments as
+    // in/out operands, which orders the MFMAs behind it).
     const int frow = lane & 15, fch = lane >> 4;
-    const int a_base = tile_off(64 * wm + frow, fch);
-    const int w_base = tile_off(32 * wn + frow, fch);
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+    const unsigned aB00 = lds0 + (unsigned)tile_off(64 * wm + frow, fch), aB01 = aB00 ^ 64u;   // stage 0, k-chunk 0 / 1
+    const unsigned aB10 = aB00 + STAGE_BYTES, aB11 = aB01 + STAGE_BYTES;                        // stage 1
+    const unsigned wB00 = lds0 + (unsigned)tile_off(32 * wn + frow, fch), wB01 = wB00 ^ 64u;
+    const unsigned wB10 = wB00 + STAGE_BYTES, wB11 = wB01 + STAGE_BYTES;
 
     f32x4 acc[2][4][2][2];  // [hm][mt][hn][nt]
     bf16x8 aF[4][2], w0F[2][2], w1F[2][2];  // [tile][kk]
 
+#define DS_READ128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
 #define LOAD_A(stage, j)                                                                                     \
     do {                                                                                                     \
-        int o0_ = a_base, o1_ = a_base ^ 64;                                                                 \
-        asm volatile("" : "+v"(o0_), "+v"(o1_));                                                             \
-        const char* b_ = smem + (stage) * STAGE_BYTES + (j) * HALF_BYTES;                                    \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                      \
-            aF[t][0] = *(const bf16x8*)(b_ + o0_ + 2048 * t);                                                \
-            aF[t][1] = *(const bf16x8*)(b_ + o1_ + 2048 * t);                                                \
+            DS_READ128(aF[t][0], (stage) ? aB10 : aB00, (j) * HALF_BYTES + 2048 * t);                        \
+            DS_READ128(aF[t][1], (stage) ? aB11 : aB01, (j) * HALF_BYTES + 2048 * t);                        \
         }                                                                                                    \
     } while (0)
 #define LOAD_W(dstF, stage, j)                                                                               \
     do {                                                                                                     \
-        int o0_ = w_base, o1_ = w_base ^ 64;                                                                 \
-        asm volatile("" : "+v"(o0_), "+v"(o1_));                                                             \
-        const char* b_ = smem + (stage) * STAGE_BYTES + (j) * HALF_BYTES;                                    \
         _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                      \
-            dstF[t][0] = *(const bf16x8*)(b_ + o0_ + 2048 * t);                                              \
-            dstF[t][1] = *(const bf16x8*)(b_ + o1_ + 2048 * t);                                              \
+            DS_READ128(dstF[t][0], (stage) ? wB10 : wB00, (j) * HALF_BYTES + 2048 * t);                      \
+            DS_READ128(dstF[t][1], (stage) ? wB11 : wB01, (j) * HALF_BYTES + 2048 * t);                      \
         }                                                                                                    \
     } while (0)
+#define WAIT_FRAGS_A()                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aF[0][0]), "+v"(aF[0][1]), "+v"(aF[1][0]), "+v"(aF[1][1]),     \
+                 "+v"(aF[2][0]), "+v"(aF[2][1]), "+v"(aF[3][0]), "+v"(aF[3][1]))
+#define WAIT_FRAGS_W(wF) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wF[0][0]), "+v"(wF[0][1]), "+v"(wF[1][0]), "+v"(wF[1][1]))
 #define MMA(hm, hn, wF)                                                                                      \
     do {                                                                                                     \
         __builtin_amdgcn_s_setprio(1);                                                                       \
@@ -176,6 +176,9 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         }                                                                                                    \
         CLIBD_WAIT_VMCNT(WAITN);                                                                             \
         BARRIER();                                                                                           \
+        if (dl_ == 0) { WAIT_FRAGS_W(w0F); WAIT_FRAGS_A(); }                                                 \
+        else if (dl_ == 1) { WAIT_FRAGS_W(w1F); }                                                            \
+        else if (dl_ == 2) { WAIT_FRAGS_A(); }                                                               \
         if (dl_ == 0) MMA(0, 0, w0F);                                                                        \
         else if (dl_ == 1) MMA(0, 1, w1F);                                                                   \
         else if (dl_ == 2) MMA(1, 1, w1F);                                                                   \
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         BARRIER();                                                                                           \
     } while (0)
 
-    // wait at the end of a load segment in the first four phases of a tile (and before its phase 0): the previous
+    // wait at the end of a load segment in the first six phases of a tile (and before its phase 0): the previous
     // epilogue's stores sit between the prologue LDS-DMA and this tile's later issues in the in-order vmcnt queue
 #define WAIT_HEAD()                                         \
     do {                                                    \
@@ -200,13 +203,16 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         if (dl_ == 0) { LOAD_W(w0F, st_, 1); LOAD_A(st_, 0); }                                               \
         else if (dl_ == 1) { LOAD_W(w1F, st_, 2); }                                                          \
         else if (dl_ == 2) { LOAD_A(st_, 3); }                                                               \
-        {                                                                                                    \
+        if ((Q8) >= 2) { /* L_6, L_7 belong to the prologue: all 8 slots are free at a tile boundary */      \
             constexpr int ju_ = ((Q8) + 2) & 3;                                                              \
             constexpr int du_ = ((Q8) + 6) >> 2;                                                             \
             ISSUE(du_, ju_, du_ & 1);                                                                        \
         }                                                                                                    \
         WAIT_HEAD();                                                                                         \
         BARRIER();                                                                                           \
+        if (dl_ == 0) { WAIT_FRAGS_W(w0F); WAIT_FRAGS_A(); }                                                 \
+        else if (dl_ == 1) { WAIT_FRAGS_W(w1F); }                                                            \
+        else if (dl_ == 2) { WAIT_FRAGS_A(); }                                                               \
         if (dl_ == 0) MMA(0, 0, w0F);                                                                        \
         else if (dl_ == 1) MMA(0, 1, w1F);                                                                   \
         else if (dl_ == 2) MMA(1, 1, w1F);                                                                   \
@@ -222,9 +228,11 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         ISSUE(0, 3, 0); __builtin_amdgcn_sched_barrier(0);                   \
         ISSUE(1, 0, 1); __builtin_amdgcn_sched_barrier(0);                   \
         ISSUE(1, 1, 1); __builtin_amdgcn_sched_barrier(0);                   \
+        ISSUE(1, 2, 1); __builtin_amdgcn_sched_barrier(0);                   \
+        ISSUE(1, 3, 1); __builtin_amdgcn_sched_barrier(0);                   \
     } while (0)
 
-    // ---- start-up skew (see header) and the first tile's prologue: L_0 .. L_5 = K-tile 0 + P_hm0, Q_hn0 of K-tile 1
+    // ---- optional start-up skew (diagnostic knob) and the first tile's prologue: L_0 .. L_7 = K-tiles 0 and 1
     if (skew_ticks > 0) {
         const int cls = (blockIdx.x >> 3) & 3;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -265,8 +273,9 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         int kt = 0;  // nk >= 4 (host-checked): the head phases always run and consume the literal-zero accumulators
         PHASE_HEAD(0); PHASE_HEAD(1); PHASE_HEAD(2); PHASE_HEAD(3);
         STAMP(1);
-        // from phase 4 on the awaited half-tile (L_6 ...) was issued AFTER the stores: in-order vmcnt => plain vmcnt(8)
-        PHASE(4, true, 8); PHASE(5, true, 8); PHASE(6, true, 8); PHASE(7, true, 8);
+        PHASE_HEAD(4); PHASE_HEAD(5);
+        // from phase 6 on the awaited half-tile (L_8 ...) was issued AFTER the stores: in-order vmcnt => plain vmcnt(8)
+        PHASE(6, true, 8); PHASE(7, true, 8);
         STAMP(2);
         for (kt = 2; kt < nk - 2; kt += 2) {
             PHASE(0, true, 8); PHASE(1, true, 8); PHASE(2, true, 8); PHASE(3, true, 8);
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         PHASE(4, false, 2); PHASE(5, false, 0); PHASE(6, false, 0); PHASE(7, false, 0);
         if (wm == 0) BARRIER();  // group 0 matches group 1's extra barrier; every LDS read of this tile is complete
         STAMP(4);
-        if (has_next) PROLOGUE_ISSUE();  // next tile's first six half-tiles fly while this tile's epilogue runs
+        if (has_next) PROLOGUE_ISSUE();  // next tile's first eight half-tiles fly while this tile's epilogue runs
 
         // lane coordinates made opaque per tile: everything the epilogue derives from them (16 row offsets x several
         // leading dimensions) is rebuilt here instead of being hoisted out of the persistent loop into spilled registers
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
             const int nb = n0 + 128 * wm + 8 * erow;  // < N: N % 256 == 0 (host-checked)
             const int mb = m0 + 64 * wn + 4 * egrp;
             float bias[8];
-            load_bias8(ep, nb, bias);
+            if (BIAS) load_bias8(ep, nb, bias);  // compile-time: without a bias the 128 adds (and the moves pairing them) vanish
 #define FOR_ROWS(...)                                                                                        \
     _Pragma("unroll") for (int hn = 0; hn < 2; ++hn)                                                         \
         _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                        \
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     const int mc = min(m, p.M - 1);
                     float v[8];
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
-                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r] + bias[4 * hm + t];
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = BIAS ? acc[hm][t][hn][n][r] + bias[4 * hm + t] : acc[hm][t][hn][n][r];
                     fold_row8<KIND>(ep, mc, nb, v);
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
                         _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[hm][t][hn][n][r] = v[4 * hm + t];
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     if (m < p.M) {
                         float v[8];
                         _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
-                            _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r] + bias[4 * hm + t];
+                            _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = BIAS ? acc[hm][t][hn][n][r] + bias[4 * hm + t] : acc[hm][t][hn][n][r];
                         store_row8<KIND>(ep, m, nb, v);
                     }
                 })
@@ -392,10 +401,13 @@ static int skew_env_value() {
     return v;
 }
 
-static const void* kernel_ptr(int kind, bool lora, bool diag) {
-#define K256(KIND)                                                                 \
-    (diag ? (const void*)gemm256_bf16_nt_kernel<KIND, false, true>                 \
-          : lora ? (const void*)gemm256_bf16_nt_kernel<KIND, true, false> : (const void*)gemm256_bf16_nt_kernel<KIND, false, false>)
+static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
+#define K256(KIND)                                                                                                    \
+    (diag ? (const void*)gemm256_bf16_nt_kernel<KIND, false, true, true>                                              \
+          : lora ? (bias ? (const void*)gemm256_bf16_nt_kernel<KIND, true, true, false>                               \
+                         : (const void*)gemm256_bf16_nt_kernel<KIND, true, false, false>)                             \
+                 : (bias ? (const void*)gemm256_bf16_nt_kernel<KIND, false, true, false>                              \
+                         : (const void*)gemm256_bf16_nt_kernel<KIND, false, false, false>))
     switch (kind) {
         case EPI_BF16: return K256(EPI_BF16);
         case EPI_GELU_SAVE: return K256(EPI_GELU_SAVE);
@@ -417,9 +429,10 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     if ((unsigned long long)p.M * p.lda * 2ull >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2ull >= (1ull << 32)) return false;  // too few 256x256 tiles to fill 256 CUs: the 128x128 kernel wins
     static const bool attr_ok = [] {
         bool ok = true;
-        for (int v = 0; v < 3; ++v)
+        for (int v = 0; v < 5; ++v)
             for (int k = 0; k < EPI_NUM_KINDS; ++k)
-                ok = ok && hipFuncSetAttribute(kernel_ptr(k, v == 1, v == 2), hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+                ok = ok && hipFuncSetAttribute(kernel_ptr(k, (v & 1) != 0, (v & 2) != 0, v == 4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               G256_LDS) == hipSuccess;
         return ok;
     }();
     if (!attr_ok) return false;
@@ -444,7 +457,7 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     const bool lora = p.ep.rank_u != nullptr;
     const bool diag = g_stamp_buffer != nullptr && !lora;
     void* args[] = {(void*)&q, (void*)&ntiles_i, (void*)&skew_arg, (void*)&stamp_arg};
-    if (hipLaunchKernel(kernel_ptr(kind, lora, diag), dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) != hipSuccess) return false;
+    if (hipLaunchKernel(kernel_ptr(kind, lora, p.ep.bias != nullptr, diag), dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) != hipSuccess) return false;
     return true;
 }
 
