@@ -323,6 +323,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     for (int n = 0; n < 4; ++n)
                         acc[hm][t][n >> 1][n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[n >> 1][n & 1], vf, acc[hm][t][n >> 1][n & 1], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);  // keep the epilogue's aux / residual loads below the rank-update operands
         }
 
         // ---- epilogue: lane (c = frow, g = fch) owns rows m0 + 64wn + 32hn + 16n + 4g + r, columns nb .. nb+7 (e = 4hm + t)

@@ -487,6 +487,70 @@ def test_gemm_gelu_save_grad_and_mul_aux(ops, dev):
     assert rel_err(out.cpu(), (bfr(a) @ bfr(w).T) * aux) < 1e-5
 
 
+@pytest.mark.parametrize("K", [256, 768])
+@pytest.mark.parametrize("kind,bias,lora", [("bf16", False, False), ("bf16", True, True), ("bf16", False, True), ("gelu_save", True, False),
+                                            ("gelu_save", False, False), ("mul_aux", False, False), ("res_f32", True, False),
+                                            ("res_f32", False, True), ("res_f32_drop", True, False), ("generic_two_outputs", True, False)])
+def test_gemm256_epilogue_kinds(ops, dev, kind, bias, lora, K):
+    """Every specialised epilogue instantiation of the 256x256 kernel (kind x bias x rank-8 update) on a ragged M (last
+    m-tile has 5 live rows), against a torch fp32 reference with the kernel's rounding points; rows past M stay untouched."""
+    from oracle import clibd_oracle as O
+
+    M, N = 11 * 256 + 5, 3072
+    g = torch.Generator().manual_seed(1000 + K)
+    a = (torch.randn(M, K, generator=g)).to(dev, BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev, BF16)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    u = torch.randn(M, 8, generator=g).to(dev, BF16) if lora else None
+    v = (torch.randn(N, 8, generator=g) * 0.1).to(dev, BF16) if lora else None
+    ref = a.float() @ w.float().T
+    if lora:
+        ref = ref + u.float() @ v.float().T
+    if bias:
+        ref = ref + b
+    GUARD = 3  # sentinel rows behind the live ones
+    def buf(dt):
+        t = torch.full((M + GUARD, N), 7.0, dtype=dt, device=dev)
+        return t, t[:M]
+    kw = dict(bias=b, rank_u=u, rank_v=v)
+    checks = []
+    if kind == "bf16":
+        full, out = buf(BF16)
+        ops.gemm_nt(a, w, out_bf16=out, **kw)
+        checks.append((full, ref, 4e-3))
+    elif kind == "gelu_save":
+        fa, act = buf(BF16)
+        fg, dg = buf(BF16)
+        ops.gemm_nt(a, w, act=ops.ACT_GELU_SAVE_GRAD, out_pre=dg, out_bf16=act, **kw)
+        pre = ref.to(BF16).float()
+        checks += [(fa, torch.nn.functional.gelu(pre), 5e-3), (fg, gelu_grad(pre.cpu()).to(dev), 5e-3)]
+    elif kind == "mul_aux":
+        aux = torch.randn(M, N, generator=g).to(dev, BF16)
+        full, out = buf(BF16)
+        ops.gemm_nt(a, w, act=ops.ACT_MUL_AUX, aux=aux, out_bf16=out, **kw)
+        checks.append((full, ref * aux.float(), 4e-3))
+    elif kind in ("res_f32", "res_f32_drop"):
+        res = torch.randn(M, N, generator=g).to(dev)
+        full, out = buf(F32)
+        if kind == "res_f32_drop":
+            seed, pdrop = 0x1234567, 0.1
+            ops.gemm_nt(a, w, residual=res, out_f32=out, drop=ops.Drop(pdrop, seed), **kw)
+            idx = (torch.arange(M, dtype=torch.int64)[:, None] * N + torch.arange(N, dtype=torch.int64)[None, :])
+            ref = ref * O.drop_factor(seed, idx, pdrop).to(dev)
+        else:
+            ops.gemm_nt(a, w, residual=res, out_f32=out, **kw)
+        checks.append((full, ref + res, 2e-5))
+    else:
+        f1, o32 = buf(F32)
+        f2, o16 = buf(BF16)
+        ops.gemm_nt(a, w, out_f32=o32, out_bf16=o16, **kw)
+        checks += [(f1, ref, 2e-5), (f2, ref, 4e-3)]
+    torch.cuda.synchronize()
+    for full, r, tol in checks:
+        assert rel_err(full[:M].float().cpu(), r.cpu()) < tol
+        assert bool((full[M:].float() == 7.0).all()), "rows past M were written"
+
+
 @pytest.mark.parametrize("B,S,nh,nq", [(3, 197, 2, 1), (2, 133, 1, 20), (2, 64, 1, 17)])
 def test_attention_query_prefix(ops, dev, B, S, nh, nq):
     """nq < S: only the first nq queries are evaluated; backward with dO given for those rows only."""
