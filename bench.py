@@ -50,7 +50,7 @@ class GemmTimer:
     """HIP-event brackets around every GEMM launch (same stream as the launch) + algorithmic FLOPs."""
 
     def __init__(self):
-        self.events, self.flops, self.enabled, self.shapes = [], 0.0, False, []
+        self.events, self.flops, self.enabled, self.shapes, self.bytes = [], 0.0, False, [], 0.0
 
     def install(self):
         from clibd_amd import ops
@@ -67,6 +67,8 @@ class GemmTimer:
             e1.record()
             timer.events.append((e0, e1))
             timer.flops += 2.0 * a.shape[0] * w.shape[0] * a.shape[1]
+            per_out = sum(b_ for k_, b_ in (("out_bf16", 2), ("out_pre", 2), ("out_f32", 4), ("residual", 4), ("aux", 2)) if kw.get(k_) is not None)
+            timer.bytes += 2.0 * a.shape[1] * (a.shape[0] + w.shape[0]) + float(per_out) * a.shape[0] * w.shape[0]
             timer.shapes.append((a.shape[0], w.shape[0], a.shape[1], "+".join(sorted(k for k, v in kw.items() if v is not None))))
 
         ops.gemm_nt = timed
@@ -79,7 +81,8 @@ class GemmTimer:
         if not self.events:
             return None
         ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events)
-        return {"launches": len(self.events), "total_ms": ms, "tflops": self.flops / (ms * 1e-3) / 1e12}
+        return {"launches": len(self.events), "total_ms": ms, "tflops": self.flops / (ms * 1e-3) / 1e12,
+                "bytes_per_launch": self.bytes / len(self.events)}
 
     def breakdown(self, steps):
         agg = {}
@@ -90,6 +93,25 @@ class GemmTimer:
         for (M, N, K, kinds), (n, t) in rows:
             print(f"[gemm] M={M:6d} N={N:5d} K={K:5d} x{n // steps:3d}/step {t / steps:7.3f} ms/step {t / n * 1e3:7.1f} us each "
                   f"{2.0 * M * N * K * n / (t * 1e-3) / 1e12:7.1f} TF  {kinds}", file=sys.stderr, flush=True)
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic*.json,
+    written by tools/pmc_traffic.py; PMC counters cannot be collected from inside this process)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic*.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        kernels = json.load(fh)["kernels"]
+    n = b = 0.0
+    for name, d in kernels.items():
+        if "gemm256" in name:
+            launches = max(d["launches_fetch_pass"], 1)
+            n += launches
+            b += launches * d["hbm_bytes_per_launch"]
+    return (b / n if n else None), os.path.basename(files[-1])
 
 
 def cpu_baseline(batch: int):
@@ -189,7 +211,7 @@ def main():
     overlap_on = bool(getattr(model, "overlap_towers", False)) and (model.image_encoder is not None) and (model.dna_encoder is not None)
     serial = None
     if overlapped and overlap_on:
-        timer.events, timer.flops, timer.shapes = [], 0.0, []
+        timer.events, timer.flops, timer.shapes, timer.bytes = [], 0.0, [], 0.0
         model.overlap_towers = False
         serial_steps = min(args.steps, 5)
         one_step()
@@ -217,10 +239,15 @@ def main():
                         "timed_region = the same quantity inside the timed region, where the towers overlap on two streams and a "
                         "launch's duration includes CU sharing; step_frac = pairs/s x 117.6 GF / (n_gpus x peak), the whole step "
                         "against the MFMA roof"}
+        traffic, traffic_src = pmc_traffic()
+        if traffic is not None:
+            roof["traffic"] = traffic
+            roof["traffic_source"] = f"profiles/{traffic_src}: mean HBM bytes per gemm256 launch (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate --pmc passes)"
         if gemm:
             gsteps = serial["steps"] if serial is not None else args.steps
             roof.update(achieved=gemm["tflops"], frac=gemm["tflops"] / PEAK_BF16_TFLOPS, launches=gemm["launches"],
-                        gemm_ms_per_step=gemm["total_ms"] / gsteps, avg_launch_us=gemm["total_ms"] / gemm["launches"] * 1e3)
+                        gemm_ms_per_step=gemm["total_ms"] / gsteps, avg_launch_us=gemm["total_ms"] / gemm["launches"] * 1e3,
+                        algorithmic_bytes_per_launch=gemm["bytes_per_launch"])
             if serial is not None:
                 roof["timed_region"] = {"achieved": overlapped["tflops"], "gemm_ms_per_step": overlapped["total_ms"] / args.steps,
                                         "avg_launch_us": overlapped["total_ms"] / overlapped["launches"] * 1e3, "streams": 2}
