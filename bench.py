@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-gemm-timing", action="store_true")
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
+    ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
     return ap.parse_args()
 
 
@@ -171,6 +172,9 @@ def main():
             if enc is not None:
                 for wb in enc.w_Bs:
                     wb.weight.normal_(0, 0.02)
+    if args.full_finetune:
+        for p_ in model.parameters():
+            p_.requires_grad_(True)
     trainer = Trainer(model, lr=scale_learning_rate(1e-3, b, world_size=world), world_size=world, rank=rank, all_gather=True)
     batch = synthetic_batch(b, dev, seed=42, rank=rank, with_text=args.tri_modal)
 
@@ -256,7 +260,8 @@ def main():
             "value": pairs_per_s, "unit": "paired samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights)",
-            "config": {"workload": "Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) LoRA r=4, bf16 MFMA" +
+            "config": {"workload": "Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
+                                   ("FULL fine-tune (disable_lora)" if args.full_finetune else "LoRA r=4") + ", bf16 MFMA" +
                                    (" + BERT-small text tower" if args.tri_modal else ""),
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}", "image": "3x224x224", "dna_tokens": 133,
                        "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW"},

@@ -21,7 +21,7 @@ INCLUDE = HERE.parent / "include"
 LIB = HERE / "libclibd_hip.so"
 OBJ = CSRC / "build"
 ARCH = "gfx950"
-SOURCES = ["capi", "gemm", "gemm256", "layernorm", "attention", "lora", "elementwise", "loss", "topk"]
+SOURCES = ["capi", "gemm", "gemm256", "layernorm", "attention", "lora", "elementwise", "loss", "topk", "paramgrad"]
 
 
 def _hipcc() -> str:

@@ -328,11 +328,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
-static inline unsigned grid_for(size_t n, int per_block = 256, unsigned cap = 4096) {
-    size_t b = (n + per_block - 1) / per_block;
-    if (b > cap) b = cap;
-    return b < 1 ? 1u : (unsigned)b;
-}
 
 }  // namespace clibd
 

@@ -448,7 +448,9 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.tiles_m = (p.M + T_M - 1) / T_M;
     q.tiles_n = p.N / T_N;
-    const int grid = (int)(tiles < num_cus ? tiles : num_cus);
+    static const int grid_cap = [] { const char* e = getenv("CLIBD_GEMM_GRID"); return e ? atoi(e) : 0; }();  // experiment knob
+    const int cus = (grid_cap > 0 && grid_cap < num_cus) ? grid_cap : num_cus;
+    const int grid = (int)(tiles < cus ? tiles : cus);
     const int kind = epilogue_kind(p.ep);
     int ntiles_i = (int)tiles;
     int skew_arg = skew_env_value();

@@ -27,4 +27,11 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
+// grid size for a grid-stride elementwise kernel: ceil(n / per_block), capped
+inline unsigned grid_for(size_t n, int per_block = 256, unsigned cap = 4096) {
+    size_t b = (n + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    return b < 1 ? 1u : (unsigned)b;
+}
+
 }  // namespace clibd

@@ -94,17 +94,17 @@ class TransformerStack:
                 k += p._version + (p.data_ptr() & 0xFFFF)
         return (k, self.layers[0].proj_w.device)
 
-    def check_frozen(self):
-        for L in self.layers:
-            for p in L.frozen():
-                if p.requires_grad:
-                    raise NotSupportedYet(
-                        "base (non-LoRA) encoder weights require grad: full fine-tuning (disable_lora) is not implemented "
-                        "on the HIP path yet (SURVEY §8f-4); freeze the base weights")
+    def full_mode(self) -> bool:
+        """True when any base (non-adapter) weight of the stack is trainable: model_config.disable_lora.
+        The forward then keeps the extra GEMM inputs the weight gradients need and the backward runs down to layer 0."""
+        return any(p.requires_grad for L in self.layers for p in L.frozen())
+
+    def base_params(self):
+        return [p for L in self.layers for p in L.frozen()]
 
     def refresh(self):
         key = self._key()
-        if key == self._cache_key:
+        if key == self._cache_key and not self.full_mode():  # the fused optimizer updates weights in place (no version bump)
             return
         self._cache = []
         with torch.no_grad():
@@ -142,24 +142,30 @@ class TransformerStack:
         return self._cache[i].a_cat
 
     # ---- forward ------------------------------------------------------------------------------------------------
-    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool, cls_only_last: bool = False, drop=None):
+    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool, cls_only_last: bool = False, drop=None, full: bool = False):
         """x_f32 [M,H] residual stream entering layer 0.  Post-LN stacks also pass its bf16 image and the layer-0
         adapter down-projection t0 (both produced by the embedding LayerNorm).  Returns (x_f32, x_bf16, saved).
         cls_only_last (pre-LN only): the caller consumes token 0 only, so the LAST block evaluates attention for that
         query, and projection + MLP for that row, per sequence — the returned x_f32 is then [B,H] (the other rows of
         the last block are dead code the reference computes and discards).
-        drop (post-LN only): (p_hidden, p_attention, base_seed) — HF BERT train-mode dropout; site seeds via ops.derive_seed."""
+        drop (post-LN only): (p_hidden, p_attention, base_seed) — HF BERT train-mode dropout; site seeds via ops.derive_seed.
+        full: full fine-tune mode — every layer keeps its own attention output, MLP input and GELU output (the X operands of
+        the weight gradients) instead of sharing temporaries."""
         H, FF, M = self.H, self.FF, B * S
         dev = x_f32.device
         saved = []
         new = lambda cols, dt: torch.empty((M, cols), dtype=dt, device=dev)
-        o = new(H, BF16)          # attention output (temporary, reused by every layer)
-        a = new(FF, BF16)         # post-GELU activation (temporary)
-        xn2 = new(H, BF16) if self.pre_ln else None
+        keep = save and full
+        o = None if keep else new(H, BF16)          # attention output (temporary, reused by every layer)
+        a = None if keep else new(FF, BF16)         # post-GELU activation (temporary)
+        xn2 = new(H, BF16) if (self.pre_ln and not keep) else None
         t = t0
         for i, (L, c) in enumerate(zip(self.layers, self._cache)):
             has_lora = L.lora is not None
             rec = {}
+            if keep:
+                o, a = new(H, BF16), new(FF, BF16)
+                xn2 = new(H, BF16) if self.pre_ln else None
             if self.pre_ln and cls_only_last and i == len(self.layers) - 1:
                 xn = new(H, BF16)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
@@ -183,6 +189,8 @@ class TransformerStack:
                 ops.gemm_nt(ac, c.w2, bias=c.b2, residual=x1, out_f32=x2)
                 if save:
                     rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h, cls_only=True)
+                    if keep:
+                        rec.update(o=o_cls, xn2=xn2c, a=ac)
                 x_f32 = x2
             elif self.pre_ln:
                 # xn = LN1(x) (+ t = xn·A^T);  qkv = xn Wqkv^T + b + t·B^T
@@ -203,6 +211,8 @@ class TransformerStack:
                 ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1, out_f32=x2)
                 if save:
                     rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h)
+                    if keep:
+                        rec.update(o=o, xn2=xn2, a=a)
                 x_f32 = x2
             else:
                 d_att = d_h1 = d_h2 = None
@@ -232,14 +242,18 @@ class TransformerStack:
                 if save:
                     rec = dict(x_bf16=x_bf16, t=t if has_lora else None, qkv=qkv, s1=s1, st1=st1, h=h, s2=s2, st2=st2,
                                d_att=d_att, d_h1=d_h1, d_h2=d_h2)
+                    if keep:
+                        rec.update(o=o, x1_bf16=x1_bf16, a=a)
                 x_f32, x_bf16, t = x2_f32, x2_bf16, t_next
             saved.append(rec)
         return x_f32, x_bf16, saved
 
     # ---- backward -----------------------------------------------------------------------------------------------
-    def backward(self, dx_f32, dx_bf16, saved, B: int, S: int, key_mask, grads: dict):
+    def backward(self, dx_f32, dx_bf16, saved, B: int, S: int, key_mask, grads: dict, full: bool = False):
         """dx = gradient w.r.t. the stack output (fp32 residual stream; pre-LN also needs its bf16 image).
-        Fills grads[id(param)] for the adapters.  The input embeddings are frozen, so nothing is returned."""
+        Fills grads[id(param)] for the adapters — and, in full fine-tune mode, for every base weight / bias / LayerNorm
+        parameter present in `grads`; returns the fp32 gradient w.r.t. the stack input then (None in LoRA mode, where the
+        walk stops at the lowest adapted layer because nothing below it is trainable)."""
         H, FF, M = self.H, self.FF, B * S
         dev = dx_f32.device
         new = lambda cols, dt: torch.empty((M, cols), dtype=dt, device=dev)
@@ -248,6 +262,11 @@ class TransformerStack:
         dqkv = new(3 * H, BF16)
         dt = torch.empty((M, 16), dtype=BF16, device=dev)
         first_lora = min((i for i, L in enumerate(self.layers) if L.lora is not None), default=len(self.layers))
+        if full:
+            first_lora = -1  # every layer has trainable parameters and the input gradient is needed
+        lng = lambda dy, x, st, w, b, drop=None: (ops.layernorm_param_grads(dy, x, st, grads[id(w)], grads[id(b)], drop=drop)
+                                                  if full and id(w) in grads else None)
+        wg = lambda dy, x, ws, bs: linear_wgrad(dy, x, ws, bs, grads) if full else None
         for i in range(len(self.layers) - 1, -1, -1):
             L, c, rec = self.layers[i], self._cache[i], saved[i]
             has_lora = L.lora is not None
@@ -257,57 +276,108 @@ class TransformerStack:
                 # dx_f32 / dx_bf16 are [B,H]: the gradient of the class-token row of this block's output
                 newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
                 dhc, dtc = newB(FF, BF16), newB(H, BF16)
+                wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dhc)
+                wg(dhc, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                 ops.gemm_nt(dhc, c.w1_t, out_bf16=dtc)
+                lng(dtc, rec["x1"], rec["st2"], L.ln2_w, L.ln2_b)
                 dx1_f32, dx1_bf16 = newB(H, F32), newB(H, BF16)
                 ops.layernorm_bwd(dtc, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16)
+                wg(dx1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtc)                                              # d(attn out), class rows
                 ops.attention_bwd(rec["qkv"], dtc, B, S, self.heads, key_mask, dqkv, nq=1)
                 if has_lora:
                     self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads)
+                wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
+                    lng(dtmp, rec["x_in"], rec["st1"], L.ln1_w, L.ln1_b)
                     _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)            # residual path: class rows only
                     ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
                     ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16)
                     dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif self.pre_ln:
+                wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)          # d(fc1 out)
+                wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                 ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
+                lng(dtmp, rec["x1"], rec["st2"], L.ln2_w, L.ln2_b)
                 dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16)
+                wg(dx1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtmp)                                             # d(attn out)
                 ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv)
                 if has_lora:
                     self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads)
+                wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
+                    lng(dtmp, rec["x_in"], rec["st1"], L.ln1_w, L.ln1_b)
                     ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
                     ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16)
                     dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             else:
+                lng(dx_f32, rec["s2"], rec["st2"], L.ln2_w, L.ln2_b)
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"])
+                wg(ds2_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 ops.gemm_nt(ds2_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)
+                wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                 dx1 = new(H, F32)
                 ops.gemm_nt(dh, c.w1_t, residual=ds2_f32, out_f32=dx1)
+                lng(dx1, rec["s1"], rec["st1"], L.ln1_w, L.ln1_b)
                 ds1_f32, ds1_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dx1, rec["s1"], rec["st1"], c.g1, dx_f32=ds1_f32, dx_bf16=ds1_bf16, drop=rec["d_h1"])
+                wg(ds1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(ds1_bf16, c.wo_t, out_bf16=dtmp)
                 ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv, drop=rec["d_att"])
                 if has_lora:
                     self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads)
+                wg(dqkv, rec["x_bf16"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ndx = new(H, F32)
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
                                 residual=ds1_f32, out_f32=ndx)
                     dx_f32 = ndx
+        return dx_f32 if full else None
 
     def _lora_grads(self, L, c, dqkv, x_bf16, t, dt, grads):
         H = self.H
         ops.gemm_nt(dqkv, c.w_dt, out_bf16=dt)  # dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v
         lp = L.lora
         ops.lora_wgrad(dqkv, x_bf16, t, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
+
+
+def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], grads: dict):
+    """Weight / bias gradients of y = x W^T + b for the parameters present in `grads` (accumulating):
+    dW [N,K] += dy^T x as the NT GEMM (dy^T [N,Mp]) (x^T [K,Mp])^T with the contraction over the (zero-padded) token rows,
+    db += column sums of dy.  `weights` may be the row-wise pieces of a fused projection (BERT query / key / value)."""
+    if not any(id(w) in grads for w in weights) and not any(id(b) in grads for b in biases):
+        return
+    if x_bf16 is None:
+        raise RuntimeError("full fine-tune backward needs the layer's GEMM input (forward ran without full=True)")
+    M = dy_bf16.shape[0]
+    if any(id(w) in grads for w in weights):
+        dyT = ops.transpose_bf16(dy_bf16, pad_to=128)   # [N, Mp]
+        xT = ops.transpose_bf16(x_bf16, pad_to=128)     # [K, Mp]
+        Mp = dyT.shape[1]
+        split = max(1, min(32, Mp // 2048))
+        n0 = 0
+        for w in weights:
+            n1 = n0 + w.shape[0]
+            if id(w) in grads:
+                gw = grads[id(w)].view(w.shape[0], -1)
+                if split > 1:
+                    ops.gemm_nt(dyT[n0:n1], xT, out_f32=gw, split_k=split)
+                else:
+                    ops.gemm_nt(dyT[n0:n1], xT, out_f32=gw, residual=gw)
+            n0 = n1
+    n0 = 0
+    for w, b in zip(weights, biases):
+        n1 = n0 + w.shape[0]
+        if b is not None and id(b) in grads:
+            ops.colsum_bf16(dy_bf16[:, n0:n1], grads[id(b)])
+        n0 = n1
 
 
 class GradBucket:

@@ -166,7 +166,7 @@ def load_clip_model(args, device=None):
         model.to(device)
     if disable_lora:
         for p in model.parameters():
-            p.requires_grad = True  # full fine-tune: the HIP towers raise NotSupportedYet at the first training step
+            p.requires_grad = True  # full fine-tune (simple_clip.py:235-237): the towers switch to their weight-gradient paths
     for cfg, enc in ((image_cfg, model.image_encoder), (dna_cfg, model.dna_encoder), (lang_cfg, model.language_encoder)):
         if cfg is not None and _get(cfg, "freeze", False) and enc is not None:
             for p in enc.parameters():

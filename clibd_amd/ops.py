@@ -465,3 +465,64 @@ def kmer_tokenize(seq_u8: torch.Tensor, k: int = 5) -> torch.Tensor:
     out = torch.empty((B, 1 + L // k), dtype=I64, device=seq_u8.device)
     check(_lib.load().clibd_kmer_tokenize(seq_u8.data_ptr(), B, L, k, out.data_ptr(), _stream()), "kmer_tokenize")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ full fine-tune mode (f4)
+def layernorm_param_grads(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
+                          drop: Optional[Drop] = None) -> None:
+    """dgamma += sum_m dy*xhat, dbeta += sum_m dy  (dy [M,H] bf16 or fp32; x fp32 [M,H]; stats fp32 [M,2])."""
+    if dy.dtype not in (BF16, F32):
+        raise TypeError("dy: expected bf16 or fp32")
+    _chk(dy, dy.dtype, "dy", contiguous=False)
+    _chk(x, F32, "x"); _chk(stats, F32, "stats"); _chk(dgamma, F32, "dgamma"); _chk(dbeta, F32, "dbeta")
+    M, H = x.shape
+    if tuple(dy.shape) != (M, H) or stats.numel() != 2 * M or dgamma.numel() != H or dbeta.numel() != H:
+        raise ValueError("layernorm_param_grads: shape mismatch")
+    d = drop if drop is not None else Drop(0.0, 0)
+    check(_lib.load().clibd_layernorm_param_grads(dy.data_ptr(), int(dy.dtype == F32), _rowmajor(dy, "dy"), x.data_ptr(), stats.data_ptr(), M, H,
+                                                  dgamma.data_ptr(), dbeta.data_ptr(), d.seed, d.thr16, d.scale, _stream()), "layernorm_param_grads")
+
+
+def batch_sum(x: torch.Tensor, out: torch.Tensor) -> None:
+    """out[...] += x.sum(0)   (x fp32 [B, ...], out fp32 with x.shape[1:] elements)."""
+    _chk(x, F32, "x"); _chk(out, F32, "out")
+    B = x.shape[0]
+    R = x.numel() // B
+    if out.numel() != R:
+        raise ValueError("batch_sum: out must have x.numel() / B elements")
+    check(_lib.load().clibd_batch_sum_f32(x.data_ptr(), B, R, out.data_ptr(), _stream()), "batch_sum")
+
+
+def bert_embed_bwd(ids: torch.Tensor, token_type: Optional[torch.Tensor], de: torch.Tensor, dword: Optional[torch.Tensor],
+                   dtype_table: Optional[torch.Tensor]) -> None:
+    """Scatter the embedding gradient de [M,H] into the word table (by ids) and the token-type table (accumulating)."""
+    _chk(ids, torch.int64, "ids"); _chk(de, F32, "de")
+    M, H = de.shape
+    if ids.numel() != M:
+        raise ValueError("bert_embed_bwd: ids / de mismatch")
+    if token_type is not None:
+        _chk(token_type, torch.int64, "token_type")
+    vocab = dword.shape[0] if dword is not None else 1
+    tv = dtype_table.shape[0] if dtype_table is not None else 1
+    for t, n in ((dword, "dword"), (dtype_table, "dtype")):
+        if t is not None:
+            _chk(t, F32, n)
+    check(_lib.load().clibd_bert_embed_bwd(ids.data_ptr(), _p(token_type), de.data_ptr(), M, H, vocab, tv, _p(dword), _p(dtype_table), _stream()),
+          "bert_embed_bwd")
+
+
+def slice_rows_cast_bf16(x: torch.Tensor, s0: int, s1: int) -> torch.Tensor:
+    """x fp32 [B,S,H] -> bf16 [B*(s1-s0), H]: rows s0..s1-1 of every sequence."""
+    _chk(x, F32, "x")
+    B, S, H = x.shape
+    out = torch.empty((B * (s1 - s0), H), dtype=BF16, device=x.device)
+    check(_lib.load().clibd_slice_rows_cast_bf16(x.data_ptr(), B, S, H, s0, s1, out.data_ptr(), _stream()), "slice_rows_cast_bf16")
+    return out
+
+
+def dropout_apply(x: torch.Tensor, drop: Drop) -> torch.Tensor:
+    """x * dropout_factor(seed, flat element index)  (fp32): the gradient through y = dropout(.)."""
+    _chk(x, F32, "x")
+    y = torch.empty_like(x)
+    check(_lib.load().clibd_dropout_apply_f32(x.data_ptr(), x.numel(), y.data_ptr(), drop.seed, drop.thr16, drop.scale, _stream()), "dropout_apply")
+    return y

@@ -13,7 +13,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .engine import BF16, F32, GradBucket, LayerSpec, LoraParams, NotSupportedYet, TransformerStack, _f32c, dense_head_backward
+from .engine import BF16, F32, GradBucket, LayerSpec, LoraParams, NotSupportedYet, TransformerStack, _f32c, dense_head_backward, linear_wgrad
 
 
 def _trainable(params):
@@ -95,6 +95,8 @@ class ViTTower(_Tower):
         self._patch_key, self._patch_w = None, None
 
     def trainable_params(self):
+        """Every parameter the tower can produce a gradient for (the caller filters by requires_grad): adapters and head
+        always; base weights, embeddings and norms in full fine-tune mode (model_config.disable_lora)."""
         ps = []
         for L in self.stack.layers:
             if L.lora is not None:
@@ -102,29 +104,28 @@ class ViTTower(_Tower):
         head = self.vit.head
         if isinstance(head, torch.nn.Linear):
             ps += [head.weight, head.bias]
-        return ps
+        return ps + self.stack.base_params() + self._frozen_extra()
 
     def _frozen_extra(self):
         v = self.vit
         return [v.patch_embed.proj.weight, v.patch_embed.proj.bias, v.cls_token, v.pos_embed, v.norm.weight, v.norm.bias]
+
+    def _full(self):
+        return self.stack.full_mode() or any(p.requires_grad for p in self._frozen_extra())
 
     def _forward(self, inputs, save):
         (image,) = inputs
         v = self.vit
         if image.dim() != 4 or tuple(image.shape[1:]) != (3, 224, 224):
             raise ValueError("image encoder expects [B,3,224,224]")
-        for p in self._frozen_extra():
-            if p.requires_grad and save:
-                raise NotSupportedYet("patch embedding / position / final norm parameters must be frozen on the HIP path (LoRA mode)")
-        if save:
-            self.stack.check_frozen()
+        full = save and self._full()
         self.stack.refresh()
         self.stack.pack_lora()
         B, S, H = image.shape[0], 197, self.H
         img = image.detach().to(F32).contiguous()
         pw = v.patch_embed.proj.weight
         key = (pw._version, pw.data_ptr())
-        if key != self._patch_key:
+        if key != self._patch_key or pw.requires_grad:  # trainable: the fused optimizer rewrites it in place every step
             self._patch_w = ops.cast_bf16(_f32c(pw).reshape(H, 768))
             self._patch_key = key
         patches = ops.patchify(img)
@@ -132,7 +133,7 @@ class ViTTower(_Tower):
         ops.gemm_nt(patches, self._patch_w, bias=_f32c(v.patch_embed.proj.bias), out_f32=proj)
         tok = ops.vit_assemble_tokens(proj, _f32c(v.cls_token).reshape(H), _f32c(v.pos_embed).reshape(S * H), B)
         # timm pools token 0 (global_pool='token'): only the class row of the last block is live
-        xcls, _, saved = self.stack.forward(tok.view(B * S, H), None, None, B, S, None, save, cls_only_last=True)
+        xcls, _, saved = self.stack.forward(tok.view(B * S, H), None, None, B, S, None, save, cls_only_last=True, full=full)
         x = xcls
         # final norm on the class token only (LayerNorm is per token), then the trainable head
         st = torch.empty((B, 2), dtype=F32, device=x.device)
@@ -145,7 +146,7 @@ class ViTTower(_Tower):
             ops.gemm_nt(xn, ops.cast_bf16(_f32c(head.weight)), bias=_f32c(head.bias), out_f32=out)
         else:
             out = xn.to(F32)
-        state = dict(saved=saved, xcls=xcls, st=st, xn=xn, B=B) if save else None
+        state = dict(saved=saved, xcls=xcls, st=st, xn=xn, B=B, full=full, patches=patches if full else None) if save else None
         return out, state
 
     def _backward(self, dout, state, grads):
@@ -157,8 +158,21 @@ class ViTTower(_Tower):
             dxn = ops.cast_bf16(dout)
         dxcls = torch.empty((B, H), dtype=F32, device=dout.device)
         dxcls_b = torch.empty((B, H), dtype=BF16, device=dout.device)
+        full = state["full"]
+        if full and id(v.norm.weight) in grads:
+            ops.layernorm_param_grads(dxn, state["xcls"], state["st"], grads[id(v.norm.weight)], grads[id(v.norm.bias)])
         ops.layernorm_bwd(dxn, state["xcls"], state["st"], _f32c(v.norm.weight), dx_f32=dxcls, dx_bf16=dxcls_b)
-        self.stack.backward(dxcls, dxcls_b, state["saved"], B, S, None, grads)  # [B,H]: the last block runs class-row-only
+        dtok = self.stack.backward(dxcls, dxcls_b, state["saved"], B, S, None, grads, full=full)  # [B,H]: the last block runs class-row-only
+        if full:
+            # tokens = [cls + pos[0] | patch_proj + pos[1:]]  (timm VisionTransformer._pos_embed)
+            d3 = dtok.view(B, S, H)
+            if id(v.pos_embed) in grads:
+                ops.batch_sum(d3, grads[id(v.pos_embed)])
+            if id(v.cls_token) in grads:
+                ops.batch_sum(ops.gather_rows(d3), grads[id(v.cls_token)])
+            pw, pb = v.patch_embed.proj.weight, v.patch_embed.proj.bias
+            if id(pw) in grads or id(pb) in grads:
+                linear_wgrad(ops.slice_rows_cast_bf16(d3, 1, S), state["patches"], [pw], [pb], grads)
 
 
 # =========================================================================================================
@@ -201,14 +215,26 @@ class BertTower(_Tower):
             ps += [self.hm["decoder"].weight, self.hm["decoder"].bias]
         else:
             ps += [self.hm["proj"].weight, self.hm["proj"].bias]
+        return ps + self.stack.base_params() + self._frozen_extra()
+
+    def _frozen_extra(self):
+        emb = self.bert.embeddings
+        ps = [emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight, emb.LayerNorm.weight,
+              emb.LayerNorm.bias]
+        if self.head_kind == "mlm":
+            ps += [self.hm["transform_dense"].weight, self.hm["transform_dense"].bias, self.hm["transform_ln"].weight,
+                   self.hm["transform_ln"].bias]
         return ps
+
+    def _full(self):
+        return self.stack.full_mode() or any(p.requires_grad for p in self._frozen_extra())
 
     def _head_images(self):
         if self.head_kind != "mlm":
             return None
         td = self.hm["transform_dense"]
         key = (td.weight._version, td.weight.data_ptr())
-        if key != self._head_key:
+        if key != self._head_key or td.weight.requires_grad:
             w = _f32c(td.weight)
             self._head_cache = (ops.cast_bf16(w), ops.cast_transpose_bf16(w))
             self._head_key = key
@@ -224,15 +250,7 @@ class BertTower(_Tower):
             raise NotSupportedYet("sequence length > 256")
         H = self.H
         dev = ids.device
-        frozen_extra = [emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight, emb.LayerNorm.weight,
-                        emb.LayerNorm.bias]
-        if self.head_kind == "mlm":
-            frozen_extra += [self.hm["transform_dense"].weight, self.hm["transform_dense"].bias, self.hm["transform_ln"].weight,
-                             self.hm["transform_ln"].bias]
-        if save:
-            if any(p.requires_grad for p in frozen_extra):
-                raise NotSupportedYet("embedding / MLM-transform parameters must be frozen on the HIP path (LoRA mode)")
-            self.stack.check_frozen()
+        full = save and self._full()
         self.stack.refresh()
         self.stack.pack_lora()
         M = B * S
@@ -252,10 +270,13 @@ class BertTower(_Tower):
             base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())  # CPU generator: reproducible under torch.manual_seed, no device sync
             drop = (self.p_hidden, self.p_attn, base)
             d_emb = ops.Drop(self.p_hidden, ops.derive_seed(base, 255, 3))
+        st_e = torch.empty((M, 2), dtype=F32, device=dev) if full else None
         ops.layernorm_fwd(e, _f32c(emb.LayerNorm.weight), _f32c(emb.LayerNorm.bias), float(emb.LayerNorm.eps), y_bf16=x_bf16, y_f32=x_f32,
-                          lora_a=a0, t_out=t0, drop=d_emb)
-        x_f32, x_bf16, saved = self.stack.forward(x_f32, x_bf16, t0, B, S, key_mask, save, drop=drop)
-        state = dict(saved=saved, B=B, S=S, key_mask=key_mask) if save else None
+                          stats=st_e, lora_a=a0, t_out=t0, drop=d_emb)
+        x_f32, x_bf16, saved = self.stack.forward(x_f32, x_bf16, t0, B, S, key_mask, save, drop=drop, full=full)
+        state = dict(saved=saved, B=B, S=S, key_mask=key_mask, full=full) if save else None
+        if full:
+            state.update(e=e, st_e=st_e, d_emb=d_emb, ids=ids, tt=tt, x_top=x_bf16)
         if self.head_kind == "mlm":
             wt, _ = self._head_images()
             td, tln, dec = self.hm["transform_dense"], self.hm["transform_ln"], self.hm["decoder"]
@@ -289,13 +310,36 @@ class BertTower(_Tower):
             tln, dec = self.hm["transform_ln"], self.hm["decoder"]
             dlogits = ops.softmax_mean_bwd(state["logits"], dout, B, S)
             dhln = dense_head_backward(dlogits, state["hln"], dec.weight, dec.bias, grads, out_bf16=True)
+            full = state["full"]
+            if full and id(tln.weight) in grads:
+                ops.layernorm_param_grads(dhln, state["g"], state["st"], grads[id(tln.weight)], grads[id(tln.bias)])
             dg = torch.empty((M, H), dtype=BF16, device=dev)
             ops.layernorm_bwd(dhln, state["g"], state["st"], _f32c(tln.weight), dx_bf16=dg)
             dhpre = ops.gelu_bwd(dg, state["hpre"])
+            if full:
+                td = self.hm["transform_dense"]
+                linear_wgrad(dhpre, state["x_top"], [td.weight], [td.bias], grads)
             dx = torch.empty((M, H), dtype=F32, device=dev)
             ops.gemm_nt(dhpre, wt_t, out_f32=dx)
         else:
             proj = self.hm["proj"]
             dmean = dense_head_backward(dout, state["mean"], proj.weight, proj.bias, grads, out_bf16=False)
             dx = ops.token_mean_bwd(dmean, S).view(M, H)
-        self.stack.backward(dx, None, state["saved"], B, S, state["key_mask"], grads)
+        full = state["full"]
+        dx0 = self.stack.backward(dx, None, state["saved"], B, S, state["key_mask"], grads, full=full)
+        if full:
+            # x0 = dropout(LayerNorm(word[ids] + position[s] + token_type[tt]))   (HF BertEmbeddings)
+            emb = self.bert.embeddings
+            lw, lb = emb.LayerNorm.weight, emb.LayerNorm.bias
+            if state["d_emb"] is not None and state["d_emb"].thr16 > 0:
+                dx0 = ops.dropout_apply(dx0, state["d_emb"])  # gradient w.r.t. the LayerNorm output
+            if id(lw) in grads:
+                ops.layernorm_param_grads(dx0, state["e"], state["st_e"], grads[id(lw)], grads[id(lb)])
+            tabs = [emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight]
+            if any(id(t) in grads for t in tabs):
+                de = torch.empty((M, H), dtype=F32, device=dev)
+                ops.layernorm_bwd(dx0, state["e"], state["st_e"], _f32c(lw), dx_f32=de)
+                if id(tabs[1]) in grads:
+                    ops.batch_sum(de.view(B, S * H), grads[id(tabs[1])][:S])
+                ops.bert_embed_bwd(state["ids"].view(-1), None if state["tt"] is None else state["tt"].view(-1), de,
+                                   grads.get(id(tabs[0])), grads.get(id(tabs[2])))

@@ -234,6 +234,26 @@ int clibd_topk_ip(const float* q, const float* keys, int Q, int Nk, int D, int k
  * (A0 C1 G2 T3, product('ACGT', repeat=k) order) or 2 (<UNK>) for a k-mer with any other character. */
 int clibd_kmer_tokenize(const void* seq_u8, int B, int L, int k, int64_t* out, void* stream);
 
+/* ---- full fine-tune mode (model_config.disable_lora): parameter gradients that are not GEMM-shaped.
+ * Every output ACCUMULATES (atomicAdd) into fp32 buffers the caller zeroes once per step.
+ * Replaces the autograd of nn.LayerNorm (timm Block.norm1/2, VisionTransformer.norm; HF Bert*LayerNorm), of nn.Embedding
+ * (HF BertEmbeddings) and of the position / class-token parameters (timm VisionTransformer._pos_embed). */
+/* dgamma[c] += sum_m dy[m,c] * (x[m,c]-mean[m]) * rstd[m];  dbeta[c] += sum_m dy[m,c].  dy [M,H] bf16 or fp32 (dy_is_f32),
+ * row stride ld_dy; x fp32 [M,H]; stats fp32 [M,2]; drop_thr16 > 0: dy is first multiplied by the dropout factor of
+ * element m*H+c (LayerNorm whose output went through dropout: HF BertEmbeddings).  H <= 1024. */
+int clibd_layernorm_param_grads(const void* dy, int dy_is_f32, int ld_dy, const float* x, const float* stats, int M, int H,
+                                float* dgamma, float* dbeta, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
+/* y[i] = x[i] * dropout_factor(seed, i) (x, y fp32 [n], may alias): gradient through a dropout whose mask index is the flat
+ * element index (y = dropout(LN(e)) of HF BertEmbeddings, when the embedding tables are trainable). */
+int clibd_dropout_apply_f32(const float* x, size_t n, float* y, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
+/* out[r] += sum_b x[b, r]  (x fp32 [B, R]): position-embedding and class-token gradients. */
+int clibd_batch_sum_f32(const float* x, int B, size_t R, float* out, void* stream);
+/* dword[ids[m], :] += de[m, :];  dtype[token_type[m] (0 if NULL), :] += de[m, :]   (de fp32 [M,H]; either table may be NULL). */
+int clibd_bert_embed_bwd(const int64_t* ids, const int64_t* token_type, const float* de, int M, int H, int vocab, int type_vocab,
+                         float* dword, float* dtype, void* stream);
+/* out bf16 [B*(s1-s0), H] = rows s0..s1-1 of every sequence of x fp32 [B,S,H] (patch rows of the ViT token gradient). */
+int clibd_slice_rows_cast_bf16(const float* x, int B, int S, int H, int s0, int s1, void* out, void* stream);
+
 /* fused AdamW step on a flat fp32 parameter bucket (torch.optim.AdamW semantics, scripts/train_cl.py:221):
  * p,g,m,v [n]; g is multiplied by grad_scale first (1/world_size folding etc.). */
 int clibd_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,

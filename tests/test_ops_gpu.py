@@ -629,3 +629,56 @@ def test_make_prediction_contract(dev):
     pred, sim, idx = make_prediction(keys[[4, 7]] * 3.0, keys, labels, with_similarity=True, with_indices=True, max_k=5, device=dev)
     assert idx[:, 0].tolist() == [4, 7] and abs(sim[0, 0] - 1.0) < 1e-5
     assert pred[0]["species"][0] == "species_4" and len(pred[1]["order"]) == 5
+
+
+# ----------------------------------------------------------------------------------------------- full fine-tune reductions
+@pytest.mark.parametrize("M,H,f32dy,drop", [(300, 768, False, False), (133, 512, True, False), (257, 128, True, True), (64, 1024, False, True)])
+def test_layernorm_param_grads(ops, dev, M, H, f32dy, drop):
+    from oracle import clibd_oracle as O
+
+    g = torch.Generator().manual_seed(M + H)
+    x = torch.randn(M, H, generator=g) * 2 + 0.5
+    dy = torch.randn(M, H, generator=g)
+    dyd = dy.to(dev) if f32dy else dy.to(dev, BF16)
+    mean = x.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-12)
+    stats = torch.cat([mean, rstd], dim=1).to(dev)
+    dg = torch.full((H,), 0.25, device=dev)
+    db = torch.full((H,), -0.5, device=dev)
+    d = ops.Drop(0.1, 99) if drop else None
+    ops.layernorm_param_grads(dyd, x.to(dev), stats, dg, db, drop=d)
+    dyr = dyd.float().cpu()
+    if drop:
+        idx = torch.arange(M, dtype=torch.int64)[:, None] * H + torch.arange(H, dtype=torch.int64)[None, :]
+        dyr = dyr * O.drop_factor(99, idx, 0.1)
+    xh = (x - mean) * rstd
+    assert rel_err(dg.cpu(), 0.25 + (dyr * xh).sum(0)) < 2e-5   # accumulates on top of what was there
+    assert rel_err(db.cpu(), -0.5 + dyr.sum(0)) < 2e-5
+
+
+def test_batch_sum_embed_bwd_slice_and_dropout_apply(ops, dev):
+    from oracle import clibd_oracle as O
+
+    g = torch.Generator().manual_seed(5)
+    B, S, H, V = 70, 13, 128, 50
+    x = torch.randn(B, S, H, generator=g)
+    out = torch.ones(S, H, device=dev)
+    ops.batch_sum(x.to(dev), out)
+    assert rel_err(out.cpu(), 1.0 + x.sum(0)) < 1e-5
+    ids = torch.randint(0, V, (B * S,), generator=g)
+    tt = torch.randint(0, 2, (B * S,), generator=g)
+    de = torch.randn(B * S, H, generator=g)
+    dword, dtype_t = torch.zeros(V, H, device=dev), torch.zeros(2, H, device=dev)
+    ops.bert_embed_bwd(ids.to(dev), tt.to(dev), de.to(dev), dword, dtype_t)
+    ref_w = torch.zeros(V, H).index_add_(0, ids, de)
+    ref_t = torch.zeros(2, H).index_add_(0, tt, de)
+    assert rel_err(dword.cpu(), ref_w) < 1e-5 and rel_err(dtype_t.cpu(), ref_t) < 1e-5
+    dtype0 = torch.zeros(2, H, device=dev)
+    ops.bert_embed_bwd(ids.to(dev), None, de.to(dev), None, dtype0)   # no token types: everything lands in row 0
+    assert rel_err(dtype0[0].cpu(), de.sum(0)) < 1e-5 and float(dtype0[1].abs().max()) == 0.0
+    sl = ops.slice_rows_cast_bf16(x.to(dev), 1, S)
+    assert torch.equal(sl.cpu(), x[:, 1:].reshape(B * (S - 1), H).to(BF16))
+    d = ops.Drop(0.1, 4242)
+    y = ops.dropout_apply(de.to(dev), d)
+    idx = torch.arange(B * S * H, dtype=torch.int64).view(B * S, H)
+    assert torch.allclose(y.cpu(), de * O.drop_factor(4242, idx, 0.1), rtol=1e-6, atol=0)
