@@ -257,6 +257,44 @@ extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw
     return check_launch("gemm_bf16_nt");
 }
 
+// ---- split-K with a partials workspace (weight gradients of the full fine-tune mode) -----------------------------------
+namespace clibd {
+// out[i] (+)= sum_s partials[s * n + i]
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ partials, int splits, size_t n4,
+                                                            float* __restrict__ out, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = accumulate ? ((const f32x4*)out)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < splits; ++k) s += ((const f32x4*)partials)[(size_t)k * n4 + i];
+        ((f32x4*)out)[i] = s;
+    }
+}
+}  // namespace clibd
+
+extern "C" size_t clibd_gemm_splitk_workspace_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)256 * (size_t)M * (size_t)N * sizeof(float) / (size_t)(((M + 255) / 256) * ((N + 255) / 256));  // <= 256 work items per round
+}
+
+extern "C" int clibd_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, float* out_f32, int ld_out,
+                                         int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !W || !out_f32 || !workspace) return set_error(CLIBD_EINVAL, "gemm_splitk: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ld_out != N) return set_error(CLIBD_EINVAL, "gemm_splitk: bad shape (out must be dense [M,N])");
+    if ((lda & 7) || (ldw & 7) || !aligned16(A) || !aligned16(W) || !aligned16(out_f32) || !aligned16(workspace) || (N & 3))
+        return set_error(CLIBD_EINVAL, "gemm_splitk: alignment");
+    GemmParams p{};
+    p.A = (const unsigned short*)A; p.W = (const unsigned short*)W;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
+    const int splits = gemm256_splitk_launch(p, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+    if (splits <= 0) return set_error(CLIBD_EINVAL, "gemm_splitk: shape not supported (need N % 256 == 0, K % 128 == 0, K >= 512, workspace)");
+    if (int e = check_launch("gemm256_splitk")) return e;
+    const size_t n4 = (size_t)M * N / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits, n4,
+                       out_f32, accumulate);
+    return check_launch("reduce_splits");
+}
+
 extern "C" int clibd_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream) {
     if (!in || !out || R <= 0 || C <= 0 || ld_in < C || ld_out < R) return set_error(CLIBD_EINVAL, "transpose: bad args");
     dim3 grid((C + 63) / 64, (ld_out + 63) / 64);

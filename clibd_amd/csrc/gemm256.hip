@@ -54,10 +54,12 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int nk = p.K / T_K;  // even, >= 4 (host-checked)
-    int tile = blockIdx.x;
+    const int nk_total = p.K / T_K;
+    const int tiles_out = p.tiles_m * p.tiles_n;
+    int tile = blockIdx.x;  // work item: (output tile, split) = (item % tiles_out, item / tiles_out); splits == 1: item = tile
     int m0, n0;          // tile being computed
     int nm0 = 0, nn0 = 0;  // tile whose loads are being issued (== m0,n0 until the last issue of the current tile)
+    int kb_issue = 0, nk_issue = nk_total, split_issue = 0;  // K-tile base / K-tile count (even, >= 4) / split of that item
 
     // ---- per-lane LDS-DMA sources: half-tile type j (0 P_hm0, 1 Q_hn0, 2 Q_hn1, 3 P_hm1) x this wave's 2 pieces
     const int prow = lane >> 3;
@@ -78,8 +80,15 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     const char* const baseW = (const char*)p.W;
     unsigned offP0 = 0, offP1 = 0;                          // P_hm0 pieces (P_hm1 = + 4 rows: scalar)
     unsigned offQ00 = 0, offQ01 = 0, offQ10 = 0, offQ11 = 0;  // Q_hn0 / Q_hn1 pieces (rows clamp individually on a ragged tile)
-    auto set_sources = [&](int tile_id) {
+    auto set_sources = [&](int item) {
         int tm, tn;
+        int tile_id = item;
+        if (KIND == EPI_SPLITK_F32) {
+            split_issue = item / tiles_out;
+            tile_id = item - split_issue * tiles_out;
+            kb_issue = split_issue * p.nk_split;
+            nk_issue = min(p.nk_split, nk_total - kb_issue);
+        }
         tile_coords(tile_id, p.tiles_m, p.tiles_n, 4, tm, tn);
         nm0 = tm * T_M;
         nn0 = tn * T_N;
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
 #define ISSUE(u, j, stage)                                                                              \
     do {                                                                                                \
         const unsigned dst_ = lds_dma0 + (unsigned)((stage) * STAGE_BYTES + (j) * HALF_BYTES);          \
-        const size_t ks_ = (size_t)(unsigned)(u) * (T_K * 2);  /* wave-uniform: folded into the scalar base */ \
+        const size_t ks_ = (size_t)(unsigned)((u) + kb_issue) * (T_K * 2);  /* wave-uniform: folded into the scalar base */ \
         if ((j) == 0) GLDS_PAIR(offP0, offP1, baseW + ks_, dst_);                                       \
         else if ((j) == 3) GLDS_PAIR(offP0, offP1, baseW + ks_ + (size_t)ldw2 * 4, dst_);               \
         else if ((j) == 1) GLDS_PAIR(offQ00, offQ01, baseA + ks_, dst_);                                \
@@ -255,6 +264,8 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     while (true) {
         m0 = nm0;
         n0 = nn0;
+        const int nk = nk_issue;         // K-tiles of this work item (== K/64 unless split-K)
+        const int split_cur = split_issue;
         const int next = tile + (int)gridDim.x;  // static round-robin: tile ids of one workgroup stay on one XCD
         const bool has_next = next < ntiles;
         WAIT_HEAD();  // L_0, L_1 of this tile have landed (this wave's pieces)
@@ -339,7 +350,16 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                 const int m = mb + 32 * hn + 16 * n + r;                                                     \
                 __VA_ARGS__                                                                                  \
             }
-            if (KIND == EPI_MUL_AUX || KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP) {
+            if (KIND == EPI_SPLITK_F32) {
+                float* outp = ep.out_f32 + (size_t)split_cur * (size_t)p.split_stride;
+                FOR_ROWS({
+                    if (m < p.M) {
+                        f32x4* o = (f32x4*)(outp + (size_t)m * ep.ld_out_f32 + nb);
+                        o[0] = (f32x4){acc[0][0][hn][n][r], acc[0][1][hn][n][r], acc[0][2][hn][n][r], acc[0][3][hn][n][r]};
+                        o[1] = (f32x4){acc[1][0][hn][n][r], acc[1][1][hn][n][r], acc[1][2][hn][n][r], acc[1][3][hn][n][r]};
+                    }
+                })
+            } else if (KIND == EPI_MUL_AUX || KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP) {
                 // Two passes so that no store sits between the epilogue's loads: vmcnt retires in order, and a load
                 // waited behind earlier stores would pay their HBM write latency once per row (16 serial round trips).
                 // Pass 1 folds bias / dropout / aux / residual into the accumulators in place (loads only, rows clamped),
@@ -415,6 +435,7 @@ static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
         case EPI_MUL_AUX: return K256(EPI_MUL_AUX);
         case EPI_RES_F32: return K256(EPI_RES_F32);
         case EPI_RES_F32_DROP: return K256(EPI_RES_F32_DROP);
+        case EPI_SPLITK_F32: return (const void*)gemm256_bf16_nt_kernel<EPI_SPLITK_F32, false, false, false>;
         default: return K256(EPI_GENERIC);
     }
 #undef K256
@@ -448,6 +469,9 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.tiles_m = (p.M + T_M - 1) / T_M;
     q.tiles_n = p.N / T_N;
+    q.splits = 1;
+    q.nk_split = nk;
+    q.split_stride = 0;
     static const int grid_cap = [] { const char* e = getenv("CLIBD_GEMM_GRID"); return e ? atoi(e) : 0; }();  // experiment knob
     const int cus = (grid_cap > 0 && grid_cap < num_cus) ? grid_cap : num_cus;
     const int grid = (int)(tiles < cus ? tiles : cus);
@@ -462,6 +486,57 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     void* args[] = {(void*)&q, (void*)&ntiles_i, (void*)&skew_arg, (void*)&stamp_arg};
     if (hipLaunchKernel(kernel_ptr(kind, lora, p.ep.bias != nullptr, diag), dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) != hipSuccess) return false;
     return true;
+}
+
+// Split-K with a partials workspace: partials[s] (fp32 [M, N], row stride N) = A[:, ks] . W[:, ks]^T for K-slice s.
+// Returns the number of splits used (>= 1) or 0 when the shape is not one this kernel takes.
+int gemm256_splitk_launch(const GemmParams& p0, float* partials, size_t partials_elems, hipStream_t stream) {
+    GemmParams q = p0;
+    const int nk = q.K / T_K;
+    if (q.K % T_K != 0 || nk < 8 || (nk & 1) || q.N % T_N != 0 || q.M < 1) return 0;
+    if ((unsigned long long)q.M * q.lda * 2ull >= (1ull << 32) || (unsigned long long)q.N * q.ldw * 2ull >= (1ull << 32)) return 0;
+    q.tiles_m = (q.M + T_M - 1) / T_M;
+    q.tiles_n = q.N / T_N;
+    const int tiles = q.tiles_m * q.tiles_n;
+    static const int num_cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+        }
+        return n;
+    }();
+    int splits = num_cus / tiles;                   // one round of work items over the CUs
+    if (splits < 1) splits = 1;
+    if (splits > nk / 4) splits = nk / 4;
+    int nks = (nk + splits - 1) / splits;
+    nks += nks & 1;                                  // even
+    if (nks < 4) nks = 4;
+    splits = (nk + nks - 1) / nks;
+    if (nk - (splits - 1) * nks < 4) {               // the last slice must keep >= 4 K-tiles (it is even: nk and nks are)
+        nks += 2;
+        splits = (nk + nks - 1) / nks;
+        if (nk - (splits - 1) * nks < 4) return 0;
+    }
+    if ((size_t)splits * (size_t)q.M * (size_t)q.N > partials_elems) return 0;
+    q.splits = splits;
+    q.nk_split = nks;
+    q.split_stride = (long long)q.M * q.N;
+    q.ep = clibd_gemm_epilogue{};
+    q.ep.out_f32 = partials;
+    q.ep.ld_out_f32 = q.N;
+    q.ep.split_k = 1;
+    static const bool attr_ok = hipFuncSetAttribute(kernel_ptr(EPI_SPLITK_F32, false, false, false), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    G256_LDS) == hipSuccess;
+    if (!attr_ok) return 0;
+    int nitems = tiles * splits, skew = 0;
+    long long* stamp = nullptr;
+    const int grid = nitems < num_cus ? nitems : num_cus;
+    void* args[] = {(void*)&q, (void*)&nitems, (void*)&skew, (void*)&stamp};
+    if (hipLaunchKernel(kernel_ptr(EPI_SPLITK_F32, false, false, false), dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) !=
+        hipSuccess)
+        return 0;
+    return splits;
 }
 
 }  // namespace clibd

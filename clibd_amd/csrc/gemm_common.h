@@ -11,6 +11,11 @@ struct GemmParams {
     int M, N, K, lda, ldw;
     int tiles_m, tiles_n, ktiles_per_split;
     clibd_gemm_epilogue ep;
+    // gemm256 split-K with a partials workspace (weight gradients: few output tiles, very long contraction): work item =
+    // (output tile, split); split s covers K-tiles [s*nk_split, min((s+1)*nk_split, K/64)) and stores its fp32 partial tile
+    // to ep.out_f32 + s*split_stride.  splits == 1: the ordinary GEMM.
+    int splits, nk_split;
+    long long split_stride;
 };
 
 // Inside a wave's 64 output columns, MFMA n-tile t (0..3), MFMA row i (0..15) carries tile-local column
@@ -154,7 +159,8 @@ enum : int {
     EPI_MUL_AUX = 3,    // * aux_bf16 -> out_bf16                               (fc2 dgrad x gelu')
     EPI_RES_F32 = 4,    // [bias] + residual_f32 -> out_f32                     (proj / fc2 forward)
     EPI_RES_F32_DROP = 5,  // [bias] -> dropout -> + residual_f32 -> out_f32    (BERT proj / fc2 forward, train mode)
-    EPI_NUM_KINDS = 6,
+    EPI_SPLITK_F32 = 6,    // plain fp32 store of this split's partial tile (split-K workspace mode)
+    EPI_NUM_KINDS = 7,
 };
 
 __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
@@ -281,5 +287,7 @@ __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, 
 
 // host side (gemm256.hip): returns true when the 256x256 kernel took the launch
 bool gemm256_try_launch(const GemmParams& p, hipStream_t stream);
+// split-K with a partials workspace; returns the number of splits (0: shape not taken)
+int gemm256_splitk_launch(const GemmParams& p, float* partials, size_t partials_elems, hipStream_t stream);
 
 }  // namespace clibd

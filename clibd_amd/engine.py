@@ -367,7 +367,9 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
             n1 = n0 + w.shape[0]
             if id(w) in grads:
                 gw = grads[id(w)].view(w.shape[0], -1)
-                if split > 1:
+                if Mp >= 4096 and ops.gemm_nt_splitk(dyT[n0:n1], xT, gw, accumulate=True):
+                    pass  # 256x256 kernel, one (tile, K-slice) per CU, partials summed by a second kernel
+                elif split > 1:
                     ops.gemm_nt(dyT[n0:n1], xT, out_f32=gw, split_k=split)
                 else:
                     ops.gemm_nt(dyT[n0:n1], xT, out_f32=gw, residual=gw)

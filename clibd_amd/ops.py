@@ -526,3 +526,28 @@ def dropout_apply(x: torch.Tensor, drop: Drop) -> torch.Tensor:
     y = torch.empty_like(x)
     check(_lib.load().clibd_dropout_apply_f32(x.data_ptr(), x.numel(), y.data_ptr(), drop.seed, drop.thr16, drop.scale, _stream()), "dropout_apply")
     return y
+
+
+_splitk_ws = {}
+
+
+def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, out_f32: torch.Tensor, accumulate: bool = True) -> bool:
+    """out (+)= a @ w.T for a long contraction and few output tiles (weight gradients), through the split-K workspace path
+    of the 256x256 kernel.  Returns False (nothing launched) when the shape is outside that path — use gemm_nt(split_k=)."""
+    _chk(a, BF16, "a", contiguous=False); _chk(w, BF16, "w", contiguous=False); _chk(out_f32, F32, "out_f32")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or tuple(out_f32.shape) != (M, N):
+        raise ValueError("gemm_nt_splitk: shape mismatch")
+    if N % 256 or K % 128 or K < 512:
+        return False
+    lib = _lib.load()
+    need = lib.clibd_gemm_splitk_workspace_bytes(M, N)
+    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream)
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(((need + 3) // 4,), dtype=F32, device=a.device)   # one workspace per (device, stream)
+        _splitk_ws[key] = ws
+    check(lib.clibd_gemm_bf16_nt_splitk(a.data_ptr(), _rowmajor(a, "a"), w.data_ptr(), _rowmajor(w, "w"), M, N, K, out_f32.data_ptr(), N,
+                                        int(accumulate), ws.data_ptr(), ws.numel() * 4, _stream()), "gemm_bf16_nt_splitk")
+    return True

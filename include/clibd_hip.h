@@ -234,6 +234,15 @@ int clibd_topk_ip(const float* q, const float* keys, int Q, int Nk, int D, int k
  * (A0 C1 G2 T3, product('ACGT', repeat=k) order) or 2 (<UNK>) for a k-mer with any other character. */
 int clibd_kmer_tokenize(const void* seq_u8, int B, int L, int k, int64_t* out, void* stream);
 
+/* Split-K GEMM through a partials workspace: out[M,N] (fp32, dense, ld_out == N) = (accumulate ? out : 0) + A[M,K] . W[N,K]^T.
+ * For products with few output tiles and a very long contraction — the weight gradients dW = dY^T X of the full
+ * fine-tune mode (autograd of every nn.Linear on the path), A = dY^T [N_w, tokens], W = X^T [K_w, tokens].
+ * The 256x256 kernel runs one (tile, K-slice) work item per CU and stores fp32 partial tiles (deterministic: no atomics);
+ * a second kernel sums the slices.  N % 256 == 0, K % 128 == 0, K >= 512; workspace >= clibd_gemm_splitk_workspace_bytes(M,N). */
+size_t clibd_gemm_splitk_workspace_bytes(int M, int N);
+int clibd_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, float* out_f32, int ld_out,
+                              int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- full fine-tune mode (model_config.disable_lora): parameter gradients that are not GEMM-shaped.
  * Every output ACCUMULATES (atomicAdd) into fp32 buffers the caller zeroes once per step.
  * Replaces the autograd of nn.LayerNorm (timm Block.norm1/2, VisionTransformer.norm; HF Bert*LayerNorm), of nn.Embedding

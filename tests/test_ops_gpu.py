@@ -682,3 +682,22 @@ def test_batch_sum_embed_bwd_slice_and_dropout_apply(ops, dev):
     y = ops.dropout_apply(de.to(dev), d)
     idx = torch.arange(B * S * H, dtype=torch.int64).view(B * S, H)
     assert torch.allclose(y.cpu(), de * O.drop_factor(4242, idx, 0.1), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 768, 50432), (3072, 768, 34048), (300, 256, 4096), (768, 3072, 8192 + 128)])
+def test_gemm_splitk_workspace_exact(ops, dev, M, N, K):
+    """Split-K through the partials workspace (weight-gradient shapes): exact small-integer products, accumulate semantics,
+    bit-identical across repeats (no atomics)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-1, 2, (M, K), generator=g).float()
+    w = torch.randint(-1, 2, (N, K), generator=g).float()
+    ad, wd = a.to(dev, BF16), w.to(dev, BF16)
+    ref = ad.float() @ wd.float().T   # |sums| <= K < 2^24: exact in fp32 in any order
+    out = torch.full((M, N), 3.0, device=dev)
+    assert ops.gemm_nt_splitk(ad, wd, out, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref + 3.0)
+    out2 = torch.empty((M, N), device=dev)
+    assert ops.gemm_nt_splitk(ad, wd, out2, accumulate=False)
+    assert torch.equal(out2, ref)
+    assert not ops.gemm_nt_splitk(ad[:, :448], wd[:, :448], out2)   # K < 512: caller falls back to gemm_nt(split_k=)
