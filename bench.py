@@ -191,8 +191,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()   # the timed region carries NO per-launch event records (they cost ~1.3 ms per step of host+GPU time)
     for _ in range(args.steps):
         loss = one_step()
     torch.cuda.synchronize()
@@ -200,19 +199,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     loss_val = float(loss.item())
 
-    # Kernel-quality pass for `roofline`: in the timed region the two towers run on separate HIP streams, so a GEMM's
-    # event-to-event duration there includes the time its CUs were shared with the other tower's kernels.  The same step
-    # is therefore run a few more times with the towers serialized on one stream (not part of `value`): per-launch
-    # durations of that pass are what the kernel itself achieves; the timed region's own figures are reported next to it.
-    overlapped = timer.result()
+    # Kernel passes for `roofline` (same step, right after the timed region, not part of `value`): HIP events around every
+    # GEMM launch, recorded on the launch stream.  Pass 1 runs exactly like the timed region: the two towers overlap on
+    # separate streams, so a launch's event-to-event time includes the time its CUs were shared with the other tower's
+    # kernels.  Pass 2 serializes the towers on one stream: its per-launch durations are what the kernel itself achieves.
     overlap_on = bool(getattr(model, "overlap_towers", False)) and (model.image_encoder is not None) and (model.dna_encoder is not None)
+    overlapped = None
+    if not args.no_gemm_timing:
+        timer.enabled = True
+        for _ in range(min(args.steps, 5)):
+            one_step()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        overlapped = timer.result()
+        overlapped["steps"] = min(args.steps, 5)
     serial = None
     if overlapped and overlap_on:
         timer.events, timer.flops, timer.shapes, timer.bytes = [], 0.0, [], 0.0
@@ -234,13 +240,13 @@ def main():
         pairs_per_s = b * world * args.steps / elapsed
         gemm = serial if serial is not None else overlapped
         if gemm and args.gemm_breakdown:
-            timer.breakdown(serial["steps"] if serial is not None else args.steps)
+            timer.breakdown(gemm["steps"])
         step_frac = pairs_per_s * GF_PER_PAIR_TRAIN * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12)
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "kernel": "gemm256_bf16_nt_kernel (256x256x64 persistent tiles; gemm_bf16_nt_kernel 128x128 for small shapes)", "step_frac": step_frac,
                 "note": "achieved = sum of 2MNK over every GEMM launch / summed HIP-event durations (rank 0, events on the launch "
                         "stream), measured right after the timed region on the same step with the towers serialized on one stream; "
-                        "timed_region = the same quantity inside the timed region, where the towers overlap on two streams and a "
+                        "timed_region = the same quantity with the towers overlapping on two streams exactly as in the timed region, where a "
                         "launch's duration includes CU sharing; step_frac = pairs/s x 117.6 GF / (n_gpus x peak), the whole step "
                         "against the MFMA roof"}
         traffic, traffic_src = pmc_traffic()
@@ -248,12 +254,12 @@ def main():
             roof["traffic"] = traffic
             roof["traffic_source"] = f"profiles/{traffic_src}: mean HBM bytes per gemm256 launch (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate --pmc passes)"
         if gemm:
-            gsteps = serial["steps"] if serial is not None else args.steps
+            gsteps = gemm["steps"]
             roof.update(achieved=gemm["tflops"], frac=gemm["tflops"] / PEAK_BF16_TFLOPS, launches=gemm["launches"],
                         gemm_ms_per_step=gemm["total_ms"] / gsteps, avg_launch_us=gemm["total_ms"] / gemm["launches"] * 1e3,
                         algorithmic_bytes_per_launch=gemm["bytes_per_launch"])
             if serial is not None:
-                roof["timed_region"] = {"achieved": overlapped["tflops"], "gemm_ms_per_step": overlapped["total_ms"] / args.steps,
+                roof["timed_region"] = {"achieved": overlapped["tflops"], "gemm_ms_per_step": overlapped["total_ms"] / overlapped["steps"],
                                         "avg_launch_us": overlapped["total_ms"] / overlapped["launches"] * 1e3, "streams": 2}
         out = {
             "metric": "paired samples/sec/step (I+D contrastive)" if not args.tri_modal else "triples/sec/step (I+D+T contrastive)",

@@ -406,12 +406,14 @@ def dense_head_backward(dout_f32: torch.Tensor, x_bf16: torch.Tensor, weight: to
     dy_b = ops.cast_bf16(dout_f32) if dout_f32.dtype == F32 else dout_f32
     M, D = dy_b.shape
     K = x_bf16.shape[1]
-    dyT = ops.transpose_bf16(dy_b)          # [D, Mp]
-    xT = ops.transpose_bf16(x_bf16)         # [K, Mp]
+    dyT = ops.transpose_bf16(dy_b, pad_to=128)          # [D, Mp]
+    xT = ops.transpose_bf16(x_bf16, pad_to=128)         # [K, Mp]
     Mp = dyT.shape[1]
     split = max(1, min(32, Mp // 2048))
     gw = grads[id(weight)]
-    if split > 1:
+    if Mp >= 4096 and ops.gemm_nt_splitk(dyT, xT, gw, accumulate=True):
+        pass  # long contraction (MLM decoder over all tokens): 256x256 split-K workspace path
+    elif split > 1:
         ops.gemm_nt(dyT, xT, out_f32=gw, split_k=split)      # atomically accumulates into the zeroed bucket
     else:
         ops.gemm_nt(dyT, xT, out_f32=gw, residual=gw)        # accumulate in place
