@@ -185,7 +185,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 }
 
 // ============================================ backward =========================================================
-template <int NKT>
+// PAIR: phase 2 sweeps two key tiles per wave (long sequences: halves the LDS traffic per MFMA; costs ~60 VGPRs, so the
+// short-sequence instantiations, which fit three waves per SIMD without it, keep the one-tile sweep)
+template <int NKT, bool PAIR>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                                     const unsigned short* __restrict__ dout, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
@@ -333,6 +335,114 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     }
     __syncthreads();  // every wave is done reading K/V tiles; statistics are visible
 
+    if constexpr (PAIR) {
+    // ---------------- phase 2: dV, dK — TWO 16-key tiles per wave (query on the MFMA row, key on the lane) ----------------
+    // Every Q / dO fragment read from LDS (row form for S and dP, transposed form for dK and dV) feeds two MFMAs, one per
+    // key tile: half the LDS traffic per MFMA of a one-tile sweep (this phase was LDS-bandwidth bound: 1 KiB per MFMA).
+    // Arithmetic per element is unchanged.
+    stage_head_tile(t0, qbase, ld, S, S_pad, wave, lane);
+    stage_head_tile(t1, dobase, (size_t)H, nq, S_pad, wave, lane);  // rows >= nq are clamped copies, masked below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nkt = (S + 15) >> 4;
+    for (int p = wave; p < ((nkt + 1) >> 1); p += ATT_WAVES) {
+        bf16x8 kf[2][2], vf[2][2];
+        bool key_ok[2];
+        int keyv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int key = (2 * p + j) * 16 + i;
+            keyv[j] = key;
+            bool ok = key < S;
+            if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+            key_ok[j] = ok;
+            const int kc = min(key, S - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[j][ks] = *(const bf16x8*)(qbase + H + (size_t)kc * ld + 32 * ks + 8 * g);
+                vf[j][ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kc * ld + 32 * ks + 8 * g);
+            }
+        }
+        f32x4 dv[2][4], dk[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dv[j][dt] = (f32x4){0, 0, 0, 0}; dk[j][dt] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll 1
+        for (int s = 0; s < (nqt + 1) / 2; ++s) {  // only query tiles that carry a gradient
+            bf16x8 qr[2][2], dor[2][2];
+            float mr[2][4], ilr[2][4], dlr[2][4];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    qr[hq][ks] = lds_row_frag(t0, (2 * s + hq) * 16 + i, ks, g);
+                    dor[hq][ks] = lds_row_frag(t1, (2 * s + hq) * 16 + i, ks, g);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = (2 * s + hq) * 16 + 4 * g + r;
+                    mr[hq][r] = st_m[qq]; ilr[hq][r] = st_il[qq]; dlr[hq][r] = st_d[qq];
+                }
+            }
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 pp[2], dd[2];
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    f32x4 sv = (f32x4){0, 0, 0, 0}, dpv = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[hq][ks], kf[j][ks], sv, 0, 0, 0);
+                        dpv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dor[hq][ks], vf[j][ks], dpv, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qq = (2 * s + hq) * 16 + 4 * g + r;
+                        const bool ok = key_ok[j] && (qq < nq);
+                        const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -mr[hq][r])) * ilr[hq][r] : 0.f;  // rounded to bf16 only inside dV's operand
+                        float fm = 1.0f;
+                        if (drop_thr16 > 0)
+                            fm = drop_one(drop_seed, (((unsigned)blockIdx.x * (unsigned)S + (unsigned)qq) << 8) + (unsigned)keyv[j], (unsigned)drop_thr16, drop_scale);
+                        pp[hq][r] = pr * fm;                                   // dV = (P o M/(1-p))^T dO
+                        dd[hq][r] = pr * (dpv[r] * fm - dlr[hq][r]) * scale;    // dS = P o (dP - delta), dP masked as in phase 1
+                    }
+                }
+                pf[j] = pack_frag(pp[0], pp[1]);
+                dsf[j] = pack_frag(dd[0], dd[1]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 trdo = lds_tr_frag(t1, s, dt, lane);
+                const bf16x8 trq = lds_tr_frag(t0, s, dt, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trdo, pf[j], dv[j][dt], 0, 0, 0);
+                    dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trq, dsf[j], dk[j][dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (keyv[j] < S) {
+                unsigned short* krow = dqbase + H + (size_t)keyv[j] * ld;
+                unsigned short* vrow = dqbase + 2 * H + (size_t)keyv[j] * ld;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    uint2 pk;
+                    pk.x = pack2bf(dk[j][dt][0], dk[j][dt][1]);
+                    pk.y = pack2bf(dk[j][dt][2], dk[j][dt][3]);
+                    *(uint2*)(krow + 16 * dt + 4 * g) = pk;
+                    pk.x = pack2bf(dv[j][dt][0], dv[j][dt][1]);
+                    pk.y = pack2bf(dv[j][dt][2], dv[j][dt][3]);
+                    *(uint2*)(vrow + 16 * dt + 4 * g) = pk;
+                }
+            }
+        }
+    }
+    } else {
     // ---------------- phase 2: per 16-key tile: dV, dK (query on the MFMA row, key on the lane) ----------------
     bf16x8 kf[2], vf[2], kfn[2], vfn[2];
     {
@@ -414,6 +524,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
     }
+    }
 }
 
 static int att_check(const void* qkv, int B, int S, int nheads, const char* who) {
@@ -485,8 +596,8 @@ extern "C" int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(N)                                                                                                 \
     do {                                                                                                          \
-        hipFuncSetAttribute((const void*)attention_bwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(attention_bwd_kernel<N>, dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
+        hipFuncSetAttribute((const void*)attention_bwd_kernel<N, (N >= 12)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attention_bwd_kernel<N, (N >= 12)>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
                            (const unsigned short*)qkv, (const unsigned short*)dout, S, nheads, (const int*)key_mask, \
                            (unsigned short*)dqkv, scale, nq, dout_seq, drop_seed, drop_thr16, drop_scale);        \
     } while (0)
