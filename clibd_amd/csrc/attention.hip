@@ -77,7 +77,7 @@ __device__ __forceinline__ float group4_max(float v) {
 constexpr float NEG_BIG = -1.0e30f;
 
 // ============================================ forward ==========================================================
-template <int NKT>  // number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32)
+template <int NKT, bool PAIR>  // NKT: number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32); PAIR: two query tiles per sweep
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ out, float scale,
@@ -108,6 +108,109 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    if constexpr (PAIR) {
+        // Two query tiles per wave and sweep: every K row fragment and every transposed V fragment read from LDS feeds two
+        // MFMAs (the one-tile sweep moves 1 KiB of LDS per MFMA and is bound by it).  Arithmetic per element is unchanged.
+        for (int p = wave; p < ((nqt + 1) >> 1); p += ATT_WAVES) {
+            bf16x8 qf2[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qc = min((2 * p + t) * 16 + i, S - 1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) qf2[t][ks] = *(const bf16x8*)(qbase + (size_t)qc * ld + 32 * ks + 8 * g);
+            }
+            f32x4 sc[2][NKT];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                sc[0][kt] = (f32x4){0, 0, 0, 0};
+                sc[1][kt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 kfr = lds_row_frag(kt_lds, kt * 16 + i, ks, g);
+                    sc[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf2[0][ks], sc[0][kt], 0, 0, 0);
+                    sc[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf2[1][ks], sc[1][kt], 0, 0, 0);
+                }
+                if (kt & 1) __builtin_amdgcn_sched_barrier(0);  // at most four K fragments in flight: 2 x NKT score quads leave no room for more
+            }
+            float inv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float mx = NEG_BIG;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    if (kt * 16 + 15 >= S || key_mask != nullptr) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt * 16 + 4 * g + r;
+                            bool ok = key < S;
+                            if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+                            if (!ok) sc[t][kt][r] = NEG_BIG;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][kt][r]);
+                }
+                mx = group4_max(mx);
+                const float mc = mx * c2;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(sc[t][kt][r], c2, -mc));
+                        sc[t][kt][r] = e;
+                        sum += e;
+                    }
+                sum = group4_sum(sum);
+                inv[t] = 1.0f / sum;
+            }
+            f32x4 o[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NKT / 2; ++s) {
+                bf16x8 pf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (drop_thr16 > 0) {
+                        const unsigned q = (unsigned)((2 * p + t) * 16 + i);
+                        const unsigned base = (((unsigned)blockIdx.x * (unsigned)S + q) << 8) + 32u * s + 4u * g;
+                        float f0, f1, f2, f3;
+                        drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
+                        drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
+                        sc[t][2 * s][0] *= f0; sc[t][2 * s][1] *= f1; sc[t][2 * s][2] *= f2; sc[t][2 * s][3] *= f3;
+                        drop_pair(drop_seed, base + 16, (unsigned)drop_thr16, drop_scale, f0, f1);
+                        drop_pair(drop_seed, base + 18, (unsigned)drop_thr16, drop_scale, f2, f3);
+                        sc[t][2 * s + 1][0] *= f0; sc[t][2 * s + 1][1] *= f1; sc[t][2 * s + 1][2] *= f2; sc[t][2 * s + 1][3] *= f3;
+                    }
+                    pf[t] = pack_frag(sc[t][2 * s], sc[t][2 * s + 1]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 vtr = lds_tr_frag(vt_lds, s, dt, lane);
+                    o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtr, pf[0], o[0][dt], 0, 0, 0);
+                    o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtr, pf[1], o[1][dt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q = (2 * p + t) * 16 + i;
+                if (q < nq) {
+                    unsigned short* orow = out + ((size_t)b * out_seq + q) * H + h * DH;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        uint2 pk;
+                        pk.x = pack2bf(o[t][dt][0] * inv[t], o[t][dt][1] * inv[t]);
+                        pk.y = pack2bf(o[t][dt][2] * inv[t], o[t][dt][3] * inv[t]);
+                        *(uint2*)(orow + 16 * dt + 4 * g) = pk;
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
         const int q = qt * 16 + i;
         f32x4 sc[NKT];
@@ -566,8 +669,8 @@ extern "C" int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nhead
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(N)                                                                                                 \
     do {                                                                                                          \
-        hipFuncSetAttribute((const void*)attention_fwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(attention_fwd_kernel<N>, dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
+        hipFuncSetAttribute((const void*)attention_fwd_kernel<N, (N >= 10)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attention_fwd_kernel<N, (N >= 10)>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
                            (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
                            drop_seed, drop_thr16, drop_scale);                                                    \
     } while (0)
