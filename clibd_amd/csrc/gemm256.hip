@@ -472,9 +472,7 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     q.splits = 1;
     q.nk_split = nk;
     q.split_stride = 0;
-    static const int grid_cap = [] { const char* e = getenv("CLIBD_GEMM_GRID"); return e ? atoi(e) : 0; }();  // experiment knob
-    const int cus = (grid_cap > 0 && grid_cap < num_cus) ? grid_cap : num_cus;
-    const int grid = (int)(tiles < cus ? tiles : cus);
+    const int grid = (int)(tiles < num_cus ? tiles : num_cus);
     const int kind = epilogue_kind(p.ep);
     int ntiles_i = (int)tiles;
     int skew_arg = skew_env_value();

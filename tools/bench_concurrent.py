@@ -1,5 +1,5 @@
-"""Two GEMM chains (ViT-sized and DNA-sized fc1 -> fc2 pairs) on one stream vs two streams.
-CLIBD_GEMM_GRID=128 halves each persistent grid, so two concurrent kernels split the CUs instead of queueing."""
+"""Two GEMM chains (ViT-sized and DNA-sized fc1 -> fc2 pairs) on one stream vs two streams (full persistent grids that
+queue behind each other: 1.112 -> 0.985 ms per pair; halving each grid so the kernels split the CUs was slower, 1.112 ms)."""
 import sys, time
 import torch
 sys.path.insert(0, ".")
