@@ -398,3 +398,62 @@ def test_full_finetune_training_step_updates_base_weights(dev):
     assert (w.detach() - before).abs().max().item() > 0
     losses = [l0] + [float(tr.step(img, ids, None, labels)) for _ in range(7)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+
+
+# ------------------------------------------------------------------------------------------ streams / full-size properties
+def test_tower_streams_do_not_change_results(dev):
+    """The towers run on separate HIP streams by default (forward and, through autograd, backward); serialized on one stream
+    they must give the same embeddings, loss and gradients (only float atomics reorder: 1e-5)."""
+    from clibd_amd.model import ClipLoss, SimpleCLIP
+
+    gd, gi, gt = load("dna_tiny_golden.pt"), load("image_tiny_golden.pt"), load("text_tiny_golden.pt")
+    img = (gi["image_u8"].float() / 255.0).to(dev)
+    ids = gd["ids"].to(dev)
+    txt = {k: v.to(dev) for k, v in gt["inputs"].items()}
+    B = min(img.shape[0], ids.shape[0], txt["input_ids"].shape[0])
+    img, ids, txt = img[:B], ids[:B], {k: v[:B] for k, v in txt.items()}
+    labels = torch.arange(B, device=dev) % 3
+    res = []
+    for overlap in (True, False):
+        model = SimpleCLIP(hip_image(gi, dev), hip_dna(gd, dev), hip_text(gt, dev)).to(dev)
+        model.overlap_towers = overlap
+        crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+        i, d, t, scale, _ = model(img, ids, txt)
+        loss = crit(i, d, t, labels, scale)
+        grads = grads_named(model, loss)
+        model.join_streams()
+        torch.cuda.synchronize()
+        res.append((i.detach().cpu(), d.detach().cpu(), t.detach().cpu(), float(loss.detach()), grads))
+    a, b = res
+    for k in range(3):
+        assert torch.equal(a[k], b[k])
+    assert a[3] == b[3]
+    for n in a[4]:
+        assert (a[4][n] - b[4][n]).abs().max().item() <= 1e-5 * (b[4][n].abs().max().item() + 1e-12), n
+
+
+def test_full_size_step_properties(dev):
+    """BASELINE configs[1] shapes (ViT-B/16 + BERT-base, 197 / 133 tokens) at a small batch: the step runs through the
+    full-size kernels (256x256 GEMM, long-sequence attention).  Size-independent properties: unit-norm embeddings, DNA head
+    rows sum to 1 before normalisation is lost (finite, positive), loss = log(B) +- small at random init with unit
+    temperature scaling, identical loss when the step is repeated from the same state, loss decreases over a few steps."""
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import CLIBDDNAEncoder, CLIBDImageEncoder, SimpleCLIP, create_vit, load_pre_trained_bioscan_bert
+    from clibd_amd.train import Trainer
+
+    torch.manual_seed(7)
+    model = SimpleCLIP(CLIBDImageEncoder(create_vit("vit_base_patch16_224"), r=4, num_classes=768),
+                       CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), r=4, num_classes=768), None).to(dev).eval()
+    B = 48
+    batch = synthetic_batch(B, dev, seed=3, rank=0, with_text=False)
+    with torch.no_grad():
+        i1, d1, _, scale, _ = model(batch["image"], batch["dna"], None)
+        i2, d2, _, _, _ = model(batch["image"], batch["dna"], None)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)                       # forward is deterministic
+    for e in (i1, d1):
+        assert torch.isfinite(e).all() and torch.allclose(e.norm(dim=1), torch.ones(B, device=dev), atol=1e-4)
+    tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True)
+    losses = [float(tr.step(batch["image"], batch["dna"], None, batch["labels"])) for _ in range(6)]
+    assert all(l == l and l < 1e4 for l in losses)
+    assert abs(losses[0] - float(torch.log(torch.tensor(float(B))))) < 0.5   # near-uniform similarities at init
+    assert losses[-1] < losses[0]
