@@ -47,6 +47,7 @@ SIGNATURES = {
     "clibd_last_error": (C.c_char_p, []),
     "clibd_abi_version": (c_int, []),
     "clibd_gemm_bf16_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
+    "clibd_gemm_bf16_nt_khole": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
     "clibd_transpose_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "clibd_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_cast_transpose_f32_to_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

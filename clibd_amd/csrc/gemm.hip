@@ -46,7 +46,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(GemmParam
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int kt0 = split * p.ktiles_per_split;
-    const int nk = min(p.ktiles_per_split, p.K / BK - kt0);
+    const int nk = min(p.ktiles_per_split, p.K / BK - p.hole_nkt - kt0);  // K-tiles this block walks (the hole is not counted)
 
     // ---- per-lane source pointers for this wave's 4 A pieces and 4 W pieces (1 KiB = 8 rows each)
     const int prow = lane >> 3;                 // row inside the piece
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(GemmParam
         const int r = (wave * 4 + j) * 8 + prow;  // LDS row 0..127
         const int gm = min(m0 + r, p.M - 1);
         const int gn = min(n0 + w_row_perm(r), p.N - 1);
-        a_src[j] = (const char*)(p.A + (size_t)gm * p.lda + (size_t)kt0 * BK) + chunk * 16;
-        w_src[j] = (const char*)(p.W + (size_t)gn * p.ldw + (size_t)kt0 * BK) + chunk * 16;
+        a_src[j] = (const char*)(p.A + (size_t)gm * p.lda) + chunk * 16;
+        w_src[j] = (const char*)(p.W + (size_t)gn * p.ldw) + chunk * 16;
     }
 
     f32x4 acc[4][4];
@@ -81,7 +81,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(GemmParam
 
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * (2 * TILE_BYTES);
-        const size_t koff = (size_t)kt * (BK * 2);
+        int kta = kt0 + kt;
+        if (kta >= p.hole_kt) kta += p.hole_nkt;   // skip the hole (hole_nkt == 0: no-op)
+        const size_t koff = (size_t)kta * (BK * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             glds16(a_src[j] + koff, base + (wave * 4 + j) * 1024);
@@ -202,9 +204,11 @@ __global__ __launch_bounds__(256) void cast_transpose_f32_bf16_kernel(const floa
 
 using namespace clibd;
 
-extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
-                                  const clibd_gemm_epilogue* ep, void* stream) {
+static int gemm_impl(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int hole_k0, int hole_len,
+                     const clibd_gemm_epilogue* ep, void* stream) {
     if (!A || !W || !ep) return set_error(CLIBD_EINVAL, "gemm: null pointer");
+    if (hole_len < 0 || hole_k0 < 0 || hole_k0 % BK || hole_len % BK || hole_k0 + hole_len > K || (hole_len > 0 && hole_len >= K))
+        return set_error(CLIBD_EINVAL, "gemm: bad K hole (multiples of 64 inside [0, K))");
     if (M <= 0 || N <= 0 || K <= 0) return set_error(CLIBD_EINVAL, "gemm: non-positive shape");
     if (K % BK != 0) return set_error(CLIBD_EINVAL, "gemm: K must be a multiple of 64");
     if (N % 16 != 0) return set_error(CLIBD_EINVAL, "gemm: N must be a multiple of 16");
@@ -236,15 +240,18 @@ extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
-    const int ktiles = K / BK;
+    const int ktiles = (K - hole_len) / BK;
     p.ktiles_per_split = (ktiles + split - 1) / split;
     p.ep = *ep;
     p.ep.split_k = split;
+    p.splits = 1; p.nk_split = 0; p.split_stride = 0;
+    p.hole_kt = hole_len > 0 ? hole_k0 / BK : 0x7fffffff;
+    p.hole_nkt = hole_len / BK;
     // kernel choice (CLIBD_GEMM_KERNEL=1 forces the 128x128 kernel: tuning aid).  A third shape — 256x128x32 tiles, 3-stage
     // ring, two workgroups per CU so epilogues overlap across workgroups — was built and measured: 800 TF at K=768 and
     // 920 TF at K=3072 against 944 / 1300 TF for the 256x256 8-phase kernel, so it was dropped.
     static const int forced = [] { const char* e = getenv("CLIBD_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
-    if (forced != 1 && gemm256_try_launch(p, (hipStream_t)stream)) return check_launch("gemm256_bf16_nt");
+    if (forced != 1 && hole_len == 0 && gemm256_try_launch(p, (hipStream_t)stream)) return check_launch("gemm256_bf16_nt");
     const long long nblocks = (long long)p.tiles_m * p.tiles_n * split;
     if (nblocks > 0x7fffffffLL) return set_error(CLIBD_EINVAL, "gemm: grid too large");
     static const bool attr_ok = [] {
@@ -255,6 +262,16 @@ extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)nblocks), dim3(GEMM_THREADS), 4 * TILE_BYTES,
                        (hipStream_t)stream, p);
     return check_launch("gemm_bf16_nt");
+}
+
+extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                                  const clibd_gemm_epilogue* ep, void* stream) {
+    return gemm_impl(A, lda, W, ldw, M, N, K, 0, 0, ep, stream);
+}
+
+extern "C" int clibd_gemm_bf16_nt_khole(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int hole_k0, int hole_len,
+                                        const clibd_gemm_epilogue* ep, void* stream) {
+    return gemm_impl(A, lda, W, ldw, M, N, K, hole_k0, hole_len, ep, stream);
 }
 
 // ---- split-K with a partials workspace (weight gradients of the full fine-tune mode) -----------------------------------

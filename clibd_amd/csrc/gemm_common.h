@@ -16,6 +16,9 @@ struct GemmParams {
     // to ep.out_f32 + s*split_stride.  splits == 1: the ordinary GEMM.
     int splits, nk_split;
     long long split_stride;
+    // 128x128 kernel only: K-tiles [hole_kt, hole_kt + hole_nkt) of both operands are skipped (a column segment of A that
+    // meets all-zero weights: the k segment of dqkv in the adapters' dt projection).  hole_nkt == 0: none.
+    int hole_kt, hole_nkt;
 };
 
 // Inside a wave's 64 output columns, MFMA n-tile t (0..3), MFMA row i (0..15) carries tile-local column

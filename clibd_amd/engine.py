@@ -343,7 +343,8 @@ class TransformerStack:
 
     def _lora_grads(self, L, c, dqkv, x_bf16, t, dt, grads):
         H = self.H
-        ops.gemm_nt(dqkv, c.w_dt, out_bf16=dt)  # dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v
+        # dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v; the k segment of dqkv meets zero weights in w_dt and is not read
+        ops.gemm_nt(dqkv, c.w_dt, out_bf16=dt, k_hole=(H, H))
         lp = L.lora
         ops.lora_wgrad(dqkv, x_bf16, t, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
 

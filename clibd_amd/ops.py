@@ -79,8 +79,10 @@ def gemm_nt(
     out_f32: Optional[torch.Tensor] = None,
     split_k: int = 1,
     drop: Optional["Drop"] = None,
+    k_hole: Optional[tuple] = None,
 ) -> None:
-    """out = epilogue(a[M,K] @ w[N,K]^T); see clibd_gemm_bf16_nt in include/clibd_hip.h."""
+    """out = epilogue(a[M,K] @ w[N,K]^T); see clibd_gemm_bf16_nt in include/clibd_hip.h.
+    k_hole = (k0, length): the K range [k0, k0+length) of both operands is skipped (multiples of 64)."""
     _chk(a, BF16, "a", contiguous=False)
     _chk(w, BF16, "w", contiguous=False)
     lda, ldw = _rowmajor(a, "a"), _rowmajor(w, "w")
@@ -125,6 +127,10 @@ def gemm_nt(
         ep.out_bf16, ep.ld_out_bf16 = out_bf16.data_ptr(), _rowmajor(out_bf16, "out_bf16")
     if out_f32 is not None:
         ep.out_f32, ep.ld_out_f32 = out_f32.data_ptr(), _rowmajor(out_f32, "out_f32")
+    if k_hole is not None:
+        check(_lib.load().clibd_gemm_bf16_nt_khole(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, int(k_hole[0]), int(k_hole[1]), C.byref(ep),
+                                                   _stream()), "gemm_bf16_nt_khole")
+        return
     check(_lib.load().clibd_gemm_bf16_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, C.byref(ep), _stream()), "gemm_bf16_nt")
 
 

@@ -77,6 +77,11 @@ typedef struct clibd_gemm_epilogue {
 
 int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                        const clibd_gemm_epilogue* ep, void* stream);
+/* Same product with the K range [hole_k0, hole_k0 + hole_len) of BOTH operands skipped (multiples of 64; 128x128 kernel):
+ * for an A whose column segment meets all-zero weights — the adapters' dt projection reads the q and v segments of dqkv
+ * and never touches the k segment (a third of the bytes of a latency/HBM-bound skinny product). */
+int clibd_gemm_bf16_nt_khole(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int hole_k0, int hole_len,
+                             const clibd_gemm_epilogue* ep, void* stream);
 
 /* bf16 transpose with zero padding: out[C, ld_out] (ld_out >= R) = in[R, C]^T; columns R..ld_out-1 zero.
  * Used to feed the weight-gradient GEMMs (contraction over the token dimension). */

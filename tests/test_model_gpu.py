@@ -427,7 +427,7 @@ def test_tower_streams_do_not_change_results(dev):
     a, b = res
     for k in range(3):
         assert torch.equal(a[k], b[k])
-    assert a[3] == b[3]
+    assert abs(a[3] - b[3]) <= 1e-6 * abs(b[3])   # the loss sum is a float-atomic reduction
     for n in a[4]:
         assert (a[4][n] - b[4][n]).abs().max().item() <= 1e-5 * (b[4][n].abs().max().item() + 1e-12), n
 

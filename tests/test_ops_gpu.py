@@ -263,6 +263,10 @@ def test_lora_pack_and_wgrad(ops, dev):
     dt_ref = torch.cat([dqkv[:, :H] @ bfr(b_q), dqkv[:, 2 * H :] @ bfr(b_v)], dim=1)
     assert rel_err(dt.cpu().float()[:, :8], dt_ref) < 4e-3
     assert torch.equal(dt.cpu().float()[:, 8:], torch.zeros(M, 8))
+    dt2 = torch.full((M, 16), float("nan"), dtype=BF16, device=dev)   # as the engine calls it: the k segment is skipped
+    ops.gemm_nt(dqkv.to(dev, BF16), w_dt, out_bf16=dt2, k_hole=(H, H))
+    torch.cuda.synchronize()
+    assert torch.equal(dt2, dt)
     dA_q, dA_v = torch.zeros((4, H), device=dev), torch.zeros((4, H), device=dev)
     dB_q, dB_v = torch.zeros((H, 4), device=dev), torch.zeros((H, 4), device=dev)
     ops.lora_wgrad(dqkv.to(dev, BF16), x.to(dev, BF16), t.to(dev, BF16), dt, dA_q, dA_v, dB_q, dB_v)
