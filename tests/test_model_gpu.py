@@ -457,3 +457,42 @@ def test_full_size_step_properties(dev):
     assert all(l == l and l < 1e4 for l in losses)
     assert abs(losses[0] - float(torch.log(torch.tensor(float(B))))) < 0.5   # near-uniform similarities at init
     assert losses[-1] < losses[0]
+
+
+def test_full_size_model_matches_oracle(dev):
+    """ViT-B/16 + BERT-base(133 tokens) at batch 16, random weights, LoRA B matrices non-zero: the full-size HIP path (long-
+    sequence attention, both GEMM kernels: 3152 token rows put the fc1 / fc2-dgrad products on the 256x256 kernel) against
+    the CPU oracle with the kernels' rounding points: embeddings, loss and the adapter / head gradients."""
+    from oracle import clibd_oracle as O
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import ClipLoss, CLIBDDNAEncoder, CLIBDImageEncoder, SimpleCLIP, create_vit, load_pre_trained_bioscan_bert
+
+    torch.manual_seed(11)
+    om = O.build_image_dna_model()
+    with torch.no_grad():
+        for n, p in om.named_parameters():
+            if "linear_b_" in n or ".w_b." in n:
+                p.normal_(0, 0.02)
+    model = SimpleCLIP(CLIBDImageEncoder(create_vit("vit_base_patch16_224"), r=4, num_classes=768),
+                       CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), r=4, num_classes=768), None)
+    model.load_state_dict(om.state_dict(), strict=True)
+    model = model.to(dev).eval()
+    B = 16
+    batch = synthetic_batch(B, torch.device("cpu"), seed=5, rank=0, with_text=False)
+    labels = torch.arange(B) % 11
+    with O.precision("bf16"):
+        oi, od, _, osc, _ = om(batch["image"], batch["dna"], None)
+        lo = O.contrastive_loss([oi, od, None], labels, osc)
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], torch.autograd.grad(lo, [p for _, p in ps], allow_unused=True)))
+    crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+    hi, hd, _, scale, _ = model(batch["image"].to(dev), batch["dna"].to(dev), None)
+    loss = crit(hi, hd, None, labels.to(dev), scale)
+    got = grads_named(model, loss)
+    model.join_streams()
+    assert (hi.cpu() - oi.detach()).abs().max().item() < 3e-3 and (hd.cpu() - od.detach()).abs().max().item() < 3e-3   # unit-norm rows
+    assert abs(float(loss.detach()) - float(lo.detach())) < 2e-3
+    allg = torch.cat([got[n].flatten() for n in sorted(got)])
+    allo = torch.cat([(torch.zeros_like(p) if go[n] is None else go[n]).flatten() for n, p in sorted(ps)])
+    assert sorted(got) == sorted(n for n, _ in ps)
+    assert cos(allg, allo) > 0.99 and rel(allg, allo) < 0.15   # 24 layers of bf16 rounding under the x14.3 temperature (DESIGN §4)
