@@ -7,8 +7,9 @@
 One "step" = forward of the ViT-B/16 + BarcodeBERT(BERT-base) towers with rank-4 LoRA adapters, L2-normalise,
 packed RCCL all-gather of the embeddings, soft-target InfoNCE over the global batch, backward (dgrad through the frozen
 bases, adapter + head gradients), flat-bucket gradient all-reduce and fused AdamW — on synthetic 224x224 images and
-660-nt barcodes (133 tokens), random-init weights of the reference's shapes.  Per-GPU batch 256 (BASELINE configs[1]
-at N=1, configs[2] = global 2048 at N=8): weak scaling.
+660-nt barcodes (133 tokens), random-init weights of the reference's shapes.  The GLOBAL batch is held at 2048
+(BASELINE.json `metric`: "global batch 2048, 1/2/4/8 GPU"): per-GPU batch = 2048 / N, so N=1 runs b=2048 on one GPU
+and N=8 is BASELINE configs[2] (b=256 per GPU) — strong scaling.  `--per-gpu-batch 256` gives BASELINE configs[1].
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of every
 GEMM launch in the timed region / their summed HIP-event durations on the launch stream, against the 2.5 PFLOP/s
@@ -37,10 +38,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--per-gpu-batch", type=int, default=256)
+    ap.add_argument("--global-batch", type=int, default=2048, help="held constant over N (BASELINE.json metric)")
+    ap.add_argument("--per-gpu-batch", type=int, default=None, help="override: fixed per-GPU batch (256 = BASELINE configs[1]); weak scaling")
     ap.add_argument("--tri-modal", action="store_true", help="add the BERT-small text tower (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="BASELINE configs[0]: batch 32")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps (median reported) after one warm-up")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-batch (PCIe-inclusive) side measurement")
     ap.add_argument("--no-gemm-timing", action="store_true")
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
     ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
@@ -96,33 +100,44 @@ class GemmTimer:
                   f"{2.0 * M * N * K * n / (t * 1e-3) / 1e12:7.1f} TF  {kinds}", file=sys.stderr, flush=True)
 
 
-def pmc_traffic():
+def pmc_traffic(per_gpu_batch: int):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic*.json,
-    written by tools/pmc_traffic.py; PMC counters cannot be collected from inside this process)."""
+    written by tools/pmc_traffic.py; PMC counters cannot be collected from inside this process).  Only a file measured on
+    THIS kernel source (csrc hash) and THIS per-GPU batch is quoted; anything else is reported as stale with traffic = null."""
     import glob
+
+    from clibd_amd.build import csrc_hash
 
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic*.json")))
     if not files:
-        return None, None
-    with open(files[-1]) as fh:
-        kernels = json.load(fh)["kernels"]
+        return None, None, "no PMC file"
+    cur = csrc_hash()
+    pick, why = None, None
+    for f in reversed(files):
+        with open(f) as fh:
+            d = json.load(fh)
+        if d.get("csrc_sha16") == cur and d.get("per_gpu_batch") == per_gpu_batch:
+            pick = (f, d)
+            break
+    if pick is None:
+        return None, os.path.basename(files[-1]), f"stale: no PMC file for csrc {cur} at per-GPU batch {per_gpu_batch}"
+    f, d = pick
     n = b = 0.0
-    for name, d in kernels.items():
+    for name, k in d["kernels"].items():
         if "gemm256" in name:
-            launches = max(d["launches_fetch_pass"], 1)
+            launches = max(k["launches_fetch_pass"], 1)
             n += launches
-            b += launches * d["hbm_bytes_per_launch"]
-    return (b / n if n else None), os.path.basename(files[-1])
+            b += launches * k["hbm_bytes_per_launch"]
+    return (b / n if n else None), os.path.basename(f), None
 
 
-def cpu_baseline(batch: int):
-    """Oracle (CPU restatement of the reference's fp32 path) training step: fwd + loss + bwd + AdamW, full-size towers."""
+def cpu_baseline(batch: int, steps: int):
+    """Oracle (CPU restatement of the reference's fp32 path, pinned to it by tests/golden) training step on BASELINE configs[0]:
+    fwd + loss + bwd + AdamW, full-size towers, batch 32, fp32.  One warm-up step (oneDNN primitive creation, allocator),
+    a one-step probe per candidate thread count, then the median of `steps` timed steps at the fastest count."""
     from oracle import clibd_oracle as O
 
-    # a few dozen threads is where this ~60 GFLOP/sample fp32 step stops scaling on the host (all 256 hardware threads
-    # of the GPU box made it >10x slower: tiny per-thread GEMM panels + NUMA traffic), so the thread count is capped
-    threads = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
+    ncpu = os.cpu_count() or 1
     torch.manual_seed(42)
     model = O.build_image_dna_model()
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
@@ -130,12 +145,34 @@ def cpu_baseline(batch: int):
     image = torch.rand(batch, 3, 224, 224, generator=g)
     dna = torch.cat([torch.zeros(batch, 1, dtype=torch.long), torch.randint(3, 1027, (batch, 132), generator=g)], dim=1)
     labels = torch.arange(batch)
-    t0 = time.time()
-    loss = O.train_step(model, opt, image, dna, labels)
-    dt = time.time() - t0
-    return {"value": batch / dt, "unit": "paired samples/s", "cores": threads, "kind": "port",
-            "sample": f"1 training step (fwd+loss+bwd+AdamW), batch {batch}, fp32, ViT-B/16 + BERT-base(133 tok) LoRA r=4, torch {torch.__version__} CPU, "
-                      f"{torch.get_num_threads()} threads, {dt:.1f} s, loss {float(loss):.4f}"}
+
+    def one():
+        t0 = time.perf_counter()
+        loss = O.train_step(model, opt, image, dna, labels)
+        return time.perf_counter() - t0, float(loss)
+
+    # thread count: all hardware threads of a 2-socket SMT host is NOT the fastest setting for this step (M = 6304-row GEMMs
+    # split into tiny per-thread panels + cross-socket traffic), so a few counts are probed, one step each, after a warm-up
+    cands = sorted({min(c, ncpu) for c in (32, 64, 128, ncpu)})
+    torch.set_num_threads(cands[0])
+    one()  # warm-up (not timed)
+    probe = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        probe[c] = one()[0]
+        if probe[c] > 60.0:
+            break
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    times, loss = [], 0.0
+    for _ in range(max(steps, 1)):
+        dt, loss = one()
+        times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    return {"value": batch / med, "unit": "paired samples/s", "cores": threads, "kind": "port", "host_cpu_count": ncpu,
+            "sample": f"BASELINE configs[0]: Image+DNA training step (fwd+loss+bwd+AdamW), batch {batch}, fp32, ViT-B/16 + BERT-base(133 tok) "
+                      f"LoRA r=4, torch {torch.__version__} CPU; 1 warm-up step, thread probe {{{', '.join(f'{c}: {t:.1f}s' for c, t in probe.items())}}}, "
+                      f"then median of {len(times)} steps at {threads} threads ({', '.join(f'{t:.1f}' for t in times)} s), loss {loss:.4f}"}
 
 
 def main():
@@ -162,7 +199,12 @@ def main():
     from clibd_amd.train import Trainer, scale_learning_rate
 
     torch.manual_seed(42)
-    b = args.per_gpu_batch
+    if args.per_gpu_batch is not None:
+        b, scaling = args.per_gpu_batch, "weak"
+    else:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} GPUs")
+        b, scaling = args.global_batch // world, "strong"
     image_enc = CLIBDImageEncoder(create_vit("vit_base_patch16_224"), r=4, num_classes=768)
     dna_enc = CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), r=4, num_classes=768)
     text_enc = CLIBDLanguageEncoder(load_pre_trained_bert()[1], r=4, num_classes=768) if args.tri_modal else None
@@ -235,6 +277,38 @@ def main():
         serial = timer.result()
         serial["steps"] = serial_steps
 
+    # Side measurement (never `value`): the same step with the batch handed over as HOST tensors, as the reference's loop does
+    # (epoch/train_epoch.py:26-32 `.to(device)` per step): pinned host buffers, async copies on the compute stream.
+    h2d = None
+    if not args.no_h2d:
+        host = {k: batch[k].cpu().pin_memory() for k in ("image", "dna", "labels")}
+        host_text = None if batch["text"] is None else {k: v.cpu().pin_memory() for k, v in batch["text"].items()}
+        nbytes = sum(t.numel() * t.element_size() for t in host.values()) + (0 if host_text is None else sum(t.numel() * t.element_size() for t in host_text.values()))
+        hsteps = min(args.steps, 5)
+
+        def host_step():
+            text_d = None if host_text is None else {k: v.to(dev, non_blocking=True) for k, v in host_text.items()}
+            return trainer.step(host["image"].to(dev, non_blocking=True), host["dna"].to(dev, non_blocking=True), text_d,
+                                host["labels"].to(dev, non_blocking=True))
+
+        host_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        th = time.perf_counter()
+        for _ in range(hsteps):
+            host_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        eh = torch.tensor([time.perf_counter() - th], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(eh, op=dist.ReduceOp.MAX)
+        h2d = {"value": b * world * hsteps / float(eh.item()), "unit": "paired samples/s", "ms_per_step": float(eh.item()) / hsteps * 1e3,
+               "steps": hsteps, "host_bytes_per_step_per_gpu": nbytes,
+               "note": "same step, batch copied from pinned host memory every step (PCIe-inclusive); reported beside `value`, never as it"}
+        del host, host_text
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         pairs_per_s = b * world * args.steps / elapsed
@@ -249,10 +323,12 @@ def main():
                         "timed_region = the same quantity with the towers overlapping on two streams exactly as in the timed region, where a "
                         "launch's duration includes CU sharing; step_frac = pairs/s x 117.6 GF / (n_gpus x peak), the whole step "
                         "against the MFMA roof"}
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src, stale = pmc_traffic(b)
         if traffic is not None:
             roof["traffic"] = traffic
             roof["traffic_source"] = f"profiles/{traffic_src}: mean HBM bytes per gemm256 launch (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate --pmc passes)"
+        else:
+            roof["traffic_note"] = stale
         if gemm:
             gsteps = gemm["steps"]
             roof.update(achieved=gemm["tflops"], frac=gemm["tflops"] / PEAK_BF16_TFLOPS, launches=gemm["launches"],
@@ -262,20 +338,23 @@ def main():
                 roof["timed_region"] = {"achieved": overlapped["tflops"], "gemm_ms_per_step": overlapped["total_ms"] / overlapped["steps"],
                                         "avg_launch_us": overlapped["total_ms"] / overlapped["launches"] * 1e3, "streams": 2}
         out = {
-            "metric": "paired samples/sec/step (I+D contrastive)" if not args.tri_modal else "triples/sec/step (I+D+T contrastive)",
+            "metric": (f"paired samples/sec/step (I+D contrastive), global batch {b * world}" if not args.tri_modal
+                       else f"triples/sec/step (I+D+T contrastive), global batch {b * world}"),
             "value": pairs_per_s, "unit": "paired samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights)",
-            "config": {"workload": "Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
+            "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
                                    ("FULL fine-tune (disable_lora)" if args.full_finetune else "LoRA r=4") + ", bf16 MFMA" +
                                    (" + BERT-small text tower" if args.tri_modal else ""),
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}", "image": "3x224x224", "dna_tokens": 133,
                        "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW"},
             "loss": loss_val, "roofline": roof,
         }
+        if h2d is not None:
+            out["h2d_inclusive"] = h2d
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)

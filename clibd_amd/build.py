@@ -24,6 +24,17 @@ ARCH = "gfx950"
 SOURCES = ["capi", "gemm", "gemm256", "layernorm", "attention", "lora", "elementwise", "loss", "topk", "paramgrad"]
 
 
+def csrc_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources and headers: ties a measurement file to the code it measured."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [INCLUDE / "clibd_hip.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):

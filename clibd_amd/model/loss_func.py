@@ -10,10 +10,15 @@ What the reference computes, restated once: with D = the ordered modality pairs 
     loss = (1 / |D|) * sum_{(a,b) in D}  mean_i CE_i(scale * a_i . B^T, T_i),      T_ij = [label_i == label_j].
 
 Each directed term is evaluated ONCE here.  Data-parallel (`ClipLoss`, world_size > 1): every rank owns the row
-block of its local samples against the all-gathered features (one packed RCCL all-gather forward, one
-reduce-scatter backward); the summed loss equals the reference's full N x N loss on every rank, and the feature
-gradients carry the same world_size factor that `torch.distributed.nn.all_gather`'s backward gives the
-reference, so wrapping the model in DDP (mean all-reduce) yields identical parameter gradients.
+block of its local samples against the all-gathered features.  Exchange steps: ONE packed RCCL all-gather forward
+(the L2-normalised embeddings of every modality AND the labels travel in one fp32 message: an int64 label is two
+fp32 slots, bit-copied), ONE reduce-scatter backward.  The summed loss equals the reference's full N x N loss on
+every rank (one scalar all-reduce; the trainer folds that scalar into its gradient all-reduce instead, see
+`reduce_loss_value`), and the feature gradients carry the same world_size factor that
+`torch.distributed.nn.all_gather`'s backward gives the reference, so DDP's mean all-reduce yields identical
+parameter gradients.  `gather_with_grad=False` (loss_func.py:99-105: only the local block of the rank's own full
+loss carries a gradient) is the same schedule without the world_size factor on the feature gradients; with
+`local_loss=True` on top, the reference's gathered buffers carry no gradient at all and only logit_scale learns.
 """
 from __future__ import annotations
 
@@ -70,10 +75,11 @@ def _dist_on(world_size: int) -> bool:
 
 
 class _SoftCEFn(torch.autograd.Function):
-    """loss = mean over directed pairs of the row-block soft-target CE; see module docstring."""
+    """loss = mean over directed pairs of the row-block soft-target CE; see module docstring.
+    feat_grad: 0 = world_size x dL/df (gather_with_grad=True), 1 = dL/df (gather_with_grad=False), 2 = none (+ local_loss)."""
 
     @staticmethod
-    def forward(ctx, pairs, labels, scale, rank, world, *feats):
+    def forward(ctx, pairs, labels, scale, rank, world, reduce_value, feat_grad, *feats):
         dev = feats[0].device
         b, D = feats[0].shape
         M = len(feats)
@@ -84,12 +90,14 @@ class _SoftCEFn(torch.autograd.Function):
             invs.append(inv)
         labels = labels.detach().to(torch.int64).contiguous()
         if world > 1:
-            packed = torch.stack(ys, dim=0)                             # [M, b, D]
-            gathered = torch.empty((world, M, b, D), dtype=F32, device=dev)
-            dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1))   # flat views: valid for RCCL and gloo alike
-            all_y = [gathered[:, m].reshape(world * b, D).contiguous() for m in range(M)]
-            all_labels = torch.empty((world * b,), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(all_labels, labels)
+            nf = M * b * D
+            packed = torch.empty((nf + 2 * b,), dtype=F32, device=dev)     # [M, b, D] embeddings | b int64 labels as 2b fp32 slots
+            torch.stack(ys, dim=0, out=packed[:nf].view(M, b, D))
+            packed[nf:].copy_(labels.view(F32))
+            gathered = torch.empty((world, nf + 2 * b), dtype=F32, device=dev)
+            dist.all_gather_into_tensor(gathered.view(-1), packed)         # the ONE forward collective (flat views: RCCL and gloo alike)
+            all_y = [gathered[:, m * b * D : (m + 1) * b * D].reshape(world * b, D).contiguous() for m in range(M)]
+            all_labels = gathered[:, nf:].contiguous().view(torch.int64).view(-1)
             row0 = rank * b
         else:
             all_y, all_labels, row0 = ys, labels, 0
@@ -102,9 +110,9 @@ class _SoftCEFn(torch.autograd.Function):
             ops.softce_rows_fwd(ys[ia], all_y[ib], all_labels, row0, scale_t, loss_sum, ws)
             wss.append(ws)
         loss = loss_sum / float(len(pairs) * N)
-        if world > 1:
+        if world > 1 and reduce_value:
             dist.all_reduce(loss)
-        ctx.pairs, ctx.rank, ctx.world, ctx.dims = pairs, rank, world, (b, N, D, M, row0)
+        ctx.pairs, ctx.rank, ctx.world, ctx.dims, ctx.feat_grad = pairs, rank, world, (b, N, D, M, row0), feat_grad
         ctx.saved = (ys, invs, all_y, all_labels, scale_t, wss)
         ctx.scale_needs_grad = scale.requires_grad
         return loss.reshape(())
@@ -116,7 +124,8 @@ class _SoftCEFn(torch.autograd.Function):
         pairs, world = ctx.pairs, ctx.world
         dev = ys[0].device
         # world factor: mirrors the reference, where reduce-scatter(SUM) of W identical full-loss gradients hands every
-        # local feature W x dL/df and DDP's mean all-reduce divides it back (SURVEY §5 "scale semantics")
+        # local feature W x dL/df and DDP's mean all-reduce divides it back (SURVEY §5 "scale semantics"); logit_scale:
+        # every rank of the reference holds the FULL dL/dscale, here W x the rank's partial, equal under the mean
         weight = float(world) / float(len(pairs) * N)
         wscale = dloss.detach().to(F32).reshape(1).contiguous()
         dlocal = torch.zeros((M, b, D), dtype=F32, device=dev)
@@ -124,17 +133,22 @@ class _SoftCEFn(torch.autograd.Function):
         dscale = torch.zeros((1,), dtype=F32, device=dev)
         for (ia, ib), ws in zip(pairs, wss):
             ops.softce_rows_bwd(all_labels, b, N, D, row0, scale_t, weight, dlocal[ia], dall[ib], dscale, ws, weight_scale=wscale)
+        ctx.saved = None
+        ds = dscale.reshape(()) if ctx.scale_needs_grad else None
+        if ctx.feat_grad == 2:
+            return (None, None, ds, None, None, None, None, *([None] * M))
         if world > 1:
             send = dall.view(M, world, b, D).permute(1, 0, 2, 3).contiguous()   # [W, M, b, D]
             recv = torch.empty((M, b, D), dtype=F32, device=dev)
-            dist.reduce_scatter_tensor(recv.view(-1), send.view(-1))
+            dist.reduce_scatter_tensor(recv.view(-1), send.view(-1))               # the ONE backward collective
             dlocal = dlocal + recv
+            if ctx.feat_grad == 1:
+                dlocal = dlocal / float(world)
         grads = [ops.l2norm_bwd(dlocal[m], ys[m], invs[m]) for m in range(M)]
-        ctx.saved = None
-        return (None, None, dscale.reshape(()) if ctx.scale_needs_grad else None, None, None, *grads)
+        return (None, None, ds, None, None, None, None, *grads)
 
 
-def _contrastive(features, labels, logit_scale, rank, world, bind_to=None, no_image_text_loss=False):
+def _contrastive(features, labels, logit_scale, rank, world, bind_to=None, no_image_text_loss=False, reduce_value=True, feat_grad=0):
     present = [(i, f) for i, f in enumerate(features) if f is not None]
     if len(present) < 2:
         raise ValueError("Too less element for calculating the contrastive loss.")
@@ -150,7 +164,7 @@ def _contrastive(features, labels, logit_scale, rank, world, bind_to=None, no_im
             raise ValueError("all modality features must be [batch, dim] with equal shapes")
     if not torch.is_tensor(logit_scale):
         logit_scale = torch.tensor(float(logit_scale), dtype=F32, device=dev)
-    return _SoftCEFn.apply(pairs, labels.to(dev), logit_scale.to(dev), rank, world, *feats)
+    return _SoftCEFn.apply(pairs, labels.to(dev), logit_scale.to(dev), rank, world, reduce_value, feat_grad, *feats)
 
 
 class ContrastiveLoss(nn.Module):
@@ -196,8 +210,6 @@ class ClipLoss(nn.Module):
         _check_criterion(criterion)
         if use_horovod:
             raise NotImplementedError("horovod is a dead branch in every shipped reference config (SURVEY §2b C6)")
-        if local_loss:
-            raise NotImplementedError("local_loss=True is not used by any shipped reference config")
         self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
         self.rank, self.world_size, self.use_horovod = rank, world_size, use_horovod
         self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss()
@@ -205,13 +217,18 @@ class ClipLoss(nn.Module):
         self.labels = {}
         self.bind_to = bind_to
         self.no_image_text_loss = no_image_text_loss
+        # True: every rank returns the full-batch loss value (one scalar all-reduce; the reference's contract).  A trainer
+        # that all-reduces gradients anyway may set it False, take the rank's PARTIAL sum (partials add up to the full loss)
+        # and fold it into that all-reduce (clibd_amd.train.Trainer does): gradients do not depend on the returned value.
+        self.reduce_loss_value = True
 
     def forward(self, image_features, dna_features, text_features, labels, logit_scale, output_dict=False):
         world = self.world_size if _dist_on(self.world_size) else 1
         if self.world_size > 1 and world == 1:
             raise RuntimeError("ClipLoss(world_size>1) needs an initialised torch.distributed process group")
+        feat_grad = 0
         if world > 1 and not self.gather_with_grad:
-            raise NotImplementedError("gather_with_grad=False is not used by any shipped reference config (SURVEY §2b C3)")
+            feat_grad = 2 if self.local_loss else 1   # loss_func.py:99-105
         total = _contrastive([image_features, dna_features, text_features], labels, logit_scale, self.rank, world, self.bind_to,
-                             self.no_image_text_loss)
+                             self.no_image_text_loss, reduce_value=self.reduce_loss_value, feat_grad=feat_grad)
         return {"contrastive_loss": total} if output_dict else total

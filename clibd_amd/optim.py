@@ -13,6 +13,8 @@ from . import ops
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    AUX_SLOTS = 64  # spare fp32 slots behind the gradients in the same allocation: scalars that ride along the gradient all-reduce
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         params = [p for p in params if p.requires_grad]
         if not params:
@@ -22,14 +24,17 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW supports a single parameter group")
         ps = self.param_groups[0]["params"]
         dev = ps[0].device
-        if not all(p.is_cuda and p.dtype == torch.float32 and p.device == dev for p in ps):
-            raise ValueError("FusedAdamW: parameters must be fp32 tensors on one GPU")
+        self._check_params(ps, dev)
         align = 64  # every parameter view starts on a 256-byte boundary (16-byte vector loads in the cast / pack kernels)
         pad = lambda k: (k + align - 1) // align * align
         n = sum(pad(p.numel()) for p in ps)
         self._offsets = []
         self.flat_p = torch.zeros((n,), dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros((n,), dtype=torch.float32, device=dev)
+        # gradients + AUX_SLOTS trailing scalars (e.g. the rank's partial loss value) = ONE all-reduce message (`flat_comm`);
+        # the optimizer kernel only ever sees the first n elements (`flat_g`)
+        self.flat_comm = torch.zeros((n + self.AUX_SLOTS,), dtype=torch.float32, device=dev)
+        self.flat_g = self.flat_comm[:n]
+        self.aux = self.flat_comm[n:]
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         off = 0
@@ -44,9 +49,14 @@ class FusedAdamW(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_scale = 1.0  # e.g. 1/world_size after a SUM all-reduce (DDP's mean)
 
+    @staticmethod
+    def _check_params(ps, dev):
+        if not all(p.is_cuda and p.dtype == torch.float32 and p.device == dev for p in ps):
+            raise ValueError("FusedAdamW: parameters must be fp32 tensors on one GPU")
+
     def zero_grad(self, set_to_none: bool = False):
         # gradients stay resident as views of the flat bucket (autograd accumulates in place)
-        self.flat_g.zero_()
+        self.flat_comm.zero_()
         for p, off in zip(self.param_groups[0]["params"], self._offsets):
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:

@@ -25,18 +25,45 @@ def scale_learning_rate(lr, batch_size, base_batch_size=500, world_size=1):
     return lr * batch_size * world_size / base_batch_size
 
 
+def _gradient_reachable(model, fix_temperature) -> list:
+    """Trainable parameters the step can actually produce a gradient for.  torch.optim.AdamW (the reference's optimizer,
+    train_cl.py:221) skips parameters whose .grad is None — logit_scale under fix_temperature, BertModel.pooler.* and the
+    replaced MLM decoder's orphaned cls.predictions.bias never receive one — while a flat-bucket update would weight-decay
+    them; they are therefore kept out of the bucket and stay exactly as initialised / loaded, as in the reference."""
+    reach = set()
+    for enc in (model.image_encoder, model.dna_encoder, model.language_encoder):
+        if enc is not None and hasattr(enc, "tower"):
+            reach.update(id(p) for p in enc.tower().trainable_params())
+    if fix_temperature is None:
+        reach.add(id(model.logit_scale))
+    return [p for p in model.parameters() if p.requires_grad and id(p) in reach]
+
+
 class Trainer:
     def __init__(self, model, lr: float = 1e-3, world_size: int = 1, rank: int = 0, all_gather: bool = True,
-                 fix_temperature: Optional[float] = None, bind_to=None, no_image_text_loss=False, weight_decay: float = 1e-2):
+                 fix_temperature: Optional[float] = None, bind_to=None, no_image_text_loss=False, weight_decay: float = 1e-2,
+                 broadcast_parameters: bool = True):
         self.model, self.world_size, self.rank = model, world_size, rank
         self.fix_temperature = fix_temperature
-        self.optimizer = FusedAdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+        self.optimizer = FusedAdamW(_gradient_reachable(model, fix_temperature), lr=lr, weight_decay=weight_decay)
         if all_gather:
             self.criterion = ClipLoss(local_loss=False, gather_with_grad=True, rank=rank, world_size=world_size,
                                       criterion=torch.nn.CrossEntropyLoss(), bind_to=bind_to, no_image_text_loss=no_image_text_loss)
+            # the rank's partial loss rides in a spare slot of the gradient all-reduce: no separate scalar collective
+            self.criterion.reduce_loss_value = world_size == 1
         else:
             self.criterion = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)
         self.optimizer.grad_scale = 1.0 / world_size  # SUM all-reduce then mean: what DDP does (train_cl.py:204)
+        if world_size > 1 and broadcast_parameters:
+            # DDP(model) broadcasts rank 0's parameters and buffers at construction (train_cl.py:204): adapters, heads and the
+            # replaced decoder are randomly initialised per process.  Trainable values live in the flat bucket (one message);
+            # frozen weights and buffers follow tensor by tensor (once, at start-up).
+            dist.broadcast(self.optimizer.flat_p, src=0)
+            own = {id(p) for p in self.optimizer.param_groups[0]["params"]}
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    if id(t) not in own:
+                        dist.broadcast(t.data, src=0)
         # let the towers accumulate parameter gradients straight into the optimizer's flat bucket
         sink = {id(p): p.grad for p in self.optimizer.param_groups[0]["params"]}
         for enc in (model.image_encoder, model.dna_encoder, model.language_encoder):
@@ -44,7 +71,9 @@ class Trainer:
                 enc.tower().grad_sink = sink
 
     def step(self, image, dna, text, labels) -> torch.Tensor:
-        """forward (all towers) -> loss -> backward -> gradient all-reduce -> AdamW.  Returns the (device) loss."""
+        """forward (all towers) -> loss -> backward -> gradient all-reduce -> AdamW.  Returns the (device) loss.
+        Collectives per step at world_size > 1: one packed all-gather (embeddings + labels), one reduce-scatter (feature
+        gradients), one all-reduce (flat gradient bucket + the loss value)."""
         self.optimizer.zero_grad()
         image_out, dna_out, text_out, logit_scale, _ = self.model(image, dna, text)
         if self.fix_temperature is not None:
@@ -53,10 +82,16 @@ class Trainer:
         loss.backward()
         if hasattr(self.model, "join_streams"):
             self.model.join_streams()  # tower backward passes ran on the towers' own streams
+        loss = loss.detach()
         if self.world_size > 1:
-            dist.all_reduce(self.optimizer.flat_g)
+            fold = not getattr(self.criterion, "reduce_loss_value", True)
+            if fold:
+                self.optimizer.aux[0:1].copy_(loss.reshape(1))     # partial sums add up to the full-batch loss
+            dist.all_reduce(self.optimizer.flat_comm)
+            if fold:
+                loss = self.optimizer.aux[0].clone()
         self.optimizer.step()
-        return loss.detach()
+        return loss
 
 
 def train_epoch(total_epochs, epoch, dataloader, trainer: Trainer, device, scheduler=None, log_every: int = 0):

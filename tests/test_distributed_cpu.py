@@ -114,3 +114,155 @@ def test_directed_pairs_follow_reference_filters():
     assert len(_directed_pairs([0, 1, 2], None, False)) == 6
     assert _directed_pairs([0, 1, 2], 1, False) == [(0, 1), (1, 0), (1, 2), (2, 1)]
     assert (0, 2) not in _directed_pairs([0, 1, 2], None, True) and len(_directed_pairs([0, 1, 2], None, True)) == 4
+
+
+# ------------------------------------------------------------------------------- reference goldens at world_size 2
+def _golden_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clibd_amd.model import loss_func
+
+        loss_func.ops = _FakeOps
+        gold = torch.load(os.path.join(ROOT, "tests", "golden", "loss_w2_golden.pt"), map_location="cpu", weights_only=False)
+        ok = gold["world_size"] == world
+        worst = 0.0
+        for c in gold["cases"]:
+            N = c["labels"].numel()
+            b = N // world
+            sl = slice(rank * b, (rank + 1) * b)
+            feats = [None if f is None else f[sl].clone().requires_grad_(True) for f in c["features"]]
+            ls = c["log_scale"].clone().requires_grad_(True)
+            crit = loss_func.ClipLoss(local_loss=False, gather_with_grad=c["gather_with_grad"], rank=rank, world_size=world,
+                                      criterion=torch.nn.CrossEntropyLoss(), bind_to=c["bind_to"], no_image_text_loss=c["no_image_text_loss"])
+            loss = crit(feats[0], feats[1], feats[2], c["labels"][sl], ls.exp())
+            present = [f for f in feats if f is not None]
+            grads = torch.autograd.grad(loss, present + [ls])
+            ref = c["per_rank"][rank]
+            ok = ok and abs(float(loss) - float(ref["loss"])) < 5e-6
+            for g_, r_ in zip(grads[:-1], ref["grads"][:-1]):      # local feature gradients: identical per rank
+                err = float((g_ - r_).abs().max() / (r_.abs().max() + 1e-30))
+                worst = max(worst, err)
+                ok = ok and err < 1e-4
+            # logit_scale: the reference holds the full gradient on every rank; here W x the rank's partial, equal under the mean
+            gs = grads[-1].clone()
+            dist.all_reduce(gs)
+            ok = ok and abs(float(gs) / world - float(ref["grads"][-1])) < 1e-4 * max(1.0, abs(float(ref["grads"][-1])))
+        out[rank] = (bool(ok), worst)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cliploss_world2_matches_reference_goldens():
+    """tests/golden/loss_w2_golden.pt = the reference's own ClipLoss on two gloo ranks (make_golden_r2.py): loss value, local
+    feature gradients (gather_with_grad True and False) and the logit-scale gradient, per rank."""
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_golden_worker, args=(2, 29621, out), nprocs=2, join=True)
+    assert all(v[0] for v in dict(out).values()), dict(out)
+
+
+# ------------------------------------------------------------------------------- Trainer: flat bucket + 1/W + broadcast
+class _ToyTower:
+    grad_sink = None
+
+    def __init__(self, lin):
+        self.lin = lin
+
+    def trainable_params(self):
+        return list(self.lin.parameters())
+
+
+class _ToyEnc(torch.nn.Module):
+    def __init__(self, din, dout):
+        super().__init__()
+        self.lin = torch.nn.Linear(din, dout)
+        self.unused = torch.nn.Parameter(torch.ones(3))   # never receives a gradient: must not be weight-decayed
+        self._tower = _ToyTower(self.lin)
+
+    def tower(self):
+        return self._tower
+
+    def forward(self, x):
+        return self.lin(x)
+
+
+class _ToyCLIP(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.image_encoder, self.dna_encoder, self.language_encoder = _ToyEnc(12, 16), _ToyEnc(9, 16), None
+        self.logit_scale = torch.nn.Parameter(torch.tensor(1.5))
+
+    def forward(self, image, dna, text):
+        n = torch.nn.functional.normalize
+        return n(self.image_encoder(image), dim=-1), n(self.dna_encoder(dna), dim=-1), None, self.logit_scale.exp(), None
+
+
+def _cpu_adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """torch.optim.AdamW arithmetic on the flat bucket (the contract of clibd_adamw_step, include/clibd_hip.h)."""
+    with torch.no_grad():
+        gg = g * grad_scale
+        p.mul_(1 - lr * weight_decay)
+        m.mul_(beta1).add_(gg, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        p.addcdiv_(m / (1 - beta1 ** step), (v / (1 - beta2 ** step)).sqrt().add_(eps), value=-lr)
+
+
+def _trainer_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clibd_amd import optim, train
+        from clibd_amd.model import loss_func
+        from oracle import clibd_oracle as O
+
+        loss_func.ops = _FakeOps
+        optim.ops.adamw_step = _cpu_adamw_step
+        optim.FusedAdamW._check_params = staticmethod(lambda ps, dev: None)
+        torch.manual_seed(100 + rank)            # different initialisation per rank: the trainer must broadcast rank 0's
+        model = _ToyCLIP()
+        torch.manual_seed(100)
+        ref_model = _ToyCLIP()                    # == rank 0's initialisation
+        b = 5
+        g = torch.Generator().manual_seed(3)
+        image, dna = torch.randn(world * b, 12, generator=g), torch.randn(world * b, 9, generator=g)
+        labels = torch.tensor([0, 1, 2, 2, 4, 5, 6, 0, 8, 9])
+        tr = train.Trainer(model, lr=1e-2, world_size=world, rank=rank, all_gather=True)
+        ropt = torch.optim.AdamW([p for n, p in ref_model.named_parameters() if "unused" not in n], lr=1e-2, weight_decay=1e-2)
+        sl = slice(rank * b, (rank + 1) * b)
+        ok = True
+        for _ in range(3):
+            loss = tr.step(image[sl], dna[sl], None, labels[sl])
+            ropt.zero_grad()
+            i, d, _, sc, _ = ref_model(image, dna, None)
+            rl = O.contrastive_loss([i, d, None], labels, sc)
+            rl.backward()
+            ropt.step()
+            ok = ok and abs(float(loss) - float(rl)) < 1e-5           # every rank reports the full-batch loss
+        for (n, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
+            ok = ok and torch.allclose(p, q, rtol=1e-4, atol=1e-6)
+        ok = ok and torch.equal(model.image_encoder.unused, torch.ones(3))   # no gradient -> untouched (torch.optim.AdamW skips it)
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_world2_gloo_matches_full_batch_adamw():
+    """Trainer.step at world_size 2 (gloo, device ops replaced by torch statements of their contracts): parameter broadcast
+    from rank 0, flat-bucket SUM all-reduce + 1/W scale, the loss value folded into that all-reduce, AdamW — against one
+    process training the same toy towers on the full batch with torch.optim.AdamW and the oracle's loss
+    (reference: DDP + AdamW, scripts/train_cl.py:204,221)."""
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trainer_worker, args=(2, 29622, out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}
