@@ -57,6 +57,8 @@ def _compile_one(name: str, report: bool) -> tuple[str, str]:
     src = CSRC / f"{name}.hip"
     obj = OBJ / f"{name}.o"
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", str(src), "-o", str(obj)]
+    if os.environ.get("CLIBD_GEMM_DIAG") == "1":
+        cmd.append("-DCLIBD_GEMM_DIAG")  # tools/gemm_stamps.py: s_memtime stamps + start-up skew knob (never in the product build)
     if report:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -116,6 +118,10 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--report", action="store_true", help="print per-kernel register/LDS usage")
+    ap.add_argument("--diag", action="store_true", help="diagnostic build of gemm256 (stamps + skew knob); forces a rebuild")
     a = ap.parse_args()
+    if a.diag:
+        os.environ["CLIBD_GEMM_DIAG"] = "1"
+        a.force = True
     build(force=a.force, report=a.report)
     sys.exit(0)

@@ -40,6 +40,18 @@ def remove_module_from_state_dict(state_dict: dict) -> dict:
     return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
 
 
+def drop_hf_buffer_keys(state_dict: dict) -> dict:
+    """The reference pins transformers==4.29.2 (requirements.txt:6), whose BertEmbeddings registers `position_ids` (and
+    `token_type_ids`) as PERSISTENT buffers: best.pth / last.pth of both BERT towers carry
+    `...embeddings.position_ids` / `...embeddings.token_type_ids` entries that are not parameters (arange / zeros, recomputed
+    here).  They are dropped before the strict load, as load_pre_trained_bioscan_bert does for the BarcodeBERT pretrain file."""
+    return {k: v for k, v in state_dict.items() if not (k.endswith("embeddings.position_ids") or k.endswith("embeddings.token_type_ids"))}
+
+
+def _normalise(state_dict: dict) -> dict:
+    return drop_hf_buffer_keys(update_checkpoint_param_names(remove_module_from_state_dict(state_dict)))
+
+
 def handle_local_ckpt_path(args) -> str:
     mc = args.model_config
     if hasattr(mc, "ckpt_path"):
@@ -55,8 +67,7 @@ def handle_local_ckpt_path(args) -> str:
 
 def load_reference_checkpoint(model: torch.nn.Module, path: str, strict: bool = True):
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    ckpt = update_checkpoint_param_names(remove_module_from_state_dict(ckpt))
-    return model.load_state_dict(ckpt, strict=strict)
+    return model.load_state_dict(_normalise(ckpt), strict=strict)
 
 
 def initialize_model_and_load_from_checkpoint(args, device=None):
@@ -86,7 +97,7 @@ def save_training_state(path: str, model: torch.nn.Module, optimizer=None, sched
 
 def load_training_state(path: str, model: torch.nn.Module, optimizer=None, scheduler=None):
     state = torch.load(path, map_location="cpu", weights_only=False)
-    model.load_state_dict(update_checkpoint_param_names(remove_module_from_state_dict(state["model"])))
+    model.load_state_dict(_normalise(state["model"]))
     if optimizer is not None and "optimizer" in state:
         o = state["optimizer"]
         optimizer.exp_avg.copy_(o["exp_avg"])

@@ -241,8 +241,8 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         ISSUE(1, 3, 1); __builtin_amdgcn_sched_barrier(0);                   \
     } while (0)
 
-    // ---- optional start-up skew (diagnostic knob) and the first tile's prologue: L_0 .. L_7 = K-tiles 0 and 1
-    if (skew_ticks > 0) {
+    // ---- optional start-up skew (diagnostic build only) and the first tile's prologue: L_0 .. L_7 = K-tiles 0 and 1
+    if (DIAG && skew_ticks > 0) {
         const int cls = (blockIdx.x >> 3) & 3;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)cls * skew_ticks) __builtin_amdgcn_s_sleep(8);
@@ -415,16 +415,24 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     }
 }
 
-static long long* g_stamp_buffer = nullptr;  // diagnostic only (tools/), never set on the product path
-
+// The product library has no mutable state.  The s_memtime stamp buffer and the start-up skew knob of
+// tools/gemm_stamps.py exist only in a diagnostic build: hipcc -DCLIBD_GEMM_DIAG (python -m clibd_amd.build --diag).
+#ifdef CLIBD_GEMM_DIAG
+static long long* g_stamp_buffer = nullptr;
 static int skew_env_value() {
     static const int v = [] { const char* e = getenv("CLIBD_GEMM_SKEW"); return e ? atoi(e) : 0; }();
     return v;
 }
+#define CLIBD_DIAG_KERNEL(KIND) (const void*)gemm256_bf16_nt_kernel<KIND, false, true, true>
+#else
+static constexpr long long* g_stamp_buffer = nullptr;
+static int skew_env_value() { return 0; }
+#define CLIBD_DIAG_KERNEL(KIND) (const void*)nullptr
+#endif
 
 static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
 #define K256(KIND)                                                                                                    \
-    (diag ? (const void*)gemm256_bf16_nt_kernel<KIND, false, true, true>                                              \
+    (diag ? CLIBD_DIAG_KERNEL(KIND)                                                                                   \
           : lora ? (bias ? (const void*)gemm256_bf16_nt_kernel<KIND, true, true, false>                               \
                          : (const void*)gemm256_bf16_nt_kernel<KIND, true, false, false>)                             \
                  : (bias ? (const void*)gemm256_bf16_nt_kernel<KIND, false, true, false>                              \
@@ -452,9 +460,10 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     static const bool attr_ok = [] {
         bool ok = true;
         for (int v = 0; v < 5; ++v)
-            for (int k = 0; k < EPI_NUM_KINDS; ++k)
-                ok = ok && hipFuncSetAttribute(kernel_ptr(k, (v & 1) != 0, (v & 2) != 0, v == 4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               G256_LDS) == hipSuccess;
+            for (int k = 0; k < EPI_NUM_KINDS; ++k) {
+                const void* fn = kernel_ptr(k, (v & 1) != 0, (v & 2) != 0, v == 4);
+                if (fn != nullptr) ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+            }
         return ok;
     }();
     if (!attr_ok) return false;
@@ -539,5 +548,7 @@ int gemm256_splitk_launch(const GemmParams& p0, float* partials, size_t partials
 
 }  // namespace clibd
 
-// Diagnostic hook for tools/: device buffer of [256 workgroups][16 tiles][2 wave groups][8] int64 s_memtime stamps.
+#ifdef CLIBD_GEMM_DIAG
+// Diagnostic hook for tools/ (diagnostic build only): device buffer of [256 workgroups][16 tiles][2 wave groups][8] int64 stamps.
 extern "C" void clibd_debug_set_gemm_stamps(void* device_buffer) { clibd::g_stamp_buffer = (long long*)device_buffer; }
+#endif

@@ -119,7 +119,8 @@ def load_clip_model(args, device=None):
     """Factory with the reference's flag semantics (`args.model_config.*`, simple_clip.py:100-246), including its quirks:
     `using_open_clip` overwrites `disable_lora` (simple_clip.py:114-116); the image tower treats `lora_layer=[]` as "all
     layers" while the BERT towers treat it as "none" (SURVEY §3.4).  Pretrained weights come from LOCAL checkpoints only
-    (`args.bioscan_bert_checkpoint`, `args.model_config.image.vit_checkpoint`); absent ones mean random initialisation."""
+    (`args.bioscan_bert_checkpoint`, `args.model_config.image.image_encoder_trained_with_simclr_style_ckpt_path`,
+    `args.model_config.image.vit_checkpoint`); absent ones mean random initialisation."""
     mc = args.model_config
     disable_lora = bool(_get(mc, "disable_lora", False))
     if hasattr(mc, "using_open_clip"):
@@ -136,9 +137,15 @@ def load_clip_model(args, device=None):
         if _get(image_cfg, "input_type", "image") != "image":
             raise NotImplementedError("pre-extracted feature (MLP) towers are out of scope (SURVEY §2 row 8)")
         vit = create_vit(_get(image_cfg, "pre_train_model", "vit_base_patch16_224"))
-        ck = _get(image_cfg, "vit_checkpoint")
+        # reference key (simple_clip.py:154-165): a SimCLR-style ViT checkpoint {"state_dict": ...}, DDP prefix stripped, loaded
+        # STRICTLY into the timm-shaped body; `vit_checkpoint` is this package's alias for a plain local timm state dict
+        # (the reference downloads `pretrained=True` weights instead, which needs the network)
+        ck = _get(image_cfg, "image_encoder_trained_with_simclr_style_ckpt_path")
         if ck:
-            sd = torch.load(ck, map_location="cpu", weights_only=False)
+            sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
+            vit.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()})
+        elif _get(image_cfg, "vit_checkpoint"):
+            sd = torch.load(_get(image_cfg, "vit_checkpoint"), map_location="cpu", weights_only=False)
             sd = sd.get("state_dict", sd)
             vit.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}, strict=False)
         image_encoder = CLIBDImageEncoder(vit_model=vit, r=4, num_classes=out_dim, lora_layer=[] if disable_lora else None)

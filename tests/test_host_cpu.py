@@ -110,3 +110,43 @@ def test_scale_learning_rate():
     from clibd_amd.train import scale_learning_rate
 
     assert scale_learning_rate(0.001, 500, world_size=4) == pytest.approx(0.004)
+
+
+def test_reference_checkpoint_with_hf_position_id_buffers_loads_strict(tmp_path):
+    """transformers==4.29.2 (the reference's pin) stores `embeddings.position_ids` as a persistent buffer in best.pth / last.pth
+    of both BERT towers; the strict load must drop them."""
+    from clibd_amd.checkpoint import load_reference_checkpoint, load_training_state
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, BertModel, CLIBDDNAEncoder, CLIBDLanguageEncoder, SimpleCLIP
+
+    tiny = dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128)
+    m = SimpleCLIP(None, CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, **tiny)), 4, 32),
+                   CLIBDLanguageEncoder(BertModel(BertConfigLite(vocab_size=100, **tiny)), 4, 32))
+    ck = {"module." + k: v.clone() for k, v in m.state_dict().items()}
+    ck["module.dna_encoder.base_dna_encoder.bert.embeddings.position_ids"] = torch.arange(512)[None]
+    ck["module.language_encoder.base_language_encoder.embeddings.position_ids"] = torch.arange(512)[None]
+    ck["module.language_encoder.base_language_encoder.embeddings.token_type_ids"] = torch.zeros(1, 512, dtype=torch.long)
+    path = tmp_path / "last.pth"
+    torch.save(ck, path)
+    res = load_reference_checkpoint(m, str(path))          # strict=True
+    assert not res.missing_keys and not res.unexpected_keys
+    torch.save({"model": ck, "epoch": 3}, tmp_path / "state.pth")
+    assert load_training_state(str(tmp_path / "state.pth"), m) == 3
+
+
+def test_load_clip_model_accepts_the_reference_simclr_checkpoint_key(tmp_path):
+    """model_config.image.image_encoder_trained_with_simclr_style_ckpt_path (reference simple_clip.py:154-165): {"state_dict": ...}
+    with a DDP prefix, loaded strictly into the ViT body."""
+    from clibd_amd.model import create_vit, load_clip_model
+
+    vit = create_vit("vit_small_patch16_224")
+    with torch.no_grad():
+        vit.cls_token.fill_(0.125)
+    path = tmp_path / "simclr.pth"
+    torch.save({"state_dict": {"module." + k: v for k, v in vit.state_dict().items()}}, path)
+    a = _args(output_dim=128, image=types.SimpleNamespace(input_type="image", pre_train_model="vit_small_patch16_224",
+                                                          image_encoder_trained_with_simclr_style_ckpt_path=str(path)))
+    m = load_clip_model(a)
+    assert float(m.image_encoder.base_image_encoder.cls_token.mean()) == 0.125
+    torch.save({"state_dict": {"module.bogus": torch.zeros(1)}}, path)
+    with pytest.raises(RuntimeError):
+        load_clip_model(a)

@@ -235,6 +235,138 @@ def test_full_step_matches_reference(dev, tag, use_text):
     assert rel(allg, allr) < 0.1 and cos(allg, allr) > 0.995
 
 
+# ------------------------------------------------------------------------------------------ BASELINE configs[3]: real-size text tower
+def _bert_small_pair(dev, seed=21):
+    """prajjwal1/bert-small shapes (language_encoder.py:12-20: L=4, H=512, A=8, FF=2048, vocab 30522), random weights, LoRA B
+    non-zero, identical state dicts in the oracle and the HIP module."""
+    from oracle import clibd_oracle as O
+    from clibd_amd.model import BertConfigLite, BertModel, CLIBDLanguageEncoder
+    from clibd_amd.model.language_encoder import BERT_SMALL
+
+    torch.manual_seed(seed)
+    om = O.LanguageEncoder(O.BertModel(vocab=30522, hidden=512, layers=4, heads=8, ff=2048), r=4, num_classes=768)
+    with torch.no_grad():
+        for n, p in om.named_parameters():
+            if p.dim() >= 2 and "embeddings" not in n:
+                p.normal_(0, 0.03)
+            if ".w_b." in n:
+                p.normal_(0, 0.02)
+    m = CLIBDLanguageEncoder(BertModel(BertConfigLite(**BERT_SMALL)), r=4, num_classes=768)
+    m.load_state_dict(om.state_dict(), strict=True)
+    return om.eval(), m.to(dev).eval()
+
+
+def _text_batch(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, 30522, (B, 20), generator=g)
+    lens = torch.randint(6, 21, (B,), generator=g)
+    return {"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": (torch.arange(20)[None, :] < lens[:, None]).long()}
+
+
+def test_bert_small_text_tower_matches_oracle(dev):
+    """The real text tower of the tri-modal config (H=512 -> 8 heads of 64, S=20 padded to 32 keys with a key mask, mean over
+    all 20 positions including pads, proj 512 -> 768) against the oracle with the kernels' rounding points."""
+    from oracle import clibd_oracle as O
+
+    om, m = _bert_small_pair(dev)
+    x = _text_batch(64, 5)
+    cot = torch.randn(64, 768, generator=torch.Generator().manual_seed(6))
+    y = m({k: v.to(dev) for k, v in x.items()})
+    got = grads_named(m, (y * cot.to(dev)).sum())
+    with O.precision("bf16"):
+        yo = om(x)
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
+    assert y.shape == (64, 768)
+    assert rel(y.cpu(), yo.detach()) < 3e-3 and (y.cpu() - yo.detach()).abs().max().item() < 1e-3 * yo.abs().max().item() + 1e-5
+    assert_grads(got, go, what="bert-small vs oracle-bf16")
+
+
+def test_trimodal_full_size_step_matches_oracle(dev):
+    """Image + DNA + Text at the real tower sizes (ViT-B/16, BERT-base 133 tokens, BERT-small 20 tokens), batch 8, 3-way loss
+    (six directed terms): embeddings, loss (1e-3) and all trainable gradients against the oracle's bf16 mode."""
+    from oracle import clibd_oracle as O
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import ClipLoss, CLIBDDNAEncoder, CLIBDImageEncoder, SimpleCLIP, create_vit, load_pre_trained_bioscan_bert
+
+    torch.manual_seed(31)
+    base = O.build_image_dna_model()
+    with torch.no_grad():
+        for n, p in base.named_parameters():
+            if "linear_b_" in n or ".w_b." in n:
+                p.normal_(0, 0.02)
+    ot_enc, ht_enc = _bert_small_pair(dev, seed=32)
+    om = O.SimpleCLIP(base.image_encoder, base.dna_encoder, ot_enc)
+    model = SimpleCLIP(CLIBDImageEncoder(create_vit("vit_base_patch16_224"), r=4, num_classes=768),
+                       CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), r=4, num_classes=768), ht_enc.cpu())
+    model.load_state_dict(om.state_dict(), strict=True)
+    model = model.to(dev).eval()
+    B = 8
+    batch = synthetic_batch(B, torch.device("cpu"), seed=9, rank=0, with_text=True)
+    labels = torch.tensor([0, 1, 2, 3, 3, 5, 6, 0])
+    with O.precision("bf16"):
+        oi, od, ot, osc, _ = om(batch["image"], batch["dna"], batch["text"])
+        lo = O.contrastive_loss([oi, od, ot], labels, osc)
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], torch.autograd.grad(lo, [p for _, p in ps], allow_unused=True)))
+    crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+    hi, hd, ht, scale, _ = model(batch["image"].to(dev), batch["dna"].to(dev), {k: v.to(dev) for k, v in batch["text"].items()})
+    loss = crit(hi, hd, ht, labels.to(dev), scale)
+    got = grads_named(model, loss)
+    model.join_streams()
+    for a, b_ in ((hi, oi), (hd, od), (ht, ot)):
+        assert (a.cpu() - b_.detach()).abs().max().item() < 3e-3
+    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-3
+    keys = sorted(n for n, _ in ps if n in got)
+    allg = torch.cat([got[n].flatten() for n in keys])
+    allo = torch.cat([(torch.zeros_like(dict(ps)[n]) if go[n] is None else go[n]).flatten() for n in keys])
+    assert cos(allg, allo) > 0.99 and rel(allg, allo) < 0.15
+
+
+# ------------------------------------------------------------------------------------------ anchored to the reference's bf16 mode
+@pytest.mark.parametrize("name", ["dna", "text", "image"])
+def test_towers_as_close_to_fp32_reference_as_reference_autocast(dev, name):
+    """tests/golden/autocast_golden.pt = the reference's own towers under torch.autocast(bfloat16) (its optional bf16 mode,
+    train_epoch.py:42-46), same weights and inputs as the fp32 goldens.  The HIP towers (bf16 MFMA operands, fp32 residual
+    stream and statistics) must be at least as close to the reference's fp32 outputs and gradients as the reference's bf16 mode
+    is (x1.25 on outputs, x1.6 on the worst per-tensor gradient error: equivalent but different rounding points), and agree with
+    that bf16 mode itself within the sum of the two distances."""
+    ac = load("autocast_golden.pt")[name]
+    if name == "dna":
+        g = load("dna_tiny_golden.pt"); m = hip_dna(g, dev); x = g["ids"].to(dev)
+    elif name == "text":
+        g = load("text_tiny_golden.pt"); m = hip_text(g, dev); x = {k: v.to(dev) for k, v in g["inputs"].items()}
+    else:
+        g = load("image_tiny_golden.pt"); m = hip_image(g, dev); x = (g["image_u8"].float() / 255.0).to(dev)
+    y = m(x)
+    got = grads_named(m, (y * g["cot"].to(dev)).sum())
+    err = float((y.detach().cpu() - g["out"]).abs().max())
+    assert err <= 1.25 * ac["err_vs_fp32"] + 1e-6, (err, ac["err_vs_fp32"])
+    assert float((y.detach().cpu() - ac["out"]).abs().max()) <= err + ac["err_vs_fp32"] + 1e-6
+    ours = theirs = 0.0
+    for n, r in g["grads"].items():
+        if r.abs().max() < 1e-9:
+            continue
+        ours, theirs = max(ours, rel(got[n], r)), max(theirs, rel(ac["grads"][n], r))
+    assert ours <= 1.6 * theirs + 1e-6, (ours, theirs)
+
+
+@pytest.mark.parametrize("tag,use_text", [("id", False), ("idt", True)])
+def test_full_step_loss_as_close_as_reference_autocast(dev, tag, use_text):
+    """Loss of the b=8 step fixture: |HIP - reference fp32| <= max(1e-3, 1.5 x |reference bf16-autocast - reference fp32|)."""
+    from clibd_amd.model import ClipLoss, SimpleCLIP
+
+    gs, gd, gt, gi, ac = load("step_tiny_golden.pt"), load("dna_tiny_golden.pt"), load("text_tiny_golden.pt"), load("image_tiny_golden.pt"), load("autocast_golden.pt")
+    model = SimpleCLIP(hip_image(gi, dev), hip_dna(gd, dev), hip_text(gt, dev)).to(dev)
+    with torch.no_grad():
+        model.logit_scale.copy_(gs["logit_scale"])
+        io, do_, to, scale, _ = model((gs["image_u8"].float() / 255.0).to(dev), gs["dna"].to(dev), {k: v.to(dev) for k, v in gs["text"].items()})
+        crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+        loss = float(crit(io, do_, to if use_text else None, gs["labels"].to(dev), scale))
+    ref32, ref16 = float(gs[f"loss_{tag}"]), float(ac[f"loss_{tag}"])
+    assert abs(loss - ref32) <= max(1e-3, 1.5 * abs(ref16 - ref32)), (loss, ref32, ref16)
+
+
 # ------------------------------------------------------------------------------------------ dropout (train mode)
 def test_bert_train_mode_dropout_matches_oracle_masks(dev):
     """HF BERT applies dropout (p = 0.1) in train mode (train_epoch.py:19 model.train()).  The HIP masks are a pure function

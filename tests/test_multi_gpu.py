@@ -1,0 +1,99 @@
+"""Data-parallel step over RCCL on real GPUs (BASELINE configs[2] path: packed embedding all-gather over xGMI, reduce-scatter of
+the feature gradients, flat gradient all-reduce).  Spawns one process per GPU for W = the largest power of two <= min(8,
+device_count); skipped on a 1-GPU box (the gloo world_size-2 tests in test_distributed_cpu.py cover the host logic there).
+
+Every rank runs `Trainer.step` on its slice of the b=8 reference step fixture (tiny towers); expected values are the
+oracle's FULL-batch step (reference semantics: loss_func.py:138-201 + DDP mean, train_cl.py:204): the loss on every rank
+within 1e-3, the all-reduced mean gradients against the oracle's (direction gates of the single-GPU full-step test), identical
+parameters on all ranks after the update although rank > 0 started from a different random initialisation (broadcast)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def _load(name):
+    return torch.load(os.path.join(G, name), map_location="cpu", weights_only=False)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from clibd_amd.model import SimpleCLIP
+        from clibd_amd.train import Trainer
+        from tests.test_model_gpu import hip_dna, hip_image, hip_text
+
+        gs, gd, gt, gi = _load("step_tiny_golden.pt"), _load("dna_tiny_golden.pt"), _load("text_tiny_golden.pt"), _load("image_tiny_golden.pt")
+        model = SimpleCLIP(hip_image(gi, dev), hip_dna(gd, dev), hip_text(gt, dev)).to(dev)   # .eval(): dropout off
+        with torch.no_grad():
+            model.logit_scale.copy_(gs["logit_scale"])
+            if rank > 0:   # a different initialisation of every trainable tensor: Trainer must broadcast rank 0's
+                for p in model.parameters():
+                    if p.requires_grad:
+                        p.add_(0.01 * (rank + 1))
+        tr = Trainer(model, lr=1e-3, world_size=world, rank=rank, all_gather=True)
+        B = gs["labels"].numel()
+        b = B // world
+        sl = slice(rank * b, (rank + 1) * b)
+        img = (gs["image_u8"][sl].float() / 255.0).to(dev)
+        text = {k: v[sl].to(dev) for k, v in gs["text"].items()}
+        loss = tr.step(img, gs["dna"][sl].to(dev), text, gs["labels"][sl].to(dev))
+        torch.cuda.synchronize()
+        names = [n for n, p in model.named_parameters() if any(p is q for q in tr.optimizer.param_groups[0]["params"])]
+        grads = {n: (p.grad / world).detach().cpu() for n, p in model.named_parameters() if n in names}   # SUM all-reduce -> mean
+        out[rank] = {"loss": float(loss), "grads": grads, "checksum": float(tr.optimizer.flat_p.double().sum()),
+                     "absmax": float(tr.optimizer.flat_p.abs().max())}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_over_rccl_matches_full_batch_oracle():
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's 8-GPU node); host logic is covered under gloo in test_distributed_cpu.py")
+    world = 2
+    while world * 2 <= min(n, 8):
+        world *= 2
+    import torch.multiprocessing as mp
+
+    from oracle import clibd_oracle as O
+    from tests.test_oracle import build_dna, build_image, build_text
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, 29651, out), nprocs=world, join=True)
+    res = dict(out)
+    assert sorted(res) == list(range(world))
+    gs, gd, gt, gi = _load("step_tiny_golden.pt"), _load("dna_tiny_golden.pt"), _load("text_tiny_golden.pt"), _load("image_tiny_golden.pt")
+    om = O.SimpleCLIP(build_image(gi), build_dna(gd), build_text(gt))
+    with torch.no_grad():
+        om.logit_scale.copy_(gs["logit_scale"])
+    with O.precision("bf16"):
+        oi, od, ot, osc, _ = om(gs["image_u8"].float() / 255.0, gs["dna"], gs["text"])
+        lo = O.contrastive_loss([oi, od, ot], gs["labels"], osc)
+        ps = [(n_, p) for n_, p in om.named_parameters() if p.requires_grad]
+        go = {n_: (torch.zeros_like(p) if g is None else g) for (n_, p), g in zip(ps, torch.autograd.grad(lo, [p for _, p in ps], allow_unused=True))}
+    for r in range(world):
+        assert abs(res[r]["loss"] - float(lo)) < 1e-3, (r, res[r]["loss"], float(lo))       # every rank: the full-batch loss
+        assert res[r]["checksum"] == res[0]["checksum"] and res[r]["absmax"] == res[0]["absmax"]   # replicas stay identical
+        got = res[r]["grads"]
+        keys = sorted(k for k in got if k in go)
+        assert keys, "no common parameter names"
+        a = torch.cat([got[k].flatten() for k in keys]).double()
+        e = torch.cat([go[k].flatten() for k in keys]).double()
+        rel = ((a - e).norm() / e.norm()).item()
+        cosv = (a @ e / (a.norm() * e.norm())).item()
+        assert rel < 0.08 and cosv > 0.997, (r, rel, cosv)

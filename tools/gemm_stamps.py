@@ -1,4 +1,5 @@
-"""Diagnostic: per-tile s_memtime stamps of gemm256 (where a persistent workgroup spends its time)."""
+"""Diagnostic: per-tile s_memtime stamps of gemm256 (where a persistent workgroup spends its time).
+Needs the diagnostic build (the product library carries no stamp buffer): python -m clibd_amd.build --diag"""
 import ctypes, sys
 import torch
 sys.path.insert(0, ".")
