@@ -63,16 +63,9 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
     return r;
 }
 
-__device__ __forceinline__ float group4_sum(float v) {  // across the 4 lane groups (lane>>4) at fixed lane&15
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-__device__ __forceinline__ float group4_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
-}
+// across the 4 lane groups (lane>>4) at fixed lane&15: v_permlane swaps, not ds_bpermute (common.h)
+__device__ __forceinline__ float group4_sum(float v) { return rows4_sum(v); }
+__device__ __forceinline__ float group4_max(float v) { return rows4_max(v); }
 
 constexpr float NEG_BIG = -1.0e30f;
 
@@ -96,6 +89,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
     const int g = lane >> 4, i = lane & 15;
     const int nqt = (nq + 15) >> 4;  // only the first nq query rows are evaluated (nq = S normally; 1 = [CLS]-only last ViT block)
     const float c2 = scale * 1.4426950408889634f;  // p = exp2(c2 * s - c2 * max): one FMA + one v_exp per score
+    // NKT is even (k-slots of 32 keys); when S <= 16 (NKT - 1) the last key tile is all padding (S = 197 -> 13 live tiles of
+    // 14, S = 133 -> 9 of 10): its score MFMAs and exponentials are skipped (probabilities exactly 0, as the mask gives)
+    const bool last_live = S > 16 * (NKT - 1);
     // this wave's first Q fragment rides along with the K/V staging; later ones are prefetched a tile ahead
     bf16x8 qf[2];
     {
@@ -124,11 +120,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
             for (int kt = 0; kt < NKT; ++kt) {
                 sc[0][kt] = (f32x4){0, 0, 0, 0};
                 sc[1][kt] = (f32x4){0, 0, 0, 0};
+                if (kt < NKT - 1 || last_live) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 kfr = lds_row_frag(kt_lds, kt * 16 + i, ks, g);
-                    sc[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf2[0][ks], sc[0][kt], 0, 0, 0);
-                    sc[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf2[1][ks], sc[1][kt], 0, 0, 0);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8 kfr = lds_row_frag(kt_lds, kt * 16 + i, ks, g);
+                        sc[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf2[0][ks], sc[0][kt], 0, 0, 0);
+                        sc[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf2[1][ks], sc[1][kt], 0, 0, 0);
+                    }
                 }
                 if (kt & 1) __builtin_amdgcn_sched_barrier(0);  // at most four K fragments in flight: 2 x NKT score quads leave no room for more
             }
@@ -138,6 +136,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                 float mx = NEG_BIG;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
+                    if (kt == NKT - 1 && !last_live) continue;
                     if (kt * 16 + 15 >= S || key_mask != nullptr) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -154,13 +153,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                 const float mc = mx * c2;
                 float sum = 0.f;
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
+                for (int kt = 0; kt < NKT; ++kt) {
+                    if (kt == NKT - 1 && !last_live) continue;   // sc stays exactly 0: the probabilities of an all-padding tile
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float e = __builtin_amdgcn_exp2f(fmaf(sc[t][kt][r], c2, -mc));
                         sc[t][kt][r] = e;
                         sum += e;
                     }
+                }
                 sum = group4_sum(sum);
                 inv[t] = 1.0f / sum;
             }
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             sc[kt] = (f32x4){0, 0, 0, 0};
+            if (kt == NKT - 1 && !last_live) continue;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(kt_lds, kt * 16 + i, ks, g), qf[ks], sc[kt], 0, 0, 0);
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
         float mx = NEG_BIG;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
+            if (kt == NKT - 1 && !last_live) continue;
             if (kt * 16 + 15 >= S || key_mask != nullptr) {  // only tiles that can hold masked keys pay for the test
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -245,13 +248,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
         const float mc = mx * c2;
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt == NKT - 1 && !last_live) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c2, -mc));  // masked scores underflow to exactly 0
                 sc[kt][r] = e;
                 sum += e;
             }
+        }
         sum = group4_sum(sum);
         const float inv = 1.0f / sum;
         f32x4 o[4];
@@ -301,9 +306,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     constexpr int S_pad = 16 * NKT;
     char* t0 = smem;                      // phase 1: K   | phase 2: Q
     char* t1 = smem + S_pad * 128;        // phase 1: V   | phase 2: dO
-    float* st_m = (float*)(smem + 2 * S_pad * 128);  // row max (scaled scores)
-    float* st_il = st_m + S_pad;                      // 1 / row sum
-    float* st_d = st_il + S_pad;                      // delta = sum_k P dP
+    // per query row: m' = c2 * max + log2(row sum), so P = exp2(c2 * s - m') is the normalised probability with one FMA and one
+    // v_exp; rows that carry no gradient (q >= nq) hold m' = +BIG, i.e. P = 0 exactly, and need no per-element test in phase 2
+    float* st_m = (float*)(smem + 2 * S_pad * 128);
+    float* st_d = st_m + S_pad;                       // delta = sum_k P dP
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / nheads, h = blockIdx.x % nheads;
@@ -326,7 +332,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     }
     stage_head_tile(t0, qbase + H, ld, S, S_pad, wave, lane);
     stage_head_tile(t1, qbase + 2 * H, ld, S, S_pad, wave, lane);
-    for (int r = threadIdx.x; r < S_pad; r += ATT_THREADS) { st_m[r] = 0.f; st_il[r] = 0.f; st_d[r] = 0.f; }
+    for (int r = threadIdx.x; r < S_pad; r += ATT_THREADS) { st_m[r] = -NEG_BIG; st_d[r] = 0.f; }
+    const bool last_live = S > 16 * (NKT - 1);  // S <= 16 (NKT - 1): the last key tile is all padding and is skipped (see forward)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -352,6 +359,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
         for (int kt = 0; kt < NKT; ++kt) {
             sc[kt] = (f32x4){0, 0, 0, 0};
             dp[kt] = (f32x4){0, 0, 0, 0};
+            if (kt == NKT - 1 && !last_live) continue;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t0, kt * 16 + i, ks, g), qf[ks], sc[kt], 0, 0, 0);
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
         if (drop_thr16 > 0) {  // O = (P o M / (1-p)) V  =>  dP = (dO V^T) o M / (1-p)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
+                if (kt == NKT - 1 && !last_live) continue;
                 const unsigned base = (((unsigned)blockIdx.x * (unsigned)S + (unsigned)q) << 8) + 16u * kt + 4u * g;
                 float f0, f1, f2, f3;
                 drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
         float mx = NEG_BIG;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
+            if (kt == NKT - 1 && !last_live) continue;
             if (kt * 16 + 15 >= S || key_mask != nullptr) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -395,7 +405,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
         const float mc = mx * c2;
         float sum = 0.f, dl = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt == NKT - 1 && !last_live) continue;   // sc, dp stay exactly 0
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c2, -mc));  // un-normalised probability
@@ -403,12 +414,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                 sum += e;
                 dl += e * dp[kt][r];
             }
+        }
         sum = group4_sum(sum);
         dl = group4_sum(dl);
         const float inv = 1.0f / sum;
         dl *= inv;                                   // delta = sum_k P dP with P = e / sum (the fp32 softmax output)
-        const float sinv = scale * inv;              // dS = P (dP - delta) scale = e (dP - delta) (scale / sum)
-        if (g == 0) { st_m[q] = mc; st_il[q] = inv; st_d[q] = dl; }  // q < S_pad always
+        // dS = P (dP - delta) scale = e (dP - delta) (scale / sum): the per-query factor scale / sum is applied to the dQ
+        // accumulators (query on the lane: one constant per lane) instead of to every score
+        const float sinv = scale * inv;
+        if (g == 0) { st_m[q] = (q < nq) ? mc + __builtin_amdgcn_logf(sum) : -NEG_BIG; st_d[q] = dl; }  // q < S_pad always
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0, 0, 0, 0};
@@ -417,14 +431,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
             f32x4 d0, d1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                d0[r] = sc[2 * s][r] * (dp[2 * s][r] - dl) * sinv;
-                d1[r] = sc[2 * s + 1][r] * (dp[2 * s + 1][r] - dl) * sinv;
+                d0[r] = sc[2 * s][r] * (dp[2 * s][r] - dl);
+                d1[r] = sc[2 * s + 1][r] * (dp[2 * s + 1][r] - dl);
             }
             const bf16x8 dsf = pack_frag(d0, d1);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(t0, s, dt, lane), dsf, dq[dt], 0, 0, 0);
         }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] *= sinv;
         if (q < S) {
             unsigned short* orow = dqbase + (size_t)q * ld;
 #pragma unroll
@@ -472,12 +488,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) { dv[j][dt] = (f32x4){0, 0, 0, 0}; dk[j][dt] = (f32x4){0, 0, 0, 0}; }
+        const bool live1 = (2 * p + 1) * 16 < S;   // the second key tile of the last pair can be all padding: skipped
+        const bool masked = key_mask != nullptr;
 #pragma unroll 1
         for (int s = 0; s < (nqt + 1) / 2; ++s) {  // only query tiles that carry a gradient
+            const bool q1 = 2 * s + 1 < nqt;       // the second query tile of the last pair can be past the last live tile
             bf16x8 qr[2][2], dor[2][2];
-            float mr[2][4], ilr[2][4], dlr[2][4];
+            float mr[2][4], dlr[2][4];
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
+                if (hq == 1 && !q1) continue;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     qr[hq][ks] = lds_row_frag(t0, (2 * s + hq) * 16 + i, ks, g);
@@ -486,15 +506,21 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = (2 * s + hq) * 16 + 4 * g + r;
-                    mr[hq][r] = st_m[qq]; ilr[hq][r] = st_il[qq]; dlr[hq][r] = st_d[qq];
+                    mr[hq][r] = st_m[qq]; dlr[hq][r] = st_d[qq];
                 }
             }
             bf16x8 pf[2], dsf[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                pf[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                dsf[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (j == 1 && !live1) continue;
                 f32x4 pp[2], dd[2];
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
+                    pp[hq] = (f32x4){0, 0, 0, 0};
+                    dd[hq] = (f32x4){0, 0, 0, 0};
+                    if (hq == 1 && !q1) continue;
                     f32x4 sv = (f32x4){0, 0, 0, 0}, dpv = (f32x4){0, 0, 0, 0};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
@@ -503,14 +529,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int qq = (2 * s + hq) * 16 + 4 * g + r;
-                        const bool ok = key_ok[j] && (qq < nq);
-                        const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -mr[hq][r])) * ilr[hq][r] : 0.f;  // rounded to bf16 only inside dV's operand
+                        // P = exp2(c2 s - m'): normalised; 0 for rows without a gradient (m' = +BIG); rounded to bf16 only inside dV's operand
+                        float pr = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -mr[hq][r]));
+                        if (masked && !key_ok[j]) pr = 0.f;   // padding keys (key >= S) need no test: their dK / dV rows are never stored
                         float fm = 1.0f;
-                        if (drop_thr16 > 0)
+                        if (drop_thr16 > 0) {
+                            const int qq = (2 * s + hq) * 16 + 4 * g + r;
                             fm = drop_one(drop_seed, (((unsigned)blockIdx.x * (unsigned)S + (unsigned)qq) << 8) + (unsigned)keyv[j], (unsigned)drop_thr16, drop_scale);
-                        pp[hq][r] = pr * fm;                                   // dV = (P o M/(1-p))^T dO
-                        dd[hq][r] = pr * (dpv[r] * fm - dlr[hq][r]) * scale;    // dS = P o (dP - delta), dP masked as in phase 1
+                        }
+                        pp[hq][r] = pr * fm;                           // dV = (P o M/(1-p))^T dO
+                        dd[hq][r] = pr * (dpv[r] * fm - dlr[hq][r]);   // dS / scale = P o (dP - delta); scale is applied to dK at the end
                     }
                 }
                 pf[j] = pack_frag(pp[0], pp[1]);
@@ -522,6 +550,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                 const bf16x8 trq = lds_tr_frag(t0, s, dt, lane);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if (j == 1 && !live1) continue;
                     dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trdo, pf[j], dv[j][dt], 0, 0, 0);
                     dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trq, dsf[j], dk[j][dt], 0, 0, 0);
                 }
@@ -535,8 +564,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     uint2 pk;
-                    pk.x = pack2bf(dk[j][dt][0], dk[j][dt][1]);
-                    pk.y = pack2bf(dk[j][dt][2], dk[j][dt][3]);
+                    pk.x = pack2bf(dk[j][dt][0] * scale, dk[j][dt][1] * scale);
+                    pk.y = pack2bf(dk[j][dt][2] * scale, dk[j][dt][3] * scale);
                     *(uint2*)(krow + 16 * dt + 4 * g) = pk;
                     pk.x = pack2bf(dv[j][dt][0], dv[j][dt][1]);
                     pk.y = pack2bf(dv[j][dt][2], dv[j][dt][3]);
@@ -577,12 +606,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
         f32x4 dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+        const bool masked = key_mask != nullptr;
 #pragma unroll 1
         for (int s = 0; s < (nqt + 1) / 2; ++s) {  // only query tiles that carry a gradient
             f32x4 pp[2], dd[2];
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
                 const int qt = 2 * s + hq;
+                pp[hq] = (f32x4){0, 0, 0, 0};
+                dd[hq] = (f32x4){0, 0, 0, 0};
+                if (hq == 1 && qt >= nqt) continue;   // past the last live query tile
                 f32x4 sv = (f32x4){0, 0, 0, 0}, dpv = (f32x4){0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -592,14 +625,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = qt * 16 + 4 * g + r;
-                    const bool ok = key_ok && (qq < nq);
-                    const float m = st_m[qq], il = st_il[qq], dl = st_d[qq];
-                    const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -m)) * il : 0.f;  // rounded to bf16 only inside dV's operand
+                    const float m = st_m[qq], dl = st_d[qq];
+                    float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -m));  // normalised; 0 for rows without a gradient (m' = +BIG); rounded to bf16 only inside dV's operand
+                    if (masked && !key_ok) p = 0.f;   // padding keys need no test: their dK / dV rows are never stored
                     float fm = 1.0f;
                     if (drop_thr16 > 0)
                         fm = drop_one(drop_seed, (((unsigned)blockIdx.x * (unsigned)S + (unsigned)qq) << 8) + (unsigned)key, (unsigned)drop_thr16, drop_scale);
-                    pp[hq][r] = p * fm;                       // dV = (P o M/(1-p))^T dO
-                    dd[hq][r] = p * (dpv[r] * fm - dl) * scale;  // dS = P o (dP - delta), dP masked as in phase 1
+                    pp[hq][r] = p * fm;                  // dV = (P o M/(1-p))^T dO
+                    dd[hq][r] = p * (dpv[r] * fm - dl);  // dS / scale = P o (dP - delta), dP masked as in phase 1; scale goes on dK at the end
                 }
             }
             const bf16x8 pf = pack_frag(pp[0], pp[1]);
@@ -616,8 +649,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 pk;
-                pk.x = pack2bf(dk[dt][0], dk[dt][1]);
-                pk.y = pack2bf(dk[dt][2], dk[dt][3]);
+                pk.x = pack2bf(dk[dt][0] * scale, dk[dt][1] * scale);
+                pk.y = pack2bf(dk[dt][2] * scale, dk[dt][3] * scale);
                 *(uint2*)(krow + 16 * dt + 4 * g) = pk;
                 pk.x = pack2bf(dv[dt][0], dv[dt][1]);
                 pk.y = pack2bf(dv[dt][2], dv[dt][3]);
@@ -694,7 +727,7 @@ extern "C" int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B
     if (nq < 1 || nq > S || dout_seq < nq) return set_error(CLIBD_EINVAL, "attention_bwd: need 1 <= nq <= S and dout_seq >= nq");
     if (!aligned16(dout) || !aligned16(dqkv)) return set_error(CLIBD_EINVAL, "attention_bwd: alignment");
     const int nkt = 2 * ((S + 31) / 32);
-    const size_t lds = (size_t)2 * nkt * 16 * 128 + (size_t)3 * nkt * 16 * sizeof(float);
+    const size_t lds = (size_t)2 * nkt * 16 * 128 + (size_t)2 * nkt * 16 * sizeof(float);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(N)                                                                                                 \

@@ -65,15 +65,57 @@ __device__ __forceinline__ float drop_one(unsigned seed, unsigned idx, unsigned 
     return (((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16) ? scale : 0.f;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// ---- cross-lane reductions on the VALU data path only (DPP + v_permlane{16,32}_swap): no LDS-crossbar instruction.
+// Round 2 finding (tools/stress_streams.py, tools/stress_ln.py; regression: tests/test_streams_gpu.py): layernorm_fwd's LoRA down-projection, whose reduction used
+// ds_bpermute_b32 (what __shfl_xor lowers to) right after its ds_read of the adapter matrix, returned wrong sums in a few rows
+// per launch whenever an attention-forward kernel of ANOTHER stream was co-resident on the CU (correct alone, correct beside
+// GEMM / LayerNorm kernels; draining every ds_bpermute with lgkmcnt(0) did not help).  The reductions below never touch the
+// LDS unit and are also cheaper (the permlane swap replaces two selects and a ds_bpermute of the butterfly).
+// Inline asm for the swaps: ROCm 7.2's hipcc returned the two results of __builtin_amdgcn_permlane32_swap in ONE register when
+// they were added.  The s_nop pads are the VALU-write -> permlane-read wait states hipcc puts around its own swaps.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140, DPP_ROW_ROR8 = 0x128;
+// after the swap: a = {a[0:31], b[0:31]}, b = {a[32:63], b[32:63]}  (tools/micro/permlane_test.hip)
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// 16-lane rows r0..r3: a = {a.r0, b.r0, a.r2, b.r2}, b = {a.r1, b.r1, a.r3, b.r3}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// v + (lane ^ 16) + (lane ^ 32) + (lane ^ 48): the four 16-lane rows combined at a fixed position in the row
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a = v, b = v;
+    permlane16_swap(a, b);   // a + b = even+odd row of each pair, in every lane of the pair
+    v = a + b;
+    a = v; b = v;
+    permlane32_swap(a, b);
+    return a + b;
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    float a = v, b = v;
+    permlane16_swap(a, b);
+    v = fmaxf(a, b);
+    a = v; b = v;
+    permlane32_swap(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float wave_sum(float v) {   // every lane returns the total of the 64 lanes
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    v += dpp_mov<DPP_QUAD_XOR2>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);   // lane i <-> 7 - i of its group of 8: quads 0 and 1 combined
+    v += dpp_mov<DPP_ROW_MIRROR>(v);        // lane i <-> 15 - i: the other half of the 16-lane row
+    return rows4_sum(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return rows4_max(v);
 }
 
 // erf with |abs err| <= 1.5e-7 (Abramowitz-Stegun 7.1.26); outputs are rounded to bf16 downstream

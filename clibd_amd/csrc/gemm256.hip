@@ -89,7 +89,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
             kb_issue = split_issue * p.nk_split;
             nk_issue = min(p.nk_split, nk_total - kb_issue);
         }
-        tile_coords(tile_id, p.tiles_m, p.tiles_n, 4, tm, tn);
+        tile_coords(tile_id, p.tiles_m, p.tiles_n, p.band, tm, tn);
         nm0 = tm * T_M;
         nn0 = tn * T_N;
         offP0 = (unsigned)(nn0 + rowP) * ldw2 + chunk16;
@@ -423,10 +423,15 @@ static int skew_env_value() {
     static const int v = [] { const char* e = getenv("CLIBD_GEMM_SKEW"); return e ? atoi(e) : 0; }();
     return v;
 }
+static int band_env_value() {
+    static const int v = [] { const char* e = getenv("CLIBD_GEMM_BAND"); return e ? atoi(e) : 0; }();
+    return v;
+}
 #define CLIBD_DIAG_KERNEL(KIND) (const void*)gemm256_bf16_nt_kernel<KIND, false, true, true>
 #else
 static constexpr long long* g_stamp_buffer = nullptr;
 static int skew_env_value() { return 0; }
+static int band_env_value() { return 0; }
 #define CLIBD_DIAG_KERNEL(KIND) (const void*)nullptr
 #endif
 
@@ -481,6 +486,7 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     q.splits = 1;
     q.nk_split = nk;
     q.split_stride = 0;
+    q.band = band_env_value() > 0 ? band_env_value() : 4;
     const int grid = (int)(tiles < num_cus ? tiles : num_cus);
     const int kind = epilogue_kind(p.ep);
     int ntiles_i = (int)tiles;
@@ -528,6 +534,7 @@ int gemm256_splitk_launch(const GemmParams& p0, float* partials, size_t partials
     if ((size_t)splits * (size_t)q.M * (size_t)q.N > partials_elems) return 0;
     q.splits = splits;
     q.nk_split = nks;
+    q.band = 4;
     q.split_stride = (long long)q.M * q.N;
     q.ep = clibd_gemm_epilogue{};
     q.ep.out_f32 = partials;

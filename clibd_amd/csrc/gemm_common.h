@@ -16,6 +16,7 @@ struct GemmParams {
     // to ep.out_f32 + s*split_stride.  splits == 1: the ordinary GEMM.
     int splits, nk_split;
     long long split_stride;
+    int band;  // gemm256 tile order: ids run m-fastest inside bands of `band` m-tiles (tile_coords)
     // 128x128 kernel only: K-tiles [hole_kt, hole_kt + hole_nkt) of both operands are skipped (a column segment of A that
     // meets all-zero weights: the k segment of dqkv in the adapters' dt projection).  hole_nkt == 0: none.
     int hole_kt, hole_nkt;

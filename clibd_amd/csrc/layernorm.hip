@@ -9,31 +9,32 @@ namespace clibd {
 
 constexpr int LN_MAX_CHUNKS = 4;  // H <= 1024: each lane owns up to 4 float4 chunks (chunk j = cols 4*(lane + 64 j))
 
-// Reduce 8 per-lane partials across the wave with 10 shuffles (butterfly that halves the live values at each
-// of the first three steps).  On return every lane holds the total of value index ((lane>>3)&7).
+// Reduce 8 per-lane partials across the wave: a butterfly that halves the live values at each of the first three steps.
+// v_permlane32_swap / v_permlane16_swap exchange the lane halves / the 16-lane rows (one swap replaces two selects and a
+// ds_bpermute), DPP row_ror:8 the 8-lane halves of a row, then row_half_mirror and two quad permutes sum the aligned group of
+// 8 lanes.  No LDS-crossbar instruction (common.h explains why).  On return every lane holds the total of value index
+// ((lane>>3)&7).
 __device__ __forceinline__ float wave_reduce8(float v[8], int lane) {
-    float w4[4], w2[2], w1;
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    float w4[4], w2[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float keep = b5 ? v[i + 4] : v[i];
-        const float send = b5 ? v[i] : v[i + 4];
-        w4[i] = keep + __shfl_xor(send, 32, 64);
+    for (int i = 0; i < 4; ++i) {   // lanes 0-31: v[i] summed over both halves; lanes 32-63: v[i+4]
+        float a = v[i], b = v[i + 4];
+        permlane32_swap(a, b);
+        w4[i] = a + b;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float keep = b4 ? w4[i + 2] : w4[i];
-        const float send = b4 ? w4[i] : w4[i + 2];
-        w2[i] = keep + __shfl_xor(send, 16, 64);
+    for (int i = 0; i < 2; ++i) {   // even 16-lane rows: w4[i] summed over the row pair; odd rows: w4[i+2]
+        float a = w4[i], b = w4[i + 2];
+        permlane16_swap(a, b);
+        w2[i] = a + b;
     }
-    {
-        const float keep = b3 ? w2[1] : w2[0];
-        const float send = b3 ? w2[0] : w2[1];
-        w1 = keep + __shfl_xor(send, 8, 64);
-    }
-    w1 += __shfl_xor(w1, 4, 64);
-    w1 += __shfl_xor(w1, 2, 64);
-    w1 += __shfl_xor(w1, 1, 64);
+    const bool b3 = lane & 8;
+    const float keep = b3 ? w2[1] : w2[0];
+    const float send = b3 ? w2[0] : w2[1];
+    float w1 = keep + dpp_mov<DPP_ROW_ROR8>(send);   // lane ^ 8 inside a 16-lane row
+    w1 += dpp_mov<DPP_ROW_HALF_MIRROR>(w1);
+    w1 += dpp_mov<DPP_QUAD_XOR1>(w1);
+    w1 += dpp_mov<DPP_QUAD_XOR2>(w1);
     return w1;  // index = 4*b5 + 2*b4 + b3
 }
 

@@ -1,0 +1,136 @@
+"""Kernels must not change their results when another HIP stream's kernels are co-resident on the same CUs (the towers of
+SimpleCLIP run on separate streams).  Regression test for a round-2 finding: layernorm_fwd's LoRA down-projection, reduced with
+ds_bpermute_b32 after LDS reads, returned wrong sums in a few rows per launch whenever an attention-forward kernel of another
+stream shared its CU (tools/stress_streams.py, tools/stress_ln.py; fix: DPP / v_permlane reductions, csrc/common.h).
+
+Every kernel under test runs alone (reference), then REPS times while a noise stream runs attention / LayerNorm+LoRA / GEMM
+work on other buffers; outputs must be bit-identical (kernels that reduce with float atomics: 1e-5 relative)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+B, S, H, FF, NH = 32, 197, 768, 3072, 12
+M = B * S
+REPS = 6
+
+
+@pytest.fixture(scope="module")
+def env(dev):
+    from clibd_amd import ops
+
+    torch.manual_seed(0)
+    mk = lambda *sh, dt=BF16, scale=1.0: (torch.randn(*sh, device=dev) * scale).to(dt)
+    n = dict(qkv=mk(128 * 133, 3 * H), att=torch.empty(128 * 133, H, device=dev, dtype=BF16), x=mk(128 * 133, H, dt=F32), gam=torch.ones(H, device=dev),
+             bet=torch.zeros(H, device=dev), acat=mk(8, H), y=torch.empty(128 * 133, H, device=dev, dtype=BF16), st=torch.empty(128 * 133, 2, device=dev),
+             t=torch.empty(128 * 133, 8, device=dev, dtype=BF16), a=mk(128 * 133, H), w1=mk(FF, H, scale=0.05), b1=torch.zeros(FF, device=dev),
+             h=torch.empty(128 * 133, FF, device=dev, dtype=BF16), g=torch.empty(128 * 133, FF, device=dev, dtype=BF16))
+
+    def noise(kind):
+        if kind == "attention":
+            ops.attention_fwd(n["qkv"], 128, 133, NH, None, n["att"])
+        elif kind == "layernorm_lora":
+            ops.layernorm_fwd(n["x"], n["gam"], n["bet"], 1e-6, y_bf16=n["y"], stats=n["st"], lora_a=n["acat"], t_out=n["t"])
+        else:
+            ops.gemm_nt(n["a"], n["w1"], bias=n["b1"], act=ops.ACT_GELU_SAVE_GRAD, out_pre=n["g"], out_bf16=n["h"])
+
+    x = dict(a=mk(M, H), w1=mk(FF, H, scale=0.05), wq=mk(3 * H, H, scale=0.05), w2=mk(H, FF, scale=0.05), b1=mk(FF, dt=F32), bq=mk(3 * H, dt=F32),
+             b2=mk(H, dt=F32), f32=mk(M, H, dt=F32), res=mk(M, H, dt=F32), gam=mk(H, dt=F32), bet=mk(H, dt=F32), acat=mk(8, H), t=mk(M, 8),
+             vf=mk(3 * H, 8, scale=0.05), qkv=mk(M, 3 * H), do=mk(M, H), big=mk(M, FF), logits=mk(B * 133, H), dout=mk(B, H, dt=F32),
+             lab=torch.arange(256, device=dev), fx=torch.nn.functional.normalize(mk(256, H, dt=F32), dim=-1),
+             fy=torch.nn.functional.normalize(mk(256, H, dt=F32), dim=-1), scale=torch.tensor([14.28], device=dev))
+    return ops, noise, x, torch.cuda.Stream(device=dev)
+
+
+def _kernels(ops, x, dev):
+    E = lambda *sh, dt=BF16: torch.empty(*sh, device=dev, dtype=dt)
+
+    def ln_fwd_lora():
+        y, st, t = E(M, H), E(M, 2, dt=F32), E(M, 8)
+        ops.layernorm_fwd(x["f32"], x["gam"], x["bet"], 1e-6, y_bf16=y, stats=st, lora_a=x["acat"], t_out=t)
+        return y, st, t
+
+    def ln_fwd():
+        y, yf, st = E(M, H), E(M, H, dt=F32), E(M, 2, dt=F32)
+        ops.layernorm_fwd(x["f32"], x["gam"], x["bet"], 1e-12, y_bf16=y, y_f32=yf, stats=st)
+        return y, yf, st
+
+    def ln_bwd():
+        st, y = E(M, 2, dt=F32), E(M, H)
+        ops.layernorm_fwd(x["f32"], x["gam"], x["bet"], 1e-6, y_bf16=y, stats=st)
+        dx, dxb = E(M, H, dt=F32), E(M, H)
+        ops.layernorm_bwd(x["do"], x["f32"], st, x["gam"], dres=x["res"], dx_f32=dx, dx_bf16=dxb)
+        return dx, dxb
+
+    def attn_fwd():
+        o = E(M, H)
+        ops.attention_fwd(x["qkv"], B, S, NH, None, o)
+        return (o,)
+
+    def attn_bwd():
+        d = E(M, 3 * H)
+        ops.attention_bwd(x["qkv"], x["do"], B, S, NH, None, d)
+        return (d,)
+
+    def qkv_lora():
+        o = E(M, 3 * H)
+        ops.gemm_nt(x["a"], x["wq"], bias=x["bq"], rank_u=x["t"], rank_v=x["vf"], out_bf16=o)
+        return (o,)
+
+    def fc1():
+        a, g = E(M, FF), E(M, FF)
+        ops.gemm_nt(x["a"], x["w1"], bias=x["b1"], act=ops.ACT_GELU_SAVE_GRAD, out_pre=g, out_bf16=a)
+        return a, g
+
+    def fc2_res():
+        o = E(M, H, dt=F32)
+        ops.gemm_nt(x["big"], x["w2"], bias=x["b2"], residual=x["res"], out_f32=o)
+        return (o,)
+
+    def gemm128():
+        o = E(512, H, dt=F32)
+        ops.gemm_nt(x["a"][:512], x["wq"][:H], bias=x["b2"], residual=x["res"][:512], out_f32=o)
+        return (o,)
+
+    def softmax_mean():
+        y = ops.softmax_mean_fwd(x["logits"], B, 133)
+        return y, ops.softmax_mean_bwd(x["logits"], x["dout"], B, 133)
+
+    def l2norm():
+        y, inv = ops.l2norm_fwd(x["f32"])
+        return y, inv, ops.l2norm_bwd(x["res"], y, inv)
+
+    def loss_rows():   # the loss sum is a float-atomic reduction: compared with a tolerance
+        ws = ops.softce_workspace(256, 256, H, dev)
+        ls = torch.zeros(1, device=dev)
+        ops.softce_rows_fwd(x["fx"], x["fy"], x["lab"], 0, x["scale"], ls, ws)
+        return (ls,)
+
+    return [("layernorm_fwd+lora", ln_fwd_lora, True), ("layernorm_fwd", ln_fwd, True), ("layernorm_bwd", ln_bwd, True),
+            ("attention_fwd", attn_fwd, True), ("attention_bwd", attn_bwd, True), ("gemm256 qkv+lora", qkv_lora, True),
+            ("gemm256 fc1", fc1, True), ("gemm256 fc2+res", fc2_res, True), ("gemm128", gemm128, True), ("softmax_mean", softmax_mean, True),
+            ("l2norm", l2norm, True), ("softce_rows_fwd", loss_rows, False)]
+
+
+@pytest.mark.parametrize("noise_kind", ["attention", "layernorm_lora", "gemm"])
+def test_results_do_not_depend_on_a_concurrent_stream(dev, env, noise_kind):
+    ops, noise, x, ns = env
+    bad = []
+    for name, fn, exact in _kernels(ops, x, dev):
+        ref = [t.clone() for t in fn()]
+        torch.cuda.synchronize()
+        for _ in range(REPS):
+            ns.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ns):
+                for _ in range(3):
+                    noise(noise_kind)
+            out = fn()
+            torch.cuda.current_stream().wait_stream(ns)
+            torch.cuda.synchronize()
+            for k, (a, b) in enumerate(zip(out, ref)):
+                ok = torch.equal(a, b) if exact else torch.allclose(a.float(), b.float(), rtol=1e-5, atol=0)
+                if not ok:
+                    bad.append((name, k, float((a.float() - b.float()).abs().max())))
+                    break
+    assert not bad, bad
