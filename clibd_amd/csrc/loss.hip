@@ -7,9 +7,13 @@
 // The similarity runs on the bf16 MFMA GEMM with the split-bf16 trick: x = hi + lo, y = hi + lo (both bf16),
 // S ~ hi·hi + hi·lo + lo·hi, expressed as ONE NT GEMM with K = 3D over the images [hi|hi|lo] and [hi|lo|hi]
 // (error ~2^-16 relative instead of 2^-8: the reference evaluates this product in fp32, loss_func.py:189-190).
-// Row statistics use one wave64 per row with shuffle reductions.  Backward materialises the bf16 coefficient
-// matrix G = w * (tsum_i * softmax(S)_ij - T_ij) once and feeds it to the same GEMM for dX = scale·G·Y and
-// dY = scale·G^T·X.
+// Row statistics use one wave64 per row with DPP / permlane reductions.  The Nx x N similarity block of THIS rank's rows is
+// the kernel's fp32 scratch (caller-owned workspace: 16 MiB at Nx = N = 2048, 32 MiB at Nx = 1024, N = 8192); what is never
+// materialised is the N x N target matrix, the log-softmax temporaries and the second (transposed) logits of the reference.
+// Backward forms the coefficient matrix G = w * (tsum_i * softmax(S)_ij - T_ij) once, split like the forward operands
+// (G = Ghi + Glo), and feeds it to the same GEMM with the K-concatenated images
+//     dX = scale * [Ghi | Ghi | Glo] . [Yhi | Ylo | Yhi]^T          dY = scale * [Ghi^T | Glo^T | Ghi^T] . [Xhi | Xhi | Xlo]^T
+// so the feature gradients carry the forward's ~2^-16 relative accuracy (the reference computes loss and gradients in fp32).
 #include "common.h"
 #include "../../include/clibd_hip.h"
 #include "host_util.h"
@@ -76,14 +80,15 @@ __global__ __launch_bounds__(256) void softce_rows_fwd_kernel(const float* __res
 }
 
 // g_ij = w * (tsum_i * exp(scale*R_ij - lse_i) - T_ij) with R = raw similarities;
-// G[i,j] = bf16(scale * g_ij) (zero padded to ldG) feeds the dX/dY GEMMs;  dscale += sum_ij g_ij * R_ij
+// scale * g_ij = hi + lo (bf16 each) is written as the row image [hi | hi | lo] of width 3 * Np (zero padded past N);
+// dscale += sum_ij g_ij * R_ij
 __global__ __launch_bounds__(256) void softce_rows_bwd_kernel(const float* __restrict__ S, int ldS, int Nx, int N,
                                                               const int64_t* __restrict__ labels, int row0,
                                                               const float* __restrict__ lse, const float* __restrict__ tsum,
                                                               float w, const float* __restrict__ wscale_ptr,
                                                               const float* __restrict__ scale_ptr,
                                                               unsigned short* __restrict__ G,
-                                                              int ldG, float* __restrict__ dscale) {
+                                                              int Np, float* __restrict__ dscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Nx) return;
@@ -92,19 +97,49 @@ __global__ __launch_bounds__(256) void softce_rows_bwd_kernel(const float* __res
     const float scale = *scale_ptr;
     if (wscale_ptr != nullptr) w *= *wscale_ptr;
     const float* sr = S + (size_t)row * ldS;
-    unsigned short* gr = G + (size_t)row * ldG;
+    unsigned short* gr = G + (size_t)row * 3 * Np;
     float ds = 0.f;
-    for (int j = lane; j < ldG; j += 64) {
+    for (int j = lane; j < Np; j += 64) {
         float g = 0.f;
         if (j < N) {
             const float v = sr[j];
             g = w * (ts * __expf(v * scale - l) - (labels[j] == lab ? 1.0f : 0.0f));
             ds += g * v;
         }
-        gr[j] = f2bf(g * scale);
+        const float gs = g * scale;
+        const unsigned short hi = f2bf(gs);
+        gr[j] = hi;
+        gr[Np + j] = hi;
+        gr[2 * Np + j] = f2bf(gs - bf2f(hi));
     }
     ds = wave_sum(ds);
     if (lane == 0 && dscale != nullptr) atomicAdd(dscale, ds);
+}
+
+// out[c, k * Rp + r] = in[r, seg(k) * W + c] for the three column segments of a [R, 3W] image (seg(k) = 2 bits of `map` each),
+// c < C <= W, r < Rp with zeros for r >= R: the K-concatenated operand images of the backward GEMMs, transposed in one launch.
+__global__ __launch_bounds__(256) void transpose3_bf16_kernel(const unsigned short* __restrict__ in, int R, int W, int C, int map,
+                                                              unsigned short* __restrict__ out, int Rp) {
+    __shared__ unsigned short tile[64][66];
+    const int k = blockIdx.z;
+    const int seg = (map >> (2 * k)) & 3;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(size_t)r * 3 * W + (size_t)seg * W + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < Rp) out[(size_t)c * 3 * Rp + (size_t)k * Rp + r] = tile[tx][i];
+    }
+}
+
+static int launch_transpose3(const unsigned short* in, int R, int W, int C, int map, unsigned short* out, int Rp, hipStream_t st) {
+    dim3 grid((C + 63) / 64, (Rp + 63) / 64, 3);
+    hipLaunchKernelGGL(transpose3_bf16_kernel, grid, dim3(256), 0, st, in, R, W, C, map, out, Rp);
+    return check_launch("softce transpose3");
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -114,8 +149,8 @@ static inline int pad16(int v) { return (v + 15) / 16 * 16; }
 struct LossWs {
     unsigned short *x3, *y3;   // [Nx,3D], [N,3D]
     float *S, *lse, *tsum;     // [Nx,N], [Nx], [Nx]
-    unsigned short *G, *GT;    // [Nx,Np], [N,Nxp]
-    unsigned short *xT, *yT;   // [D,Nxp], [D,Np]
+    unsigned short *G, *GT;    // [Nx,3Np] = [hi|hi|lo],  [N,3Nxp] = [hi^T|lo^T|hi^T]
+    unsigned short *xT, *yT;   // [D,3Nxp] = [hi^T|hi^T|lo^T],  [D,3Np] = [hi^T|lo^T|hi^T]
     size_t total;
 };
 
@@ -134,10 +169,10 @@ static LossWs carve(void* base, int Nx, int N, int D) {
     w.S = (float*)take((size_t)Nx * pad16(N) * 4);              // ld = N16, columns N.. ignored
     w.lse = (float*)take((size_t)Nx * 4);
     w.tsum = (float*)take((size_t)Nx * 4);
-    w.G = (unsigned short*)take((size_t)Nx * Np * 2);
-    w.GT = (unsigned short*)take((size_t)N * Nxp * 2);
-    w.xT = (unsigned short*)take((size_t)D * Nxp * 2);
-    w.yT = (unsigned short*)take((size_t)D * Np * 2);
+    w.G = (unsigned short*)take((size_t)Nx * 3 * Np * 2);
+    w.GT = (unsigned short*)take((size_t)N * 3 * Nxp * 2);
+    w.xT = (unsigned short*)take((size_t)D * 3 * Nxp * 2);
+    w.yT = (unsigned short*)take((size_t)D * 3 * Np * 2);
     w.total = off;
     return w;
 }
@@ -194,21 +229,21 @@ extern "C" int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D
     const LossWs w = carve(workspace, Nx, N, D);
     if (workspace_bytes < w.total) return set_error(CLIBD_EINVAL, "softce_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const int Np = pad64(N), Nxp = pad64(Nx);
+    const int Np = pad64(N), Nxp = pad64(Nx);   // multiples of 64: every K segment of the backward GEMMs is whole K-tiles
     hipLaunchKernelGGL(softce_rows_bwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, pad16(N), Nx, N, labels, row0, w.lse,
                        w.tsum, weight, weight_scale, scale, w.G, Np, dscale);
     if (int e = check_launch("softce_rows_bwd")) return e;
-    // operand images: G^T [N,Nxp], xhi^T [D,Nxp], yhi^T [D,Np] (bf16, zero padded along the contraction)
-    if (int e = clibd_transpose_bf16(w.G, Np, Nx, N, w.GT, Nxp, stream)) return e;
-    if (int e = clibd_transpose_bf16(w.x3, 3 * D, Nx, D, w.xT, Nxp, stream)) return e;
-    if (int e = clibd_transpose_bf16(w.y3, 3 * D, N, D, w.yT, Np, stream)) return e;
+    // operand images, zero padded along the contraction: segment order pairs hi.hi + hi.lo + lo.hi (see the file header)
+    if (int e = launch_transpose3(w.G, Nx, Np, N, /*hi, lo, hi*/ 0 | (2 << 2) | (0 << 4), w.GT, Nxp, st)) return e;
+    if (int e = launch_transpose3(w.x3, Nx, D, D, /*hi, hi, lo*/ 0 | (1 << 2) | (2 << 4), w.xT, Nxp, st)) return e;
+    if (int e = launch_transpose3(w.y3, N, D, D, /*hi, lo, hi*/ 0 | (1 << 2) | (2 << 4), w.yT, Np, st)) return e;
     clibd_gemm_epilogue ep = {};
     ep.split_k = 1;
     // dx[i,:] += sum_j G[i,j] y[j,:]      (accumulate in place through the residual path)
     ep.out_f32 = dx; ep.ld_out_f32 = D; ep.residual_f32 = dx; ep.ld_res = D;
-    if (int e = clibd_gemm_bf16_nt(w.G, Np, w.yT, Np, Nx, D, Np, &ep, stream)) return e;
+    if (int e = clibd_gemm_bf16_nt(w.G, 3 * Np, w.yT, 3 * Np, Nx, D, 3 * Np, &ep, stream)) return e;
     // dy[j,:] += sum_i G[i,j] x[i,:]
     ep.out_f32 = dy; ep.residual_f32 = dy;
-    if (int e = clibd_gemm_bf16_nt(w.GT, Nxp, w.xT, Nxp, N, D, Nxp, &ep, stream)) return e;
+    if (int e = clibd_gemm_bf16_nt(w.GT, 3 * Nxp, w.xT, 3 * Nxp, N, D, 3 * Nxp, &ep, stream)) return e;
     return CLIBD_OK;
 }
