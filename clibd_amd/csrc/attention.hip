@@ -69,8 +69,23 @@ __device__ __forceinline__ float group4_max(float v) { return rows4_max(v); }
 
 constexpr float NEG_BIG = -1.0e30f;
 
+#ifdef CLIBD_GEMM_DIAG
+// diagnostic build only (python -m clibd_amd.build --diag; tools/att_stamps.py): s_memtime at the phase boundaries of the backward
+__device__ long long* g_att_stamps = nullptr;   // [workgroup][8]
+#define ATT_STAMP(k)                                                                                      \
+    do {                                                                                                  \
+        if (g_att_stamps != nullptr && threadIdx.x == 0) g_att_stamps[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ATT_STAMP(k) do { } while (0)
+#endif
+
 // ============================================ forward ==========================================================
-template <int NKT, bool PAIR>  // NKT: number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32); PAIR: two query tiles per sweep
+// MASK: a key-padding mask is present (text tower).  Compile-time, because the per-key mask loads and their divergent
+// select code — emitted for every (key tile, register) pair when the test is a run-time pointer check — cost the unmasked
+// towers ~400 SGPR-spill v_readlane/v_writelane and ~450 exec-mask scalar ops per query tile (ISA of the round-1 kernel).
+// DROP: dropout on the probabilities (HF BERT train mode); compile-time for the same reason (its counter hash is ~7 VALU per score).
+template <int NKT, bool PAIR, bool MASK, bool DROP>  // NKT: number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32); PAIR: two query tiles per sweep
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ out, float scale,
@@ -137,12 +152,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     if (kt == NKT - 1 && !last_live) continue;
-                    if (kt * 16 + 15 >= S || key_mask != nullptr) {
+                    if (MASK || (kt >= NKT - 2 && kt * 16 + 15 >= S)) {   // S > 16 (NKT - 2): only the last two tiles can hold padding keys
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int key = kt * 16 + 4 * g + r;
                             bool ok = key < S;
-                            if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+                            if (MASK) ok = ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
                             if (!ok) sc[t][kt][r] = NEG_BIG;
                         }
                     }
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                 bf16x8 pf[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    if (drop_thr16 > 0) {
+                    if (DROP) {
                         const unsigned q = (unsigned)((2 * p + t) * 16 + i);
                         const unsigned base = (((unsigned)blockIdx.x * (unsigned)S + q) << 8) + 32u * s + 4u * g;
                         float f0, f1, f2, f3;
@@ -232,12 +247,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt == NKT - 1 && !last_live) continue;
-            if (kt * 16 + 15 >= S || key_mask != nullptr) {  // only tiles that can hold masked keys pay for the test
+            if (MASK || (kt >= NKT - 2 && kt * 16 + 15 >= S)) {  // only tiles that can hold masked keys pay for the test
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + 4 * g + r;
                     bool ok = key < S;
-                    if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+                    if (MASK) ok = ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
                     if (!ok) sc[kt][r] = NEG_BIG;
                 }
             }
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < NKT / 2; ++s) {
-            if (drop_thr16 > 0) {  // dropout on the probabilities (HF BertSelfAttention.dropout); index ((b*nh+h)*S+q)*256+key
+            if (DROP) {  // dropout on the probabilities (HF BertSelfAttention.dropout); index ((b*nh+h)*S+q)*256+key
                 const unsigned base = (((unsigned)blockIdx.x * (unsigned)S + (unsigned)q) << 8) + 32u * s + 4u * g;
                 float f0, f1, f2, f3;
                 drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
@@ -295,8 +310,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 // ============================================ backward =========================================================
 // PAIR: phase 2 sweeps two key tiles per wave (long sequences: halves the LDS traffic per MFMA; costs ~60 VGPRs, so the
 // short-sequence instantiations, which fit three waves per SIMD without it, keep the one-tile sweep)
-template <int NKT, bool PAIR>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
+template <int NKT, bool PAIR, bool MASK, bool DROP>
+__global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                                     const unsigned short* __restrict__ dout, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ dqkv, float scale,
@@ -330,6 +345,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
             dof[ks] = *(const bf16x8*)(dobase + (size_t)min(qc0, nq - 1) * H + 32 * ks + 8 * g);
         }
     }
+    ATT_STAMP(0);
     stage_head_tile(t0, qbase + H, ld, S, S_pad, wave, lane);
     stage_head_tile(t1, qbase + 2 * H, ld, S, S_pad, wave, lane);
     for (int r = threadIdx.x; r < S_pad; r += ATT_THREADS) { st_m[r] = -NEG_BIG; st_d[r] = 0.f; }
@@ -337,6 +353,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    ATT_STAMP(1);
     // ---------------- phase 1: per 16-query tile: softmax statistics, dS, dQ ----------------
     const int nqt = (nq + 15) >> 4;      // query tiles that carry a gradient (rows >= nq have dO = 0)
     const int nqt_all = (S + 15) >> 4;
@@ -366,7 +383,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                 dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(t1, kt * 16 + i, ks, g), dof[ks], dp[kt], 0, 0, 0);
             }
         }
-        if (drop_thr16 > 0) {  // O = (P o M / (1-p)) V  =>  dP = (dO V^T) o M / (1-p)
+        if (DROP) {  // O = (P o M / (1-p)) V  =>  dP = (dO V^T) o M / (1-p)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 if (kt == NKT - 1 && !last_live) continue;
@@ -389,12 +406,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt == NKT - 1 && !last_live) continue;
-            if (kt * 16 + 15 >= S || key_mask != nullptr) {
+            if (MASK || (kt >= NKT - 2 && kt * 16 + 15 >= S)) {  // only tiles that can hold masked keys pay for the test
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + 4 * g + r;
                     bool ok = key < S;
-                    if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+                    if (MASK) ok = ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
                     if (!ok) sc[kt][r] = NEG_BIG;
                 }
             }
@@ -452,7 +469,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
             }
         }
     }
+    ATT_STAMP(2);
     __syncthreads();  // every wave is done reading K/V tiles; statistics are visible
+    ATT_STAMP(3);
 
     if constexpr (PAIR) {
     // ---------------- phase 2: dV, dK — TWO 16-key tiles per wave (query on the MFMA row, key on the lane) ----------------
@@ -463,6 +482,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     stage_head_tile(t1, dobase, (size_t)H, nq, S_pad, wave, lane);  // rows >= nq are clamped copies, masked below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ATT_STAMP(4);
 
     const int nkt = (S + 15) >> 4;
     for (int p = wave; p < ((nkt + 1) >> 1); p += ATT_WAVES) {
@@ -474,7 +494,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
             const int key = (2 * p + j) * 16 + i;
             keyv[j] = key;
             bool ok = key < S;
-            if (ok && key_mask != nullptr) ok = key_mask[(size_t)b * S + key] != 0;
+            if (MASK) ok = ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
             key_ok[j] = ok;
             const int kc = min(key, S - 1);
 #pragma unroll
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) { dv[j][dt] = (f32x4){0, 0, 0, 0}; dk[j][dt] = (f32x4){0, 0, 0, 0}; }
         const bool live1 = (2 * p + 1) * 16 < S;   // the second key tile of the last pair can be all padding: skipped
-        const bool masked = key_mask != nullptr;
+        constexpr bool masked = MASK;
 #pragma unroll 1
         for (int s = 0; s < (nqt + 1) / 2; ++s) {  // only query tiles that carry a gradient
             const bool q1 = 2 * s + 1 < nqt;       // the second query tile of the last pair can be past the last live tile
@@ -533,7 +553,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                         float pr = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -mr[hq][r]));
                         if (masked && !key_ok[j]) pr = 0.f;   // padding keys (key >= S) need no test: their dK / dV rows are never stored
                         float fm = 1.0f;
-                        if (drop_thr16 > 0) {
+                        if (DROP) {
                             const int qq = (2 * s + hq) * 16 + 4 * g + r;
                             fm = drop_one(drop_seed, (((unsigned)blockIdx.x * (unsigned)S + (unsigned)qq) << 8) + (unsigned)keyv[j], (unsigned)drop_thr16, drop_scale);
                         }
@@ -574,6 +594,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
             }
         }
     }
+    ATT_STAMP(5);
     } else {
     // ---------------- phase 2: per 16-key tile: dV, dK (query on the MFMA row, key on the lane) ----------------
     bf16x8 kf[2], vf[2], kfn[2], vfn[2];
@@ -594,7 +615,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
     for (int kt = wave; kt < nkt; kt += ATT_WAVES) {
         const int key = kt * 16 + i;
         bool key_ok = key < S;
-        if (key_ok && key_mask != nullptr) key_ok = key_mask[(size_t)b * S + key] != 0;
+        if (MASK) key_ok = key_ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
         {   // next key tile's K / V fragments fly during this tile's sweep over the queries
             const int kn = min((kt + ATT_WAVES) * 16 + i, S - 1);
 #pragma unroll
@@ -606,7 +627,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
         f32x4 dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
-        const bool masked = key_mask != nullptr;
+        constexpr bool masked = MASK;
 #pragma unroll 1
         for (int s = 0; s < (nqt + 1) / 2; ++s) {  // only query tiles that carry a gradient
             f32x4 pp[2], dd[2];
@@ -629,7 +650,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_bwd_kernel(const uns
                     float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -m));  // normalised; 0 for rows without a gradient (m' = +BIG); rounded to bf16 only inside dV's operand
                     if (masked && !key_ok) p = 0.f;   // padding keys need no test: their dK / dV rows are never stored
                     float fm = 1.0f;
-                    if (drop_thr16 > 0)
+                    if (DROP)
                         fm = drop_one(drop_seed, (((unsigned)blockIdx.x * (unsigned)S + (unsigned)qq) << 8) + (unsigned)key, (unsigned)drop_thr16, drop_scale);
                     pp[hq][r] = p * fm;                  // dV = (P o M/(1-p))^T dO
                     dd[hq][r] = p * (dpv[r] * fm - dl);  // dS / scale = P o (dP - delta), dP masked as in phase 1; scale goes on dK at the end
@@ -700,15 +721,23 @@ extern "C" int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nhead
     const size_t lds = (size_t)2 * nkt * 16 * 128;
     const float scale = 0.125f;  // 1/sqrt(64)
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(N)                                                                                                 \
+#define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
-        hipFuncSetAttribute((const void*)attention_fwd_kernel<N, (N >= 10)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((attention_fwd_kernel<N, (N >= 10)>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
+        hipFuncSetAttribute((const void*)attention_fwd_kernel<N, (N >= 10), MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attention_fwd_kernel<N, (N >= 10), MSK, DRP>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,       \
                            (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
                            drop_seed, drop_thr16, drop_scale);                                                    \
     } while (0)
+#define LAUNCH(N)                                                        \
+    do {                                                                 \
+        if (key_mask != nullptr && drop_thr16 > 0) LAUNCH_M(N, true, true);   \
+        else if (key_mask != nullptr) LAUNCH_M(N, true, false);          \
+        else if (drop_thr16 > 0) LAUNCH_M(N, false, true);               \
+        else LAUNCH_M(N, false, false);                                  \
+    } while (0)
     ATT_DISPATCH(nkt, LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_M
     return check_launch("attention_fwd");
 }
 
@@ -730,15 +759,23 @@ extern "C" int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B
     const size_t lds = (size_t)2 * nkt * 16 * 128 + (size_t)2 * nkt * 16 * sizeof(float);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(N)                                                                                                 \
+#define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
-        hipFuncSetAttribute((const void*)attention_bwd_kernel<N, (N >= 12)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((attention_bwd_kernel<N, (N >= 12)>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,                 \
+        hipFuncSetAttribute((const void*)attention_bwd_kernel<N, (N >= 12), MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attention_bwd_kernel<N, (N >= 12), MSK, DRP>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,       \
                            (const unsigned short*)qkv, (const unsigned short*)dout, S, nheads, (const int*)key_mask, \
                            (unsigned short*)dqkv, scale, nq, dout_seq, drop_seed, drop_thr16, drop_scale);        \
     } while (0)
+#define LAUNCH(N)                                                        \
+    do {                                                                 \
+        if (key_mask != nullptr && drop_thr16 > 0) LAUNCH_M(N, true, true);   \
+        else if (key_mask != nullptr) LAUNCH_M(N, true, false);          \
+        else if (drop_thr16 > 0) LAUNCH_M(N, false, true);               \
+        else LAUNCH_M(N, false, false);                                  \
+    } while (0)
     ATT_DISPATCH(nkt, LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_M
     return check_launch("attention_bwd");
 }
 
@@ -746,3 +783,10 @@ extern "C" int clibd_attention_bwd(const void* qkv, const void* dout, int B, int
                                    void* dqkv, int nq, int dout_seq, void* stream) {
     return clibd_attention_bwd_drop(qkv, dout, B, S, nheads, key_mask, dqkv, nq, dout_seq, 0u, 0, 1.0f, stream);
 }
+
+#ifdef CLIBD_GEMM_DIAG
+extern "C" void clibd_debug_set_att_stamps(void* device_buffer) {
+    long long* p = (long long*)device_buffer;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(clibd::g_att_stamps), &p, sizeof(p));
+}
+#endif
