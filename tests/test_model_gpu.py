@@ -316,7 +316,7 @@ def test_trimodal_full_size_step_matches_oracle(dev):
     got = grads_named(model, loss)
     model.join_streams()
     for a, b_ in ((hi, oi), (hd, od), (ht, ot)):
-        assert (a.cpu() - b_.detach()).abs().max().item() < 3e-3
+        assert (a.cpu() - b_.detach()).abs().max().item() < 1e-3, (a.cpu() - b_.detach()).abs().max().item()   # unit-norm rows
     assert abs(float(loss.detach()) - float(lo.detach())) < 1e-3
     keys = sorted(n for n, _ in ps if n in got)
     allg = torch.cat([got[n].flatten() for n in keys])
@@ -618,13 +618,22 @@ def test_full_size_model_matches_oracle(dev):
         lo = O.contrastive_loss([oi, od, None], labels, osc)
         ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
         go = dict(zip([n for n, _ in ps], torch.autograd.grad(lo, [p for _, p in ps], allow_unused=True)))
+    with torch.no_grad():   # the oracle's fp32 mode = the reference's default (non-autocast) arithmetic
+        fi, fd, _, fsc, _ = om(batch["image"], batch["dna"], None)
+        lf = O.contrastive_loss([fi, fd, None], labels, fsc)
     crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
     hi, hd, _, scale, _ = model(batch["image"].to(dev), batch["dna"].to(dev), None)
     loss = crit(hi, hd, None, labels.to(dev), scale)
     got = grads_named(model, loss)
     model.join_streams()
-    assert (hi.cpu() - oi.detach()).abs().max().item() < 3e-3 and (hd.cpu() - od.detach()).abs().max().item() < 3e-3   # unit-norm rows
-    assert abs(float(loss.detach()) - float(lo.detach())) < 2e-3
+    # north_star: "logits/loss within 1e-3 (bf16 tolerance)".  Measured at this size (tools/full_size_errors.py): embeddings
+    # 5.7e-4 / 1.3e-4 from the bf16 oracle and 9.6e-4 / 3.1e-4 from the FP32 path; loss 6e-5 from either.
+    for a, b_, f_ in ((hi, oi, fi), (hd, od, fd)):
+        assert (a.cpu() - b_.detach()).abs().max().item() < 1e-3           # unit-norm rows; vs the kernels' rounding points
+        assert (a.cpu() - f_).abs().max().item() < 1.5e-3                  # vs fp32 (the oracle's own bf16 mode: 1.0e-3)
+    sim_h, sim_o = (hi.detach().cpu() @ hd.detach().cpu().T), (oi.detach() @ od.detach().T)
+    assert (sim_h - sim_o).abs().max().item() < 1e-3                       # cosine logits (before the temperature)
+    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-3 and abs(float(loss.detach()) - float(lf)) < 1e-3
     allg = torch.cat([got[n].flatten() for n in sorted(got)])
     allo = torch.cat([(torch.zeros_like(p) if go[n] is None else go[n]).flatten() for n, p in sorted(ps)])
     assert sorted(got) == sorted(n for n, _ in ps)
