@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma ;  optional + dres
-template <int NCH>
+// PG (full fine-tune mode): also dgamma[c] += sum_rows dy * xhat, dbeta[c] += sum_rows dy — the kernel has dy and xhat in
+// registers anyway; every wave keeps its columns' partial sums over the rows it walks, the block combines its four waves in
+// LDS and issues ONE float atomic per column and parameter (the grid is capped so that these stay a few microseconds).
+template <int NCH, bool PG>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy_bf16,
                                                             const float* __restrict__ dy_f32,
                                                             const float* __restrict__ x,
@@ -140,17 +143,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                                                             const float* __restrict__ dres,
                                                             float* __restrict__ dx_f32,
                                                             unsigned short* __restrict__ dx_bf16, unsigned drop_seed,
-                                                            int drop_thr16, float drop_scale) {
+                                                            int drop_thr16, float drop_scale, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
     f32x4 g[NCH];
+    f32x4 pgam[PG ? NCH : 1], pbet[PG ? NCH : 1];
     bool act[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = 4 * (lane + 64 * j);
         act[j] = c < H;
         g[j] = act[j] ? *(const f32x4*)(gamma + c) : (f32x4){0, 0, 0, 0};
+        if (PG) { pgam[j] = (f32x4){0, 0, 0, 0}; pbet[j] = (f32x4){0, 0, 0, 0}; }
     }
     const float invH = 1.0f / (float)H;
     for (int row = wave_in_grid; row < M; row += nwaves) {
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                 xh[j][e] = (xv[e] - mean) * rstd;
                 s1 += gy[j][e];
                 s2 += gy[j][e] * xh[j][e];
+                if (PG) { pgam[j][e] += d[e] * xh[j][e]; pbet[j][e] += d[e]; }
             }
         }
         const float m1 = wave_sum(s1) * invH;
@@ -208,6 +215,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                 pk.y = pack2bf(o[2], o[3]);
                 *(uint2*)(dx_bf16 + (size_t)row * H + c) = pk;
             }
+        }
+    }
+    if (PG) {
+        __shared__ __attribute__((aligned(16))) float pg_lds[2][4][1024];   // [gamma|beta][wave][column]
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (!act[j]) continue;
+            const int c = 4 * (lane + 64 * j);
+            *(f32x4*)(&pg_lds[0][wv][c]) = pgam[j];
+            *(f32x4*)(&pg_lds[1][wv][c]) = pbet[j];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < H; c += 256) {
+            atomicAdd(dgamma + c, (pg_lds[0][0][c] + pg_lds[0][1][c]) + (pg_lds[0][2][c] + pg_lds[0][3][c]));
+            atomicAdd(dbeta + c, (pg_lds[1][0][c] + pg_lds[1][1][c]) + (pg_lds[1][2][c] + pg_lds[1][3][c]));
         }
     }
 }
@@ -265,20 +288,30 @@ extern "C" int clibd_layernorm_fwd(const float* x, int M, int H, const float* ga
     return clibd_layernorm_fwd_drop(x, M, H, gamma, beta, eps, y_bf16, y_f32, stats, lora_a_bf16, t_bf16, 0u, 0, 1.0f, stream);
 }
 
-extern "C" int clibd_layernorm_bwd_drop(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
-                                        const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
-                                        void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
+                              const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
+                              void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, float* dgamma, float* dbeta, void* stream) {
     if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "layernorm_bwd: bad dropout threshold");
     if (!x || !stats || !gamma) return set_error(CLIBD_EINVAL, "layernorm_bwd: null pointer");
     if ((dy_bf16 == nullptr) == (dy_f32 == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: exactly one of dy_bf16/dy_f32");
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_bwd: H must be a multiple of 64, <= 1024");
     if (!dx_f32 && !dx_bf16) return set_error(CLIBD_EINVAL, "layernorm_bwd: no output");
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: dgamma/dbeta must come together");
     const int nch = (H + 255) / 256;
-    dim3 grid(min((M + 3) / 4, 4096)), block(256);
+    const bool pg = dgamma != nullptr;
+    // parameter-gradient mode: at most 4 blocks per CU-slot (1024 blocks): 2 x H float atomics per block stay ~1.5 M per launch
+    dim3 grid(min((M + 3) / 4, pg ? 1024 : 4096)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(N)                                                                                              \
-    hipLaunchKernelGGL(layernorm_bwd_kernel<N>, grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
-                       stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale)
+    do {                                                                                                       \
+        if (pg)                                                                                                \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<N, true>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
+                               stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma, dbeta); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<N, false>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
+                               stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale, \
+                               (float*)nullptr, (float*)nullptr);                                             \
+    } while (0)
     switch (nch) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -289,8 +322,24 @@ extern "C" int clibd_layernorm_bwd_drop(const void* dy_bf16, const float* dy_f32
     return check_launch("layernorm_bwd");
 }
 
+extern "C" int clibd_layernorm_bwd_drop(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
+                                        const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
+                                        void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+    return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, nullptr,
+                              nullptr, stream);
+}
+
 extern "C" int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
                                    const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
                                    void* dx_bf16, void* stream) {
-    return clibd_layernorm_bwd_drop(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, 0u, 0, 1.0f, stream);
+    return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, 0u, 0, 1.0f, nullptr, nullptr, stream);
+}
+
+extern "C" int clibd_layernorm_bwd_pg(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
+                                      const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
+                                      void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, float* dgamma, float* dbeta,
+                                      void* stream) {
+    if (!dgamma || !dbeta) return set_error(CLIBD_EINVAL, "layernorm_bwd_pg: null dgamma/dbeta");
+    return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma, dbeta,
+                              stream);
 }

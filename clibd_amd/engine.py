@@ -264,8 +264,8 @@ class TransformerStack:
         first_lora = min((i for i, L in enumerate(self.layers) if L.lora is not None), default=len(self.layers))
         if full:
             first_lora = -1  # every layer has trainable parameters and the input gradient is needed
-        lng = lambda dy, x, st, w, b, drop=None: (ops.layernorm_param_grads(dy, x, st, grads[id(w)], grads[id(b)], drop=drop)
-                                                  if full and id(w) in grads else None)
+        # full fine-tune: the LayerNorm backward accumulates d(gamma), d(beta) in the same pass (it holds dy and xhat anyway)
+        pg = lambda w, b: (dict(dgamma=grads[id(w)].view(-1), dbeta=grads[id(b)].view(-1)) if full and id(w) in grads else {})
         wg = lambda dy, x, ws, bs: linear_wgrad(dy, x, ws, bs, grads) if full else None
         for i in range(len(self.layers) - 1, -1, -1):
             L, c, rec = self.layers[i], self._cache[i], saved[i]
@@ -280,9 +280,8 @@ class TransformerStack:
                 ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dhc)
                 wg(dhc, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                 ops.gemm_nt(dhc, c.w1_t, out_bf16=dtc)
-                lng(dtc, rec["x1"], rec["st2"], L.ln2_w, L.ln2_b)
                 dx1_f32, dx1_bf16 = newB(H, F32), newB(H, BF16)
-                ops.layernorm_bwd(dtc, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16)
+                ops.layernorm_bwd(dtc, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
                 wg(dx1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtc)                                              # d(attn out), class rows
                 ops.attention_bwd(rec["qkv"], dtc, B, S, self.heads, key_mask, dqkv, nq=1)
@@ -291,19 +290,17 @@ class TransformerStack:
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
-                    lng(dtmp, rec["x_in"], rec["st1"], L.ln1_w, L.ln1_b)
                     _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)            # residual path: class rows only
                     ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
-                    ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16)
+                    ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
                     dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif self.pre_ln:
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)          # d(fc1 out)
                 wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                 ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
-                lng(dtmp, rec["x1"], rec["st2"], L.ln2_w, L.ln2_b)
                 dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
-                ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16)
+                ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
                 wg(dx1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtmp)                                             # d(attn out)
                 ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv)
@@ -312,22 +309,19 @@ class TransformerStack:
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
-                    lng(dtmp, rec["x_in"], rec["st1"], L.ln1_w, L.ln1_b)
                     ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
-                    ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16)
+                    ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
                     dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             else:
-                lng(dx_f32, rec["s2"], rec["st2"], L.ln2_w, L.ln2_b)
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
-                ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"])
+                ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"], **pg(L.ln2_w, L.ln2_b))
                 wg(ds2_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 ops.gemm_nt(ds2_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)
                 wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                 dx1 = new(H, F32)
                 ops.gemm_nt(dh, c.w1_t, residual=ds2_f32, out_f32=dx1)
-                lng(dx1, rec["s1"], rec["st1"], L.ln1_w, L.ln1_b)
                 ds1_f32, ds1_bf16 = new(H, F32), new(H, BF16)
-                ops.layernorm_bwd(dx1, rec["s1"], rec["st1"], c.g1, dx_f32=ds1_f32, dx_bf16=ds1_bf16, drop=rec["d_h1"])
+                ops.layernorm_bwd(dx1, rec["s1"], rec["st1"], c.g1, dx_f32=ds1_f32, dx_bf16=ds1_bf16, drop=rec["d_h1"], **pg(L.ln1_w, L.ln1_b))
                 wg(ds1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(ds1_bf16, c.wo_t, out_bf16=dtmp)
                 ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv, drop=rec["d_att"])
@@ -358,8 +352,14 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
     if x_bf16 is None:
         raise RuntimeError("full fine-tune backward needs the layer's GEMM input (forward ran without full=True)")
     M = dy_bf16.shape[0]
+    want_b = [b is not None and id(b) in grads for b in biases]
+    bias_done = False
     if any(id(w) in grads for w in weights):
-        dyT = ops.transpose_bf16(dy_bf16, pad_to=128)   # [N, Mp]
+        N = dy_bf16.shape[1]
+        csum = None
+        if any(want_b) and N % 8 == 0 and dy_bf16.stride(0) % 8 == 0:
+            csum = torch.zeros((N,), dtype=F32, device=dy_bf16.device)   # column sums of dy in the same pass as its transpose
+        dyT = ops.transpose_bf16(dy_bf16, pad_to=128, colsum=csum)   # [N, Mp]
         xT = ops.transpose_bf16(x_bf16, pad_to=128)     # [K, Mp]
         Mp = dyT.shape[1]
         split = max(1, min(32, Mp // 2048))
@@ -375,12 +375,21 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
                 else:
                     ops.gemm_nt(dyT[n0:n1], xT, out_f32=gw, residual=gw)
             n0 = n1
-    n0 = 0
-    for w, b in zip(weights, biases):
-        n1 = n0 + w.shape[0]
-        if b is not None and id(b) in grads:
-            ops.colsum_bf16(dy_bf16[:, n0:n1], grads[id(b)])
-        n0 = n1
+        if csum is not None:
+            n0 = 0
+            for w, b, wb in zip(weights, biases, want_b):
+                n1 = n0 + w.shape[0]
+                if wb:
+                    grads[id(b)].view(-1).add_(csum[n0:n1])
+                n0 = n1
+            bias_done = True
+    if not bias_done:
+        n0 = 0
+        for w, b in zip(weights, biases):
+            n1 = n0 + w.shape[0]
+            if b is not None and id(b) in grads:
+                ops.colsum_bf16(dy_bf16[:, n0:n1], grads[id(b)])
+            n0 = n1
 
 
 class GradBucket:
@@ -407,7 +416,8 @@ def dense_head_backward(dout_f32: torch.Tensor, x_bf16: torch.Tensor, weight: to
     dy_b = ops.cast_bf16(dout_f32) if dout_f32.dtype == F32 else dout_f32
     M, D = dy_b.shape
     K = x_bf16.shape[1]
-    dyT = ops.transpose_bf16(dy_b, pad_to=128)          # [D, Mp]
+    fused_bias = D % 8 == 0 and dy_b.stride(0) % 8 == 0
+    dyT = ops.transpose_bf16(dy_b, pad_to=128, colsum=grads[id(bias)].view(-1) if fused_bias else None)   # [D, Mp] (+ db)
     xT = ops.transpose_bf16(x_bf16, pad_to=128)         # [K, Mp]
     Mp = dyT.shape[1]
     split = max(1, min(32, Mp // 2048))
@@ -418,7 +428,8 @@ def dense_head_backward(dout_f32: torch.Tensor, x_bf16: torch.Tensor, weight: to
         ops.gemm_nt(dyT, xT, out_f32=gw, split_k=split)      # atomically accumulates into the zeroed bucket
     else:
         ops.gemm_nt(dyT, xT, out_f32=gw, residual=gw)        # accumulate in place
-    ops.colsum_bf16(dy_b, grads[id(bias)])
+    if not fused_bias:
+        ops.colsum_bf16(dy_b, grads[id(bias)])
     w_t = ops.cast_transpose_bf16(_f32c(weight))   # [K, D]
     if out_bf16:
         dx = torch.empty((M, K), dtype=BF16, device=dy_b.device)

@@ -134,14 +134,21 @@ def gemm_nt(
     check(_lib.load().clibd_gemm_bf16_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, C.byref(ep), _stream()), "gemm_bf16_nt")
 
 
-def transpose_bf16(x: torch.Tensor, pad_to: int = 64) -> torch.Tensor:
-    """[R,C] bf16 -> [C, R_pad] bf16 (zero padded along R to a multiple of `pad_to`)."""
+def transpose_bf16(x: torch.Tensor, pad_to: int = 64, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[R,C] bf16 -> [C, R_pad] bf16 (zero padded along R to a multiple of `pad_to`).
+    colsum (fp32 [C], accumulates): column sums of x in the same pass (bias gradient beside the weight gradient's dy^T)."""
     _chk(x, BF16, "x", contiguous=False)
     ld = _rowmajor(x, "x")
     R, Cc = x.shape
     Rp = (R + pad_to - 1) // pad_to * pad_to
     out = torch.empty((Cc, Rp), dtype=BF16, device=x.device)
-    check(_lib.load().clibd_transpose_bf16(x.data_ptr(), ld, R, Cc, out.data_ptr(), Rp, _stream()), "transpose_bf16")
+    if colsum is not None:
+        _chk(colsum, F32, "colsum")
+        if colsum.numel() != Cc:
+            raise ValueError("transpose_bf16: colsum must have C elements")
+        check(_lib.load().clibd_transpose_colsum_bf16(x.data_ptr(), ld, R, Cc, out.data_ptr(), Rp, colsum.data_ptr(), _stream()), "transpose_colsum_bf16")
+    else:
+        check(_lib.load().clibd_transpose_bf16(x.data_ptr(), ld, R, Cc, out.data_ptr(), Rp, _stream()), "transpose_bf16")
     return out
 
 
@@ -181,7 +188,8 @@ def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, l
                                           _p(stats), _p(lora_a), _p(t_out), _stream()), "layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, drop=None) -> None:
+def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, drop=None, dgamma=None, dbeta=None) -> None:
+    """dgamma / dbeta (fp32 [H], accumulate): the LayerNorm parameter gradients in the same pass (full fine-tune mode)."""
     _chk(x, F32, "x")
     M, H = x.shape
     if dy.dtype == BF16:
@@ -199,6 +207,15 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, 
             _chk(t, dt, nm)
             if tuple(t.shape) != (M, H):
                 raise ValueError(f"layernorm_bwd: {nm} shape")
+    if dgamma is not None or dbeta is not None:
+        _chk(dgamma, F32, "dgamma"); _chk(dbeta, F32, "dbeta")
+        if dgamma.numel() != H or dbeta.numel() != H:
+            raise ValueError("layernorm_bwd: dgamma / dbeta must have H elements")
+        d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
+        check(_lib.load().clibd_layernorm_bwd_pg(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres), _p(dx_f32),
+                                                 _p(dx_bf16), d.seed, d.thr16, d.scale, dgamma.data_ptr(), dbeta.data_ptr(), _stream()),
+              "layernorm_bwd_pg")
+        return
     if drop is not None and drop.thr16 > 0:
         check(_lib.load().clibd_layernorm_bwd_drop(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres), _p(dx_f32),
                                                    _p(dx_bf16), drop.seed, drop.thr16, drop.scale, _stream()), "layernorm_bwd_drop")

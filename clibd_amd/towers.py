@@ -159,9 +159,8 @@ class ViTTower(_Tower):
         dxcls = torch.empty((B, H), dtype=F32, device=dout.device)
         dxcls_b = torch.empty((B, H), dtype=BF16, device=dout.device)
         full = state["full"]
-        if full and id(v.norm.weight) in grads:
-            ops.layernorm_param_grads(dxn, state["xcls"], state["st"], grads[id(v.norm.weight)], grads[id(v.norm.bias)])
-        ops.layernorm_bwd(dxn, state["xcls"], state["st"], _f32c(v.norm.weight), dx_f32=dxcls, dx_bf16=dxcls_b)
+        pg = dict(dgamma=grads[id(v.norm.weight)].view(-1), dbeta=grads[id(v.norm.bias)].view(-1)) if full and id(v.norm.weight) in grads else {}
+        ops.layernorm_bwd(dxn, state["xcls"], state["st"], _f32c(v.norm.weight), dx_f32=dxcls, dx_bf16=dxcls_b, **pg)
         dtok = self.stack.backward(dxcls, dxcls_b, state["saved"], B, S, None, grads, full=full)  # [B,H]: the last block runs class-row-only
         if full:
             # tokens = [cls + pos[0] | patch_proj + pos[1:]]  (timm VisionTransformer._pos_embed)
@@ -311,10 +310,9 @@ class BertTower(_Tower):
             dlogits = ops.softmax_mean_bwd(state["logits"], dout, B, S)
             dhln = dense_head_backward(dlogits, state["hln"], dec.weight, dec.bias, grads, out_bf16=True)
             full = state["full"]
-            if full and id(tln.weight) in grads:
-                ops.layernorm_param_grads(dhln, state["g"], state["st"], grads[id(tln.weight)], grads[id(tln.bias)])
+            pg = dict(dgamma=grads[id(tln.weight)].view(-1), dbeta=grads[id(tln.bias)].view(-1)) if full and id(tln.weight) in grads else {}
             dg = torch.empty((M, H), dtype=BF16, device=dev)
-            ops.layernorm_bwd(dhln, state["g"], state["st"], _f32c(tln.weight), dx_bf16=dg)
+            ops.layernorm_bwd(dhln, state["g"], state["st"], _f32c(tln.weight), dx_bf16=dg, **pg)
             dhpre = ops.gelu_bwd(dg, state["hpre"])
             if full:
                 td = self.hm["transform_dense"]
@@ -333,12 +331,13 @@ class BertTower(_Tower):
             lw, lb = emb.LayerNorm.weight, emb.LayerNorm.bias
             if state["d_emb"] is not None and state["d_emb"].thr16 > 0:
                 dx0 = ops.dropout_apply(dx0, state["d_emb"])  # gradient w.r.t. the LayerNorm output
-            if id(lw) in grads:
-                ops.layernorm_param_grads(dx0, state["e"], state["st_e"], grads[id(lw)], grads[id(lb)])
+            pg = dict(dgamma=grads[id(lw)].view(-1), dbeta=grads[id(lb)].view(-1)) if id(lw) in grads else {}
             tabs = [emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight]
-            if any(id(t) in grads for t in tabs):
+            need_de = any(id(t) in grads for t in tabs)
+            if need_de or pg:
                 de = torch.empty((M, H), dtype=F32, device=dev)
-                ops.layernorm_bwd(dx0, state["e"], state["st_e"], _f32c(lw), dx_f32=de)
+                ops.layernorm_bwd(dx0, state["e"], state["st_e"], _f32c(lw), dx_f32=de, **pg)   # + d(gamma), d(beta) in the same pass
+            if need_de:
                 if id(tabs[1]) in grads:
                     ops.batch_sum(de.view(B, S * H), grads[id(tabs[1])][:S])
                 ops.bert_embed_bwd(state["ids"].view(-1), None if state["tt"] is None else state["tt"].view(-1), de,

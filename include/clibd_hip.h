@@ -86,6 +86,9 @@ int clibd_gemm_bf16_nt_khole(const void* A, int lda, const void* W, int ldw, int
 /* bf16 transpose with zero padding: out[C, ld_out] (ld_out >= R) = in[R, C]^T; columns R..ld_out-1 zero.
  * Used to feed the weight-gradient GEMMs (contraction over the token dimension). */
 int clibd_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
+/* same, and colsum[c] += sum_r in[r, c] (fp32, accumulates): the bias gradient of a linear layer rides along with the transpose
+ * of dy that its weight gradient needs (full fine-tune mode).  Needs C, ld_in, ld_out multiples of 8, 16-byte aligned bases. */
+int clibd_transpose_colsum_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum, void* stream);
 
 /* fp32 -> bf16 cast of a contiguous buffer (weights are kept fp32 in the state dict, bf16 shadow copies
  * feed the MFMA path, as torch.autocast does per call in the reference, epoch/train_epoch.py:43). */
@@ -120,6 +123,11 @@ int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x
 int clibd_layernorm_bwd_drop(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
                              const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
                              void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
+/* full fine-tune mode: the same backward that also accumulates the parameter gradients it has the operands for
+ *   dgamma[c] += sum_m dy[m,c] * xhat[m,c],  dbeta[c] += sum_m dy[m,c]     (fp32 [H], caller zeroes once per step). */
+int clibd_layernorm_bwd_pg(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
+                           int M, int H, const float* dres_f32, float* dx_f32, void* dx_bf16, uint32_t drop_seed, int drop_thr16,
+                           float drop_scale, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3: multi-head attention, head dim 64, whole sequence per workgroup (S <= 256: ViT 197, BarcodeBERT 133,

@@ -708,3 +708,51 @@ def test_gemm_splitk_workspace_exact(ops, dev, M, N, K):
     assert ops.gemm_nt_splitk(ad, wd, out2, accumulate=False)
     assert torch.equal(out2, ref)
     assert not ops.gemm_nt_splitk(ad[:, :448], wd[:, :448], out2)   # K < 512: caller falls back to gemm_nt(split_k=)
+
+
+# ----------------------------------------------------------------------------------------------- round 2: full fine-tune fusions
+@pytest.mark.parametrize("R,C,ld_extra", [(300, 256, 0), (50432, 768, 0), (133 * 7 + 3, 3072, 8), (64, 64, 0), (1000, 72, 16)])
+def test_transpose_with_column_sums(ops, dev, R, C, ld_extra):
+    """clibd_transpose_colsum_bf16: bit-exact transpose (zero padded rows) + column sums accumulated in fp32."""
+    g = torch.Generator().manual_seed(R + C)
+    big = torch.randn(R, C + ld_extra, generator=g).to(BF16)
+    x = big.to(dev)[:, :C]
+    cs = torch.full((C,), 0.5, device=dev)
+    out = ops.transpose_bf16(x, pad_to=128, colsum=cs)
+    torch.cuda.synchronize()
+    Rp = (R + 127) // 128 * 128
+    assert tuple(out.shape) == (C, Rp)
+    ref = big[:, :C].T.contiguous()
+    assert torch.equal(out[:, :R].cpu(), ref) and float(out[:, R:].float().abs().sum()) == 0.0
+    assert rel_err(cs.cpu() - 0.5, big[:, :C].double().sum(0)) < 2e-5
+    assert torch.equal(ops.transpose_bf16(x, pad_to=128).cpu(), out.cpu())           # same kernel without the sums
+
+
+@pytest.mark.parametrize("M,H,f32dy,drop,res", [(300, 768, False, False, True), (5000, 768, True, True, False), (133, 512, True, False, False),
+                                                (64, 1024, False, False, True)])
+def test_layernorm_bwd_with_fused_param_grads(ops, dev, M, H, f32dy, drop, res):
+    """clibd_layernorm_bwd_pg = clibd_layernorm_bwd (bit-identical dx) + d(gamma), d(beta) accumulated in the same pass."""
+    g = torch.Generator().manual_seed(M + H)
+    x = torch.randn(M, H, generator=g) * 2 + 0.3
+    gam, bet = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    dy = torch.randn(M, H, generator=g)
+    dyd = dy.to(dev) if f32dy else dy.to(dev, BF16)
+    dyr = dy if f32dy else bfr(dy)
+    st = torch.empty((M, 2), device=dev)
+    y = torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_fwd(x.to(dev), gam.to(dev), bet.to(dev), 1e-6, y_bf16=y, stats=st)
+    d = ops.Drop(0.1, 777) if drop else None
+    dres = torch.randn(M, H, generator=g).to(dev) if res else None
+    outs = []
+    for fused in (False, True):
+        dxf, dxb = torch.empty((M, H), device=dev), torch.empty((M, H), dtype=BF16, device=dev)
+        dgam, dbet = torch.full((H,), 0.25, device=dev), torch.full((H,), -0.5, device=dev)
+        kw = dict(dgamma=dgam, dbeta=dbet) if fused else {}
+        ops.layernorm_bwd(dyd, x.to(dev), st, gam.to(dev), dres=dres, dx_f32=dxf, dx_bf16=dxb, drop=d, **kw)
+        torch.cuda.synchronize()
+        outs.append((dxf.cpu(), dxb.cpu(), dgam.cpu(), dbet.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    xd = x.double()
+    xhat = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6)
+    assert rel_err(outs[1][2] - 0.25, (dyr.double() * xhat).sum(0)) < 2e-4
+    assert rel_err(outs[1][3] + 0.5, dyr.double().sum(0)) < 2e-4
