@@ -356,9 +356,12 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
     bias_done = False
     if any(id(w) in grads for w in weights):
         N = dy_bf16.shape[1]
-        csum = None
+        csum, direct = None, False
         if any(want_b) and N % 8 == 0 and dy_bf16.stride(0) % 8 == 0:
-            csum = torch.zeros((N,), dtype=F32, device=dy_bf16.device)   # column sums of dy in the same pass as its transpose
+            if len(weights) == 1:
+                csum, direct = grads[id(biases[0])].view(-1), True        # one bias over all N columns: accumulate in place
+            else:
+                csum = torch.zeros((N,), dtype=F32, device=dy_bf16.device)   # column sums of dy in the same pass as its transpose
         dyT = ops.transpose_bf16(dy_bf16, pad_to=128, colsum=csum)   # [N, Mp]
         xT = ops.transpose_bf16(x_bf16, pad_to=128)     # [K, Mp]
         Mp = dyT.shape[1]
@@ -379,7 +382,7 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
             n0 = 0
             for w, b, wb in zip(weights, biases, want_b):
                 n1 = n0 + w.shape[0]
-                if wb:
+                if wb and not direct:
                     grads[id(b)].view(-1).add_(csum[n0:n1])
                 n0 = n1
             bias_done = True

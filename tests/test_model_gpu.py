@@ -638,3 +638,22 @@ def test_full_size_model_matches_oracle(dev):
     allo = torch.cat([(torch.zeros_like(p) if go[n] is None else go[n]).flatten() for n, p in sorted(ps)])
     assert sorted(got) == sorted(n for n, _ in ps)
     assert cos(allg, allo) > 0.99 and rel(allg, allo) < 0.15   # 24 layers of bf16 rounding under the x14.3 temperature
+
+
+def test_device_prefetcher_delivers_the_batches_in_order(dev):
+    """clibd_amd.data.DevicePrefetcher: batch i+1 is copied on a side stream while batch i is in use; contents and order must
+    be exactly the host iterator's (nested dict / tuple structure preserved, non-tensor leaves passed through)."""
+    from clibd_amd.data import DevicePrefetcher
+
+    g = torch.Generator().manual_seed(3)
+    host = [{"image": torch.rand(8, 3, 32, 32, generator=g).pin_memory(), "dna": torch.randint(0, 1027, (8, 133), generator=g).pin_memory(),
+             "text": {"input_ids": torch.randint(0, 100, (8, 20), generator=g)}, "ids": [f"s{i}"], "pair": (torch.full((4,), float(i)), i)}
+            for i in range(5)]
+    seen = 0
+    for i, bt in enumerate(DevicePrefetcher(iter(host), dev)):
+        y = bt["image"] * 2.0       # use it on the compute stream right away
+        assert bt["image"].is_cuda and torch.equal(bt["image"].cpu(), host[i]["image"]) and torch.equal(bt["dna"].cpu(), host[i]["dna"])
+        assert torch.equal(bt["text"]["input_ids"].cpu(), host[i]["text"]["input_ids"]) and bt["ids"] == [f"s{i}"]
+        assert torch.equal(bt["pair"][0].cpu(), host[i]["pair"][0]) and bt["pair"][1] == i and torch.equal(y.cpu(), host[i]["image"] * 2.0)
+        seen += 1
+    assert seen == 5
