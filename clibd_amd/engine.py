@@ -73,6 +73,19 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t if (t.dtype == F32 and t.is_contiguous()) else t.to(F32).contiguous()
 
 
+def _pad_rank4(lp: "LoraParams"):
+    """The kernels carry the adapters as rank 4 + 4 (one MFMA k-slot of 8).  Ranks 1-3 (the reference accepts any r > 0,
+    image_encoder.py:53; every shipped config uses 4) run zero-padded: A gets zero rows, B zero columns — the same product."""
+    a_q, a_v, b_q, b_v = _f32c(lp.a_q), _f32c(lp.a_v), _f32c(lp.b_q), _f32c(lp.b_v)
+    r = a_q.shape[0]
+    if r == 4:
+        return a_q, a_v, b_q, b_v
+    H = a_q.shape[1]
+    pa = lambda a: torch.cat([a, a.new_zeros((4 - r, H))], dim=0)
+    pb = lambda b: torch.cat([b, b.new_zeros((H, 4 - r))], dim=1).contiguous()
+    return pa(a_q), pa(a_v), pb(b_q), pb(b_v)
+
+
 class TransformerStack:
     """Shared machinery of the ViT (pre-LN) and BERT (post-LN) encoder stacks."""
 
@@ -134,7 +147,7 @@ class TransformerStack:
                 c.a_cat = torch.empty((8, H), dtype=BF16, device=dev)
                 c.w_dt = torch.empty((16, 3 * H), dtype=BF16, device=dev)
             lp = L.lora
-            ops.lora_pack(_f32c(lp.a_q), _f32c(lp.a_v), _f32c(lp.b_q), _f32c(lp.b_v), c.v_fwd, c.v_bwd, c.a_cat, c.w_dt)
+            ops.lora_pack(*_pad_rank4(lp), c.v_fwd, c.v_bwd, c.a_cat, c.w_dt)
 
     def lora_a(self, i: int):
         if i >= len(self.layers) or self.layers[i].lora is None:
@@ -340,7 +353,16 @@ class TransformerStack:
         # dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v; the k segment of dqkv meets zero weights in w_dt and is not read
         ops.gemm_nt(dqkv, c.w_dt, out_bf16=dt, k_hole=(H, H))
         lp = L.lora
-        ops.lora_wgrad(dqkv, x_bf16, t, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
+        r = lp.a_q.shape[0]
+        if r == 4:
+            ops.lora_wgrad(dqkv, x_bf16, t, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
+        else:   # ranks 1-3: rank-4 scratch gradients (the padded rows / columns receive exact zeros' worth of signal), sliced back
+            dev = dqkv.device
+            ga_q, ga_v = torch.zeros((4, H), dtype=F32, device=dev), torch.zeros((4, H), dtype=F32, device=dev)
+            gb_q, gb_v = torch.zeros((H, 4), dtype=F32, device=dev), torch.zeros((H, 4), dtype=F32, device=dev)
+            ops.lora_wgrad(dqkv, x_bf16, t, dt, ga_q, ga_v, gb_q, gb_v)
+            grads[id(lp.a_q)].add_(ga_q[:r]); grads[id(lp.a_v)].add_(ga_v[:r])
+            grads[id(lp.b_q)].add_(gb_q[:, :r]); grads[id(lp.b_v)].add_(gb_v[:, :r])
 
 
 def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], grads: dict):

@@ -697,3 +697,39 @@ def test_other_vit_sizes_match_oracle(dev, name, dim, depth, heads):
     per_tensor_scale = allo.double().norm().item() / len(keys) ** 0.5
     worst = max(((got[n].double() - go[n].double()).norm().item() / per_tensor_scale, n) for n in keys)
     assert worst[0] < 5e-2, worst
+
+
+@pytest.mark.parametrize("r", [1, 2, 3])
+def test_lora_ranks_below_four(dev, r):
+    """The reference accepts any r > 0 (image_encoder.py:53, dna_encoder.py:84); its configs use 4.  Ranks 1-3 run zero-padded on
+    the rank-4 kernels: outputs and all adapter gradients (shapes [r,H] / [H,r]) against the oracle, both tower kinds."""
+    from oracle import clibd_oracle as O
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder, CLIBDImageEncoder, VisionTransformer
+
+    torch.manual_seed(40 + r)
+    g = torch.Generator().manual_seed(r)
+    od = O.DNAEncoder(O.BertForMaskedLM(vocab=1027, hidden=128, layers=2, heads=2, ff=256), r=r, num_classes=128)
+    oi = O.ImageEncoder(O.VisionTransformer(img_size=224, patch=16, dim=128, depth=2, heads=2, num_classes=10), r, 128)
+    with torch.no_grad():
+        for om in (od, oi):
+            for n, p in om.named_parameters():
+                if p.dim() >= 2:
+                    p.normal_(0, 0.05)
+    hd = CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                                        intermediate_size=256)), r=r, num_classes=128)
+    hi = CLIBDImageEncoder(VisionTransformer(embed_dim=128, depth=2, num_heads=2, num_classes=10), r=r, num_classes=128)
+    hd.load_state_dict(od.state_dict(), strict=True)
+    hi.load_state_dict(oi.state_dict(), strict=True)
+    ids = torch.cat([torch.zeros(3, 1, dtype=torch.long), torch.randint(3, 1027, (3, 132), generator=g)], dim=1)
+    img = torch.rand(3, 3, 224, 224, generator=g)
+    for hm, om, x in ((hd.to(dev).eval(), od.eval(), ids), (hi.to(dev).eval(), oi.eval(), img)):
+        cot = torch.randn(3, 128, generator=g)
+        y = hm(x.to(dev))
+        got = grads_named(hm, (y * cot.to(dev)).sum())
+        with O.precision("bf16"):
+            yo = om(x)
+            ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+            go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
+        assert rel(y.cpu(), yo.detach()) < 3e-3
+        assert any(tuple(v.shape) in ((r, 128), (128, r)) for v in got.values())
+        assert_grads(got, go, rel_tol=5e-2, cos_tol=0.998, what=f"r={r}")   # random N(0, 0.05) weights, batch 3: single tensors reach 3 %
