@@ -733,3 +733,42 @@ def test_lora_ranks_below_four(dev, r):
         assert rel(y.cpu(), yo.detach()) < 3e-3
         assert any(tuple(v.shape) in ((r, 128), (128, r)) for v in got.values())
         assert_grads(got, go, rel_tol=5e-2, cos_tol=0.998, what=f"r={r}")   # random N(0, 0.05) weights, batch 3: single tensors reach 3 %
+
+
+def test_training_trajectory_matches_oracle(dev):
+    """Ten optimizer steps of the b=8 tri-modal fixture: `Trainer.step` on the HIP path (fused AdamW on the flat bucket) against
+    the oracle's bf16 mode trained with torch.optim.AdamW on the CPU from the same weights — the whole loop of train_epoch.py:21-63
+    (forward, loss, backward, AdamW), not a single evaluation: per-step losses within 2e-3, final adapter / head parameters on
+    the oracle's direction (update cosine > 0.98)."""
+    from clibd_amd.model import SimpleCLIP
+    from clibd_amd.train import Trainer
+    from oracle import clibd_oracle as O
+
+    gs, gd, gt, gi = load("step_tiny_golden.pt"), load("dna_tiny_golden.pt"), load("text_tiny_golden.pt"), load("image_tiny_golden.pt")
+    model = SimpleCLIP(hip_image(gi, dev), hip_dna(gd, dev), hip_text(gt, dev)).to(dev)   # eval(): dropout off on both sides
+    build_dna, build_text, build_image = oracle_models()
+    om = O.SimpleCLIP(build_image(gi), build_dna(gd), build_text(gt))
+    with torch.no_grad():
+        model.logit_scale.copy_(gs["logit_scale"])
+        om.logit_scale.copy_(gs["logit_scale"])
+    start = {n: p.detach().clone() for n, p in om.named_parameters() if p.requires_grad}
+    tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True)
+    oopt = torch.optim.AdamW([p for p in om.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-2)
+    img = gs["image_u8"].float() / 255.0
+    text_d = {k: v.to(dev) for k, v in gs["text"].items()}
+    hl, ol = [], []
+    for _ in range(10):
+        hl.append(float(tr.step(img.to(dev), gs["dna"].to(dev), text_d, gs["labels"].to(dev))))
+        oopt.zero_grad()
+        with O.precision("bf16"):
+            oi, od, ot, osc, _ = om(img, gs["dna"], gs["text"])
+            lo = O.contrastive_loss([oi, od, ot], gs["labels"], osc)
+        lo.backward()
+        oopt.step()
+        ol.append(float(lo.detach()))
+    assert ol[-1] < ol[0] - 0.05                                         # it trains
+    assert max(abs(a - b) for a, b in zip(hl, ol)) < 2e-3, list(zip(hl, ol))
+    hp = {n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    du_h = torch.cat([(hp[n] - start[n]).flatten() for n in sorted(start)])
+    du_o = torch.cat([(dict(om.named_parameters())[n].detach() - start[n]).flatten() for n in sorted(start)])
+    assert cos(du_h, du_o) > 0.98 and rel(du_h, du_o) < 0.2, (cos(du_h, du_o), rel(du_h, du_o))
