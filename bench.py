@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-batch (PCIe-inclusive) side measurement")
     ap.add_argument("--no-gemm-timing", action="store_true")
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
+    ap.add_argument("--fp8-forward", action="store_true", help="BASELINE configs[4]: forward GEMMs on the fp8 MFMA (not the headline config)")
     ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
     return ap.parse_args()
 
@@ -56,6 +57,7 @@ class GemmTimer:
 
     def __init__(self):
         self.events, self.flops, self.enabled, self.shapes, self.bytes = [], 0.0, False, [], 0.0
+        self.flops_fp8 = 0.0
 
     def install(self):
         from clibd_amd import ops
@@ -76,7 +78,25 @@ class GemmTimer:
             timer.bytes += 2.0 * a.shape[1] * (a.shape[0] + w.shape[0]) + float(per_out) * a.shape[0] * w.shape[0]
             timer.shapes.append((a.shape[0], w.shape[0], a.shape[1], "+".join(sorted(k for k, v in kw.items() if v is not None))))
 
+        inner8 = ops.gemm_fp8_nt
+
+        def timed8(a, w, cs, **kw):
+            if not timer.enabled:
+                return inner8(a, w, cs, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inner8(a, w, cs, **kw)
+            e1.record()
+            timer.events.append((e0, e1))
+            fl = 2.0 * a.shape[0] * w.shape[0] * a.shape[1]
+            timer.flops += fl
+            timer.flops_fp8 += fl
+            per_out = sum(b_ for k_, b_ in (("out_bf16", 2), ("out_pre", 2), ("out_f32", 4), ("residual", 4), ("gelu_out_fp8", 1)) if kw.get(k_) is not None)
+            timer.bytes += 1.0 * a.shape[1] * (a.shape[0] + w.shape[0]) + float(per_out) * a.shape[0] * w.shape[0]
+            timer.shapes.append((a.shape[0], w.shape[0], a.shape[1], "fp8+" + "+".join(sorted(k for k, v in kw.items() if v is not None))))
+
         ops.gemm_nt = timed
+        ops.gemm_fp8_nt = timed8
         import clibd_amd.engine as eng
         import clibd_amd.towers as tw
 
@@ -86,8 +106,10 @@ class GemmTimer:
         if not self.events:
             return None
         ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events)
+        # time the same launches would take at the dense MFMA peaks (fp8 launches priced at the fp8 peak = 2 x bf16)
+        ideal_ms = ((self.flops - self.flops_fp8) / (PEAK_BF16_TFLOPS * 1e12) + self.flops_fp8 / (2 * PEAK_BF16_TFLOPS * 1e12)) * 1e3
         return {"launches": len(self.events), "total_ms": ms, "tflops": self.flops / (ms * 1e-3) / 1e12,
-                "bytes_per_launch": self.bytes / len(self.events)}
+                "bytes_per_launch": self.bytes / len(self.events), "frac": ideal_ms / ms, "fp8_flop_share": self.flops_fp8 / max(self.flops, 1.0)}
 
     def breakdown(self, steps):
         agg = {}
@@ -217,6 +239,8 @@ def main():
     if args.full_finetune:
         for p_ in model.parameters():
             p_.requires_grad_(True)
+    if args.fp8_forward:
+        model.enable_fp8_forward()
     trainer = Trainer(model, lr=scale_learning_rate(1e-3, b, world_size=world), world_size=world, rank=rank, all_gather=True)
     batch = synthetic_batch(b, dev, seed=42, rank=rank, with_text=args.tri_modal)
 
@@ -346,7 +370,7 @@ def main():
             roof["traffic_note"] = stale
         if gemm:
             gsteps = gemm["steps"]
-            roof.update(achieved=gemm["tflops"], frac=gemm["tflops"] / PEAK_BF16_TFLOPS, launches=gemm["launches"],
+            roof.update(achieved=gemm["tflops"], frac=gemm["frac"], launches=gemm["launches"],
                         gemm_ms_per_step=gemm["total_ms"] / gsteps, avg_launch_us=gemm["total_ms"] / gemm["launches"] * 1e3,
                         algorithmic_bytes_per_launch=gemm["bytes_per_launch"])
             if serial is not None:
@@ -356,10 +380,11 @@ def main():
             "metric": (f"paired samples/sec/step (I+D contrastive), global batch {b * world}" if not args.tri_modal
                        else f"triples/sec/step (I+D+T contrastive), global batch {b * world}"),
             "value": pairs_per_s, "unit": "paired samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16" if not args.fp8_forward else "fp8 (e4m3) forward GEMMs + bf16",
             "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights)",
-            "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
-                                   ("FULL fine-tune (disable_lora)" if args.full_finetune else "LoRA r=4") + ", bf16 MFMA" +
+            "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune and not args.fp8_forward else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
+                                   ("FULL fine-tune (disable_lora)" if args.full_finetune else "LoRA r=4") +
+                                   (", bf16 MFMA" if not args.fp8_forward else ", fp8-forward mode (BASELINE configs[4]): forward GEMMs on the fp8 MFMA, backward bf16") +
                                    (" + BERT-small text tower" if args.tri_modal else ""),
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}", "image": "3x224x224", "dna_tokens": 133,
                        "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW"},

@@ -48,6 +48,8 @@ SIGNATURES = {
     "clibd_abi_version": (c_int, []),
     "clibd_gemm_bf16_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
     "clibd_gemm_bf16_nt_khole": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
+    "clibd_gemm_fp8_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, C.POINTER(GemmEpilogue), c_void_p]),
+    "clibd_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clibd_transpose_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "clibd_transpose_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "clibd_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -56,6 +58,8 @@ SIGNATURES = {
     "clibd_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_layernorm_fwd_drop": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),
     "clibd_layernorm_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),
+    "clibd_layernorm_fwd_fp8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p, c_float, c_void_p]),
+    "clibd_attention_fwd_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_float, c_void_p]),
     "clibd_layernorm_bwd_pg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clibd_attention_fwd_drop": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),
     "clibd_attention_bwd_drop": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ out, float scale,
                                                                     int nq, int out_seq, unsigned drop_seed,
-                                                                    int drop_thr16, float drop_scale) {
+                                                                    int drop_thr16, float drop_scale, float out_fp8_scale) {
+    // out_fp8_scale > 0 (fp8-forward mode): `out` holds OCP e4m3 bytes, fp8(o * out_fp8_scale) — the projection GEMM's operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
     char* kt_lds = smem;
@@ -214,13 +215,22 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
             for (int t = 0; t < 2; ++t) {
                 const int q = (2 * p + t) * 16 + i;
                 if (q < nq) {
-                    unsigned short* orow = out + ((size_t)b * out_seq + q) * H + h * DH;
+                    const size_t oidx = ((size_t)b * out_seq + q) * H + h * DH;
+                    if (out_fp8_scale > 0.f) {
+                        unsigned char* orow8 = (unsigned char*)out + oidx;
+                        const float sc8 = inv[t] * out_fp8_scale;
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        uint2 pk;
-                        pk.x = pack2bf(o[t][dt][0] * inv[t], o[t][dt][1] * inv[t]);
-                        pk.y = pack2bf(o[t][dt][2] * inv[t], o[t][dt][3] * inv[t]);
-                        *(uint2*)(orow + 16 * dt + 4 * g) = pk;
+                        for (int dt = 0; dt < 4; ++dt)
+                            *(unsigned*)(orow8 + 16 * dt + 4 * g) = pack4fp8(o[t][dt][0] * sc8, o[t][dt][1] * sc8, o[t][dt][2] * sc8, o[t][dt][3] * sc8);
+                    } else {
+                        unsigned short* orow = out + oidx;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            uint2 pk;
+                            pk.x = pack2bf(o[t][dt][0] * inv[t], o[t][dt][1] * inv[t]);
+                            pk.y = pack2bf(o[t][dt][2] * inv[t], o[t][dt][3] * inv[t]);
+                            *(uint2*)(orow + 16 * dt + 4 * g) = pk;
+                        }
                     }
                 }
             }
@@ -295,13 +305,22 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(vt_lds, s, dt, lane), pf, o[dt], 0, 0, 0);
         }
         if (q < nq) {
-            unsigned short* orow = out + ((size_t)b * out_seq + q) * H + h * DH;
+            const size_t oidx = ((size_t)b * out_seq + q) * H + h * DH;
+            if (out_fp8_scale > 0.f) {
+                unsigned char* orow8 = (unsigned char*)out + oidx;
+                const float sc8 = inv * out_fp8_scale;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 pk;
-                pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
-                pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-                *(uint2*)(orow + 16 * dt + 4 * g) = pk;
+                for (int dt = 0; dt < 4; ++dt)
+                    *(unsigned*)(orow8 + 16 * dt + 4 * g) = pack4fp8(o[dt][0] * sc8, o[dt][1] * sc8, o[dt][2] * sc8, o[dt][3] * sc8);
+            } else {
+                unsigned short* orow = out + oidx;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    uint2 pk;
+                    pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+                    pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+                    *(uint2*)(orow + 16 * dt + 4 * g) = pk;
+                }
             }
         }
     }
@@ -710,8 +729,8 @@ using namespace clibd;
         default: MACRO(16); break;    \
     }
 
-extern "C" int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
-                                        int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
+                              int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, float out_fp8_scale, void* stream) {
     if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "attention_fwd: bad dropout threshold");
     if (drop_thr16 > 0 && (unsigned long long)B * nheads * S * 256ull >= (1ull << 32)) return set_error(CLIBD_EINVAL, "attention_fwd: dropout index overflow");
     if (int e = att_check(qkv, B, S, nheads, "fwd")) return e;
@@ -726,7 +745,7 @@ extern "C" int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nhead
         hipFuncSetAttribute((const void*)attention_fwd_kernel<N, (N >= 10), MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((attention_fwd_kernel<N, (N >= 10), MSK, DRP>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,       \
                            (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
-                           drop_seed, drop_thr16, drop_scale);                                                    \
+                           drop_seed, drop_thr16, drop_scale, out_fp8_scale);                                     \
     } while (0)
 #define LAUNCH(N)                                                        \
     do {                                                                 \
@@ -739,6 +758,18 @@ extern "C" int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nhead
 #undef LAUNCH
 #undef LAUNCH_M
     return check_launch("attention_fwd");
+}
+
+extern "C" int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
+                                        int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+    return attention_fwd_impl(qkv, B, S, nheads, key_mask, out, nq, out_seq, drop_seed, drop_thr16, drop_scale, 0.f, stream);
+}
+
+extern "C" int clibd_attention_fwd_fp8(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out_fp8,
+                                       int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, float out_fp8_scale,
+                                       void* stream) {
+    if (!(out_fp8_scale > 0.f)) return set_error(CLIBD_EINVAL, "attention_fwd_fp8: scale must be positive");
+    return attention_fwd_impl(qkv, B, S, nheads, key_mask, out_fp8, nq, out_seq, drop_seed, drop_thr16, drop_scale, out_fp8_scale, stream);
 }
 
 extern "C" int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,

@@ -30,6 +30,22 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ float bfround(float x) { return bf2f(f2bf(x)); }
 
+// ---- OCP fp8 e4m3 (gfx950's v_cvt_pk_fp8_f32; max finite 448) for the fp8-forward mode: values are clamped first, so the
+// result never depends on the conversion's overflow mode.  pack4fp8: byte i = fp8(v_i).
+__device__ __forceinline__ unsigned pack4fp8(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+__device__ __forceinline__ uint2 pack8fp8(const float v[8], float s) {
+    uint2 o;
+    o.x = pack4fp8(v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+    o.y = pack4fp8(v[4] * s, v[5] * s, v[6] * s, v[7] * s);
+    return o;
+}
+
 // 16-byte LDS-DMA: each lane supplies its own global source; LDS dest = wave-uniform base + lane*16
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);

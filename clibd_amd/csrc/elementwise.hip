@@ -333,6 +333,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 using namespace clibd;
 
+// ---- fp8-forward mode: per-output-channel quantisation of a frozen weight matrix ------------------------------------------
+namespace clibd {
+// one wave per row: s = 448 / max|w[n,:]|, w8[n,k] = e4m3(w[n,k] * s), col_scale[n] = 1 / (s * act_scale)
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const float* __restrict__ w, int N, int K, float act_scale,
+                                                               unsigned char* __restrict__ w8, float* __restrict__ col_scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* wr = w + (size_t)row * K;
+    float amax = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const f32x4 v = *(const f32x4*)(wr + k);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? 448.f / amax : 1.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const f32x4 v = *(const f32x4*)(wr + k);
+        *(unsigned*)(w8 + (size_t)row * K + k) = pack4fp8(v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+    }
+    if (lane == 0) col_scale[row] = 1.f / (s * act_scale);
+}
+}  // namespace clibd
+
+extern "C" int clibd_quantize_rows_fp8(const float* w, int N, int K, float act_scale, void* w_fp8, float* col_scale, void* stream) {
+    if (!w || !w_fp8 || !col_scale) return set_error(CLIBD_EINVAL, "quantize_rows_fp8: null pointer");
+    if (N <= 0 || K <= 0 || (K & 3) || !(act_scale > 0.f) || !aligned16(w) || ((uintptr_t)w_fp8 & 3)) return set_error(CLIBD_EINVAL, "quantize_rows_fp8: bad args (K % 4, act_scale > 0, alignment)");
+    hipLaunchKernelGGL(clibd::quantize_rows_fp8_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w, N, K, act_scale,
+                       (unsigned char*)w_fp8, col_scale);
+    return check_launch("quantize_rows_fp8");
+}
+
 extern "C" int clibd_patchify(const float* image, int B, void* patches_bf16, void* stream) {
     if (!image || !patches_bf16 || B <= 0) return set_error(CLIBD_EINVAL, "patchify: bad args");
     if (!aligned16(image) || !aligned16(patches_bf16)) return set_error(CLIBD_EINVAL, "patchify: alignment");

@@ -318,6 +318,30 @@ extern "C" int clibd_gemm_bf16_nt_khole(const void* A, int lda, const void* W, i
     return gemm_impl(A, lda, W, ldw, M, N, K, hole_k0, hole_len, ep, stream);
 }
 
+extern "C" int clibd_gemm_fp8_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* col_scale,
+                                 float out_fp8_scale, const clibd_gemm_epilogue* ep, void* stream) {
+    if (!A || !W || !ep || !col_scale) return set_error(CLIBD_EINVAL, "gemm_fp8: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K) return set_error(CLIBD_EINVAL, "gemm_fp8: bad shape");
+    if ((lda & 15) || (ldw & 15) || !aligned16(A) || !aligned16(W) || !aligned16(col_scale)) return set_error(CLIBD_EINVAL, "gemm_fp8: alignment (lda, ldw % 16)");
+    if (ep->ld_out_bf16 & 7 || ep->ld_out_f32 & 3 || ep->ld_res & 3 || ep->ld_pre & 7 || ep->ld_rank_u & 7)
+        return set_error(CLIBD_EINVAL, "gemm_fp8: leading dimensions");
+    if ((ep->out_bf16 && !aligned16(ep->out_bf16)) || (ep->out_f32 && !aligned16(ep->out_f32)) || (ep->out_pre_bf16 && !aligned16(ep->out_pre_bf16)) ||
+        (ep->residual_f32 && !aligned16(ep->residual_f32)) || (ep->rank_u && !aligned16(ep->rank_u)) || (ep->rank_v && !aligned16(ep->rank_v)) ||
+        (ep->bias && !aligned16(ep->bias)))
+        return set_error(CLIBD_EINVAL, "gemm_fp8: pointer alignment");
+    if ((ep->rank_u == nullptr) != (ep->rank_v == nullptr)) return set_error(CLIBD_EINVAL, "gemm_fp8: rank_u / rank_v must come together");
+    GemmParams p{};
+    p.A = (const unsigned short*)A; p.W = (const unsigned short*)W;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
+    p.ep = *ep;
+    if (p.ep.split_k < 1) p.ep.split_k = 1;
+    p.fp8 = 1; p.col_scale = col_scale; p.out_fp8_scale = out_fp8_scale;
+    if (!gemm256_fp8_launch(p, (hipStream_t)stream))
+        return set_error(CLIBD_EINVAL, "gemm_fp8: shape / epilogue not supported (N % 256, K % 256, K >= 512, bias required; forms: "
+                                       "[lora] bias->bf16 | bias->gelu->fp8 + gelu' | bias[->dropout]+residual->f32)");
+    return check_launch("gemm256_fp8_nt");
+}
+
 // ---- split-K with a partials workspace (weight gradients of the full fine-tune mode) -----------------------------------
 namespace clibd {
 // out[i] (+)= sum_s partials[s * n + i]

@@ -46,7 +46,17 @@ constexpr int G256_LDS = 2 * STAGE_BYTES;      // 128 KiB
 
 #define CLIBD_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int KIND, bool LORA, bool BIAS, bool DIAG>
+// FP8: both operands are OCP e4m3 bytes (K counted in bytes; a K-tile is still 128 bytes per row, i.e. 128 k), the same
+// LDS image and DMA schedule, and each (P tile, Q tile) pair takes ONE v_mfma_scale_f32_16x16x128_f8f6f4 with unit block
+// scales on the lane's two 16-byte k-chunks (32 cycles for 128 k against 2 x 16 cycles for 64 k in bf16).  The accumulators
+// are dequantised by p.col_scale[n] right after the K loop, before the (bf16) LoRA rank update and the epilogue.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x8 cat_frag(bf16x8 lo, bf16x8 hi) {
+    return __builtin_shufflevector(__builtin_bit_cast(i32x4, lo), __builtin_bit_cast(i32x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8>
 __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -54,7 +64,8 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int nk_total = p.K / T_K;
+    constexpr int ESZ = FP8 ? 1 : 2;             // bytes per operand element
+    const int nk_total = p.K * ESZ / (T_K * 2);  // 128-byte K-tiles
     const int tiles_out = p.tiles_m * p.tiles_n;
     int tile = blockIdx.x;  // work item: (output tile, split) = (item % tiles_out, item / tiles_out); splits == 1: item = tile
     int m0, n0;          // tile being computed
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     const int rowP = 128 * (wave >> 2) + 8 * prow + (wave & 3);
     const int rowQ = 64 * (wave >> 1) + 16 * (wave & 1) + prow;
     const unsigned chunk16 = (unsigned)chunk * 16u;
-    const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.ldw * 2u;
+    const unsigned lda2 = (unsigned)p.lda * (unsigned)ESZ, ldw2 = (unsigned)p.ldw * (unsigned)ESZ;  // row strides in bytes
     const char* const baseA = (const char*)p.A;
     const char* const baseW = (const char*)p.W;
     unsigned offP0 = 0, offP1 = 0;                          // P_hm0 pieces (P_hm1 = + 4 rows: scalar)
@@ -132,9 +143,14 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     const unsigned wB10 = wB00 + STAGE_BYTES, wB11 = wB01 + STAGE_BYTES;
 
     f32x4 acc[2][4][2][2];  // [hm][mt][hn][nt]
+    const int unit_scale = 0;  // E8M0 1.0 in every byte (FP8 only)
     bf16x8 aF[4][2], w0F[2][2], w1F[2][2];  // [tile][kk]
+    i32x8 aF8[4], w0F8[2], w1F8[2];         // FP8: [tile], both 16-byte k-chunks of the lane as ONE 8-VGPR MFMA operand
+    // (w0F / w0F8 etc. are selected by token pasting in the macros below: the unused set never materialises)
 
 #define DS_READ128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+// FP8: the two halves are joined right at the read (a REG_SEQUENCE the coalescer folds into the asm outputs: the ISA must
+// show no v_mov between a ds_read and its WAIT_FRAGS - tools/check_gemm256_isa.sh)
 #define LOAD_A(stage, j)                                                                                     \
     do {                                                                                                     \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                      \
@@ -150,16 +166,30 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         }                                                                                                    \
     } while (0)
 #define WAIT_FRAGS_A()                                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aF[0][0]), "+v"(aF[0][1]), "+v"(aF[1][0]), "+v"(aF[1][1]),     \
-                 "+v"(aF[2][0]), "+v"(aF[2][1]), "+v"(aF[3][0]), "+v"(aF[3][1]))
-#define WAIT_FRAGS_W(wF) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wF[0][0]), "+v"(wF[0][1]), "+v"(wF[1][0]), "+v"(wF[1][1]))
+    do {                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aF[0][0]), "+v"(aF[0][1]), "+v"(aF[1][0]), "+v"(aF[1][1]),  \
+                     "+v"(aF[2][0]), "+v"(aF[2][1]), "+v"(aF[3][0]), "+v"(aF[3][1]));                         \
+        if constexpr (FP8) { _Pragma("unroll") for (int t = 0; t < 4; ++t) aF8[t] = cat_frag(aF[t][0], aF[t][1]); } \
+    } while (0)
+#define WAIT_FRAGS_W(wF)                                                                                     \
+    do {                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wF[0][0]), "+v"(wF[0][1]), "+v"(wF[1][0]), "+v"(wF[1][1])); \
+        if constexpr (FP8) { wF##8[0] = cat_frag(wF[0][0], wF[0][1]); wF##8[1] = cat_frag(wF[1][0], wF[1][1]); } \
+    } while (0)
 #define MMA(hm, hn, wF)                                                                                      \
     do {                                                                                                     \
         __builtin_amdgcn_s_setprio(1);                                                                       \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                     \
+        if constexpr (FP8) {                                                                                 \
             _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                    \
                 _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                \
-                    acc[hm][t][hn][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wF[n][kk], aF[t][kk], acc[hm][t][hn][n], 0, 0, 0); \
+                    acc[hm][t][hn][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                    \
+                        wF##8[n], aF8[t], acc[hm][t][hn][n], 0, 0, 0, unit_scale, 0, unit_scale); \
+        } else {                                                                                             \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                 \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                \
+                    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                            \
+                        acc[hm][t][hn][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wF[n][kk], aF[t][kk], acc[hm][t][hn][n], 0, 0, 0); \
+        }                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                       \
     } while (0)
 #define BARRIER()                                   \
@@ -306,6 +336,19 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         // leading dimensions) is rebuilt here instead of being hoisted out of the persistent loop into spilled registers
         int erow = frow, egrp = fch;
         asm volatile("" : "+v"(erow), "+v"(egrp));
+        // ---- FP8: dequantise in place, before the (bf16, unscaled) rank update: acc[.., column e] *= col_scale[nb + e]
+        if constexpr (FP8) {
+            const float* csp = p.col_scale + n0 + 128 * wm + 8 * erow;
+            const f32x4 c0 = *(const f32x4*)csp, c1 = *(const f32x4*)(csp + 4);
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float c = hm ? c1[t] : c0[t];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[hm][t][q >> 1][q & 1] *= c;
+                }
+        }
         // ---- LoRA rank-8 update: one extra zero-padded k-step (lanes with k-chunk 0 carry U[m,0:8] / V[n,0:8])
         // (compile-time flag: a run-time test here puts all 128 accumulators behind a phi the register allocator
         //  cannot coalesce -> 26 spilled VGPRs and vmcnt(0) drains around their reloads)
@@ -343,6 +386,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
             const int mb = m0 + 64 * wn + 4 * egrp;
             float bias[8];
             if (BIAS) load_bias8(ep, nb, bias);  // compile-time: without a bias the 128 adds (and the moves pairing them) vanish
+#define EPV(hm, t) (BIAS ? acc[hm][t][hn][n][r] + bias[4 * (hm) + (t)] : acc[hm][t][hn][n][r])
 #define FOR_ROWS(...)                                                                                        \
     _Pragma("unroll") for (int hn = 0; hn < 2; ++hn)                                                         \
         _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                        \
@@ -368,7 +412,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     const int mc = min(m, p.M - 1);
                     float v[8];
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
-                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = BIAS ? acc[hm][t][hn][n][r] + bias[4 * hm + t] : acc[hm][t][hn][n][r];
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = EPV(hm, t);
                     fold_row8<KIND>(ep, mc, nb, v);
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
                         _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[hm][t][hn][n][r] = v[4 * hm + t];
@@ -399,12 +443,14 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     if (m < p.M) {
                         float v[8];
                         _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
-                            _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = BIAS ? acc[hm][t][hn][n][r] + bias[4 * hm + t] : acc[hm][t][hn][n][r];
-                        store_row8<KIND>(ep, m, nb, v);
+                            _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = EPV(hm, t);
+                        if (FP8 && KIND == EPI_GELU_SAVE) store_row8_gelu_fp8(ep, m, nb, v, p.out_fp8_scale);
+                        else store_row8<KIND>(ep, m, nb, v);
                     }
                 })
             }
 #undef FOR_ROWS
+#undef EPV
         }
         STAMP(5);
         if (DIAG) ++tile_i;
@@ -427,7 +473,7 @@ static int band_env_value() {
     static const int v = [] { const char* e = getenv("CLIBD_GEMM_BAND"); return e ? atoi(e) : 0; }();
     return v;
 }
-#define CLIBD_DIAG_KERNEL(KIND) (const void*)gemm256_bf16_nt_kernel<KIND, false, true, true>
+#define CLIBD_DIAG_KERNEL(KIND) (const void*)gemm256_bf16_nt_kernel<KIND, false, true, true, false>
 #else
 static constexpr long long* g_stamp_buffer = nullptr;
 static int skew_env_value() { return 0; }
@@ -438,20 +484,80 @@ static int band_env_value() { return 0; }
 static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
 #define K256(KIND)                                                                                                    \
     (diag ? CLIBD_DIAG_KERNEL(KIND)                                                                                   \
-          : lora ? (bias ? (const void*)gemm256_bf16_nt_kernel<KIND, true, true, false>                               \
-                         : (const void*)gemm256_bf16_nt_kernel<KIND, true, false, false>)                             \
-                 : (bias ? (const void*)gemm256_bf16_nt_kernel<KIND, false, true, false>                              \
-                         : (const void*)gemm256_bf16_nt_kernel<KIND, false, false, false>))
+          : lora ? (bias ? (const void*)gemm256_bf16_nt_kernel<KIND, true, true, false, false>                        \
+                         : (const void*)gemm256_bf16_nt_kernel<KIND, true, false, false, false>)                      \
+                 : (bias ? (const void*)gemm256_bf16_nt_kernel<KIND, false, true, false, false>                       \
+                         : (const void*)gemm256_bf16_nt_kernel<KIND, false, false, false, false>))
     switch (kind) {
         case EPI_BF16: return K256(EPI_BF16);
         case EPI_GELU_SAVE: return K256(EPI_GELU_SAVE);
         case EPI_MUL_AUX: return K256(EPI_MUL_AUX);
         case EPI_RES_F32: return K256(EPI_RES_F32);
         case EPI_RES_F32_DROP: return K256(EPI_RES_F32_DROP);
-        case EPI_SPLITK_F32: return (const void*)gemm256_bf16_nt_kernel<EPI_SPLITK_F32, false, false, false>;
+        case EPI_SPLITK_F32: return (const void*)gemm256_bf16_nt_kernel<EPI_SPLITK_F32, false, false, false, false>;
         default: return K256(EPI_GENERIC);
     }
 #undef K256
+}
+
+// fp8 operands: only the four forward shapes of a transformer layer are instantiated (bias always present there)
+static const void* kernel_ptr_fp8(int kind, bool lora) {
+    switch (kind) {
+        case EPI_BF16: return lora ? (const void*)gemm256_bf16_nt_kernel<EPI_BF16, true, true, false, true>
+                                   : (const void*)gemm256_bf16_nt_kernel<EPI_BF16, false, true, false, true>;
+        case EPI_GELU_SAVE: return lora ? nullptr : (const void*)gemm256_bf16_nt_kernel<EPI_GELU_SAVE, false, true, false, true>;
+        case EPI_RES_F32: return lora ? nullptr : (const void*)gemm256_bf16_nt_kernel<EPI_RES_F32, false, true, false, true>;
+        case EPI_RES_F32_DROP: return lora ? nullptr : (const void*)gemm256_bf16_nt_kernel<EPI_RES_F32_DROP, false, true, false, true>;
+        default: return nullptr;
+    }
+}
+
+static int device_cus() {
+    static const int num_cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+        }
+        return n;
+    }();
+    return num_cus;
+}
+
+// fp8 launch: p.K / lda / ldw in bytes; the epilogue must be one of the instantiated forms and carry a bias.
+bool gemm256_fp8_launch(const GemmParams& p, hipStream_t stream) {
+    const int nk = p.K / 128;
+    if (!p.fp8 || p.col_scale == nullptr || p.K % 128 != 0 || nk < 4 || (nk & 1) || p.N % T_N != 0 || p.M < 1 || p.ep.split_k > 1) return false;
+    if (p.ep.bias == nullptr) return false;
+    if ((unsigned long long)p.M * p.lda >= (1ull << 32) || (unsigned long long)p.N * p.ldw >= (1ull << 32)) return false;
+    const int kind = epilogue_kind(p.ep);
+    const bool lora = p.ep.rank_u != nullptr;
+    const void* fn = kernel_ptr_fp8(kind, lora);
+    if (fn == nullptr) return false;
+    if ((p.out_fp8_scale > 0.f) != (kind == EPI_GELU_SAVE)) return false;
+    static const bool attr_ok = [] {
+        bool ok = true;
+        for (int k = 0; k < EPI_NUM_KINDS; ++k)
+            for (int l = 0; l < 2; ++l) {
+                const void* f = kernel_ptr_fp8(k, l != 0);
+                if (f != nullptr) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+            }
+        return ok;
+    }();
+    if (!attr_ok) return false;
+    GemmParams q = p;
+    q.tiles_m = (p.M + T_M - 1) / T_M;
+    q.tiles_n = p.N / T_N;
+    q.splits = 1;
+    q.nk_split = nk;
+    q.split_stride = 0;
+    q.band = 4;
+    const long long tiles = (long long)q.tiles_m * q.tiles_n;
+    const int grid = (int)(tiles < device_cus() ? tiles : device_cus());
+    int ntiles_i = (int)tiles, skew = 0;
+    long long* stamp = nullptr;
+    void* args[] = {(void*)&q, (void*)&ntiles_i, (void*)&skew, (void*)&stamp};
+    return hipLaunchKernel(fn, dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) == hipSuccess;
 }
 
 bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {

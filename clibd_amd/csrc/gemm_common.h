@@ -20,6 +20,11 @@ struct GemmParams {
     // 128x128 kernel only: K-tiles [hole_kt, hole_kt + hole_nkt) of both operands are skipped (a column segment of A that
     // meets all-zero weights: the k segment of dqkv in the adapters' dt projection).  hole_nkt == 0: none.
     int hole_kt, hole_nkt;
+    // gemm256 fp8 mode (clibd_gemm_fp8_nt): A / W are OCP e4m3 bytes, K / lda / ldw count bytes; acc * col_scale[n] dequantises.
+    // out_fp8_scale > 0 (fc1 form, EPI_GELU_SAVE): ep.out_bf16 receives fp8(gelu(x) * out_fp8_scale), ld_out_bf16 in bytes.
+    int fp8;
+    const float* col_scale;
+    float out_fp8_scale;
 };
 
 // Inside a wave's 64 output columns, MFMA n-tile t (0..3), MFMA row i (0..15) carries tile-local column
@@ -260,6 +265,15 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
     if (KIND == EPI_GENERIC && ep.out_bf16 != nullptr) *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
 }
 
+// fp8-forward fc1: gelu' saved as bf16 for the backward, the activation itself leaves as fp8 (fc2's operand)
+__device__ __forceinline__ void store_row8_gelu_fp8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8], float out_scale) {
+    float dg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gelu_and_grad_f(bfround(v[e]), v[e], dg[e]);
+    *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(dg);
+    *(uint2*)((unsigned char*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8fp8(v, out_scale);
+}
+
 // Pass 1 of the two-pass epilogues (gemm256): everything of store_row8<KIND> up to, not including, the stores.
 template <int KIND>
 __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
@@ -291,6 +305,8 @@ __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, 
 
 // host side (gemm256.hip): returns true when the 256x256 kernel took the launch
 bool gemm256_try_launch(const GemmParams& p, hipStream_t stream);
+// fp8 operands (p.fp8, p.col_scale set; K / lda / ldw in bytes): true when launched
+bool gemm256_fp8_launch(const GemmParams& p, hipStream_t stream);
 // split-K with a partials workspace; returns the number of splits (0: shape not taken)
 int gemm256_splitk_launch(const GemmParams& p, float* partials, size_t partials_elems, hipStream_t stream);
 

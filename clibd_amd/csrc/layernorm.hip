@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             float* __restrict__ y_f32, float* __restrict__ stats,
                                                             const unsigned short* __restrict__ lora_a,
                                                             unsigned short* __restrict__ t_bf16, unsigned drop_seed,
-                                                            int drop_thr16, float drop_scale) {
+                                                            int drop_thr16, float drop_scale,
+                                                            unsigned char* __restrict__ y_fp8, float fp8_scale) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[];  // [8][H] when LORA
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -113,6 +114,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             pk.x = pack2bf(y[0], y[1]);
             pk.y = pack2bf(y[2], y[3]);
             if (y_bf16 != nullptr) *(uint2*)(y_bf16 + (size_t)row * H + c) = pk;
+            if (y_fp8 != nullptr)  // fp8-forward mode: the next GEMM's operand, quantised from the fp32 value
+                *(unsigned*)(y_fp8 + (size_t)row * H + c) = pack4fp8(y[0] * fp8_scale, y[1] * fp8_scale, y[2] * fp8_scale, y[3] * fp8_scale);
             if (LORA) {
                 const float y0 = bf2f((unsigned short)(pk.x & 0xffff)), y1 = bf2f((unsigned short)(pk.x >> 16));
                 const float y2 = bf2f((unsigned short)(pk.y & 0xffff)), y3 = bf2f((unsigned short)(pk.y >> 16));
@@ -245,13 +248,14 @@ static inline int ln_grid(int M) {
 
 using namespace clibd;
 
-extern "C" int clibd_layernorm_fwd_drop(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
-                                        void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
-                                        uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+static int layernorm_fwd_impl(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                              void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
+                              uint32_t drop_seed, int drop_thr16, float drop_scale, void* y_fp8, float fp8_scale, void* stream) {
     if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "layernorm_fwd: bad dropout threshold");
     if (!x || !gamma || !beta) return set_error(CLIBD_EINVAL, "layernorm_fwd: null pointer");
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_fwd: H must be a multiple of 64, <= 1024");
-    if (!y_bf16 && !y_f32) return set_error(CLIBD_EINVAL, "layernorm_fwd: no output");
+    if (!y_bf16 && !y_f32 && !y_fp8) return set_error(CLIBD_EINVAL, "layernorm_fwd: no output");
+    if (y_fp8 && (!(fp8_scale > 0.f) || ((uintptr_t)y_fp8 & 3))) return set_error(CLIBD_EINVAL, "layernorm_fwd: fp8 output needs a positive scale and 4-byte alignment");
     if ((lora_a_bf16 == nullptr) != (t_bf16 == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_fwd: lora_a/t must come together");
     if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (y_f32 && !aligned16(y_f32)) ||
         (y_bf16 && !aligned16(y_bf16)) || (lora_a_bf16 && !aligned16(lora_a_bf16)))
@@ -266,11 +270,11 @@ extern "C" int clibd_layernorm_fwd_drop(const float* x, int M, int H, const floa
         if (lora)                                                                                              \
             hipLaunchKernelGGL((layernorm_fwd_kernel<N, true>), grid, block, lds, st, x, M, H, gamma, beta, eps, \
                                (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)lora_a_bf16,      \
-                               (unsigned short*)t_bf16, drop_seed, drop_thr16, drop_scale);                    \
+                               (unsigned short*)t_bf16, drop_seed, drop_thr16, drop_scale, (unsigned char*)y_fp8, fp8_scale); \
         else                                                                                                   \
             hipLaunchKernelGGL((layernorm_fwd_kernel<N, false>), grid, block, 0, st, x, M, H, gamma, beta, eps, \
                                (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)nullptr,          \
-                               (unsigned short*)nullptr, drop_seed, drop_thr16, drop_scale);                   \
+                               (unsigned short*)nullptr, drop_seed, drop_thr16, drop_scale, (unsigned char*)y_fp8, fp8_scale); \
     } while (0)
     switch (nch) {
         case 1: LAUNCH(1); break;
@@ -282,10 +286,23 @@ extern "C" int clibd_layernorm_fwd_drop(const float* x, int M, int H, const floa
     return check_launch("layernorm_fwd");
 }
 
+extern "C" int clibd_layernorm_fwd_drop(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                                        void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
+                                        uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+    return layernorm_fwd_impl(x, M, H, gamma, beta, eps, y_bf16, y_f32, stats, lora_a_bf16, t_bf16, drop_seed, drop_thr16, drop_scale, nullptr, 0.f, stream);
+}
+
 extern "C" int clibd_layernorm_fwd(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
                                    void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16,
                                    void* t_bf16, void* stream) {
-    return clibd_layernorm_fwd_drop(x, M, H, gamma, beta, eps, y_bf16, y_f32, stats, lora_a_bf16, t_bf16, 0u, 0, 1.0f, stream);
+    return layernorm_fwd_impl(x, M, H, gamma, beta, eps, y_bf16, y_f32, stats, lora_a_bf16, t_bf16, 0u, 0, 1.0f, nullptr, 0.f, stream);
+}
+
+extern "C" int clibd_layernorm_fwd_fp8(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                                       void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
+                                       uint32_t drop_seed, int drop_thr16, float drop_scale, void* y_fp8, float fp8_scale, void* stream) {
+    if (!y_fp8) return set_error(CLIBD_EINVAL, "layernorm_fwd_fp8: null y_fp8");
+    return layernorm_fwd_impl(x, M, H, gamma, beta, eps, y_bf16, y_f32, stats, lora_a_bf16, t_bf16, drop_seed, drop_thr16, drop_scale, y_fp8, fp8_scale, stream);
 }
 
 static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,

@@ -63,9 +63,10 @@ class LayerSpec:
 
 
 class _LayerCache:
-    """bf16 device images of one layer's frozen weights: W [N,K] for forward, W^T [K,N] for dgrad."""
+    """bf16 device images of one layer's frozen weights: W [N,K] for forward, W^T [K,N] for dgrad.
+    fp8-forward mode adds the e4m3 forward images and their per-channel dequantisation factors (w*8, cs_*)."""
     __slots__ = ("wqkv", "wqkv_t", "bqkv", "wo", "wo_t", "bo", "w1", "w1_t", "b1", "w2", "w2_t", "b2", "g1", "be1", "g2", "be2",
-                 "v_fwd", "v_bwd", "a_cat", "w_dt")
+                 "v_fwd", "v_bwd", "a_cat", "w_dt", "wqkv8", "cs_qkv", "wo8", "cs_o", "w18", "cs_1", "w28", "cs_2")
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -98,6 +99,26 @@ class TransformerStack:
         self.FF = layers[0].fc1_w.shape[0]
         self._cache: List[_LayerCache] = []
         self._cache_key = None
+        self.fp8 = None  # fp8-forward mode: {site: activation scale}; see enable_fp8
+
+    # ---- fp8-forward mode (BASELINE.json configs[4]) ----------------------------------------------------------------
+    FP8_SCALES = dict(ln=8.0, attn=32.0, gelu=4.0)
+
+    def enable_fp8(self, scales: Optional[dict] = None):
+        """The four forward GEMMs of every layer run on the fp8 MFMA (ops.gemm_fp8_nt): frozen weights are quantised per
+        output channel once, activations per tensor with the static power-of-two factors in `scales` (LayerNorm outputs,
+        attention outputs, GELU outputs; e4m3 saturates at 448 / scale) inside the kernels that produce them.  The backward
+        is unchanged bf16 (it needs gelu', qkv, statistics and — for the adapters — the bf16 LayerNorm output only), i.e.
+        gradients are those of the bf16 network evaluated at the fp8 forward's activations.  LoRA / frozen-base mode only."""
+        if self.full_mode():
+            raise NotSupportedYet("fp8 forward needs frozen base weights (their gradients would need the bf16 GEMM inputs)")
+        if self.H % 256 or self.H < 512 or self.FF % 256:
+            raise NotSupportedYet("fp8 forward needs hidden % 256 == 0, hidden >= 512, intermediate % 256 == 0")
+        self.fp8 = dict(self.FP8_SCALES, **(scales or {}))
+        self._cache_key = None
+
+    def disable_fp8(self):
+        self.fp8 = None
 
     # ---- frozen-weight images ---------------------------------------------------------------------------------
     def _key(self):
@@ -130,6 +151,12 @@ class TransformerStack:
                 c.w1, c.w1_t, c.b1 = ops.cast_bf16(_f32c(L.fc1_w)), ops.cast_transpose_bf16(_f32c(L.fc1_w)), _f32c(L.fc1_b)
                 c.w2, c.w2_t, c.b2 = ops.cast_bf16(_f32c(L.fc2_w)), ops.cast_transpose_bf16(_f32c(L.fc2_w)), _f32c(L.fc2_b)
                 c.g1, c.be1, c.g2, c.be2 = _f32c(L.ln1_w), _f32c(L.ln1_b), _f32c(L.ln2_w), _f32c(L.ln2_b)
+                if self.fp8 is not None:
+                    f8 = self.fp8
+                    c.wqkv8, c.cs_qkv = ops.quantize_rows_fp8(wqkv.contiguous(), f8["ln"])
+                    c.wo8, c.cs_o = ops.quantize_rows_fp8(_f32c(L.proj_w), f8["attn"])
+                    c.w18, c.cs_1 = ops.quantize_rows_fp8(_f32c(L.fc1_w), f8["ln"])
+                    c.w28, c.cs_2 = ops.quantize_rows_fp8(_f32c(L.fc2_w), f8["gelu"])
                 c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = None
                 self._cache.append(c)
         self._cache_key = key
@@ -155,7 +182,8 @@ class TransformerStack:
         return self._cache[i].a_cat
 
     # ---- forward ------------------------------------------------------------------------------------------------
-    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool, cls_only_last: bool = False, drop=None, full: bool = False):
+    def forward(self, x_f32, x_bf16, t0, B: int, S: int, key_mask, save: bool, cls_only_last: bool = False, drop=None, full: bool = False,
+                x_fp8=None):
         """x_f32 [M,H] residual stream entering layer 0.  Post-LN stacks also pass its bf16 image and the layer-0
         adapter down-projection t0 (both produced by the embedding LayerNorm).  Returns (x_f32, x_bf16, saved).
         cls_only_last (pre-LN only): the caller consumes token 0 only, so the LAST block evaluates attention for that
@@ -163,15 +191,22 @@ class TransformerStack:
         the last block are dead code the reference computes and discards).
         drop (post-LN only): (p_hidden, p_attention, base_seed) — HF BERT train-mode dropout; site seeds via ops.derive_seed.
         full: full fine-tune mode — every layer keeps its own attention output, MLP input and GELU output (the X operands of
-        the weight gradients) instead of sharing temporaries."""
+        the weight gradients) instead of sharing temporaries.
+        x_fp8 (post-LN, fp8-forward mode): the e4m3 image of x (scale fp8["ln"]) from the embedding LayerNorm."""
         H, FF, M = self.H, self.FF, B * S
         dev = x_f32.device
         saved = []
         new = lambda cols, dt: torch.empty((M, cols), dtype=dt, device=dev)
         keep = save and full
-        o = None if keep else new(H, BF16)          # attention output (temporary, reused by every layer)
-        a = None if keep else new(FF, BF16)         # post-GELU activation (temporary)
-        xn2 = new(H, BF16) if (self.pre_ln and not keep) else None
+        f8 = self.fp8
+        if f8 is not None and full:
+            raise NotSupportedYet("fp8 forward with trainable base weights")
+        AT = ops.FP8 if f8 is not None else BF16    # dtype of the GEMM-operand temporaries
+        o = None if keep else new(H, AT)            # attention output (temporary, reused by every layer)
+        a = None if keep else new(FF, AT)           # post-GELU activation (temporary)
+        xn2 = new(H, AT) if (self.pre_ln and not keep) else None
+        xn8 = new(H, ops.FP8) if f8 is not None else None   # fp8 image of the first LayerNorm's output (temporary)
+        h_tmp = new(FF, BF16) if (f8 is not None and not save) else None        # the fp8 fc1 form always writes gelu'
         t = t0
         for i, (L, c) in enumerate(zip(self.layers, self._cache)):
             has_lora = L.lora is not None
@@ -183,9 +218,14 @@ class TransformerStack:
                 xn = new(H, BF16)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
                 t = torch.empty((M, 8), dtype=BF16, device=dev) if has_lora else None
-                ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
                 qkv = new(3 * H, BF16)
-                ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
+                if f8 is not None:   # the full-size GEMM of this block; its class-row remainder stays bf16
+                    ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t,
+                                      y_fp8=xn8, fp8_scale=f8["ln"])
+                    ops.gemm_fp8_nt(xn8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
+                else:
+                    ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
+                    ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
                 newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
                 o_cls = newB(H, BF16)
                 ops.attention_fwd(qkv, B, S, self.heads, key_mask, o_cls, nq=1)
@@ -210,18 +250,28 @@ class TransformerStack:
                 xn = new(H, BF16)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
                 t = torch.empty((M, 8), dtype=BF16, device=dev) if has_lora else None
-                ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
                 qkv = new(3 * H, BF16)
-                ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
-                ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
                 x1 = new(H, F32)
-                ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
-                ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
                 h = new(FF, BF16) if save else None      # holds gelu'(fc1 out): all the backward needs
-                ops.gemm_nt(xn2, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                 x2 = new(H, F32)
-                ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1, out_f32=x2)
+                if f8 is not None:
+                    ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t,
+                                      y_fp8=xn8, fp8_scale=f8["ln"])
+                    ops.gemm_fp8_nt(xn8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
+                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, out_fp8_scale=f8["attn"])
+                    ops.gemm_fp8_nt(o, c.wo8, c.cs_o, bias=c.bo, residual=x_f32, out_f32=x1)
+                    ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, stats=st2, y_fp8=xn2, fp8_scale=f8["ln"])
+                    ops.gemm_fp8_nt(xn2, c.w18, c.cs_1, bias=c.b1, gelu_out_fp8=a, gelu_out_scale=f8["gelu"], out_pre=h if save else h_tmp)
+                    ops.gemm_fp8_nt(a, c.w28, c.cs_2, bias=c.b2, residual=x1, out_f32=x2)
+                else:
+                    ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
+                    ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
+                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
+                    ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
+                    ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
+                    ops.gemm_nt(xn2, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
+                    ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1, out_f32=x2)
                 if save:
                     rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h)
                     if keep:
@@ -235,23 +285,40 @@ class TransformerStack:
                     d_h1 = ops.Drop(p_h, ops.derive_seed(base, i, 1))
                     d_h2 = ops.Drop(p_h, ops.derive_seed(base, i, 2))
                 qkv = new(3 * H, BF16)
-                ops.gemm_nt(x_bf16, c.wqkv, bias=c.bqkv, rank_u=t if has_lora else None, rank_v=c.v_fwd if has_lora else None,
-                            out_bf16=qkv)
-                ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att)
                 s1 = new(H, F32)
-                ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=s1, drop=d_h1)
-                x1_f32, x1_bf16 = new(H, F32), new(H, BF16)
+                x1_f32 = new(H, F32)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
-                ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_bf16=x1_bf16, y_f32=x1_f32, stats=st1)
                 h = new(FF, BF16) if save else None
-                ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                 s2 = new(H, F32)
-                ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1_f32, out_f32=s2, drop=d_h2)
                 x2_f32, x2_bf16 = new(H, F32), new(H, BF16)
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
                 nxt = self.lora_a(i + 1)
                 t_next = torch.empty((M, 8), dtype=BF16, device=dev) if nxt is not None else None
-                ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next)
+                ru, rv = (t if has_lora else None), (c.v_fwd if has_lora else None)
+                if f8 is not None:
+                    if x_fp8 is None:
+                        raise ValueError("fp8 forward (post-LN): the caller passes the e4m3 image of x")
+                    x1_bf16 = None
+                    x18 = xn8
+                    ops.gemm_fp8_nt(x_fp8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=ru, rank_v=rv, out_bf16=qkv)
+                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att, out_fp8_scale=f8["attn"])
+                    ops.gemm_fp8_nt(o, c.wo8, c.cs_o, bias=c.bo, residual=x_f32, out_f32=s1, drop=d_h1)
+                    ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_f32=x1_f32, stats=st1, y_fp8=x18, fp8_scale=f8["ln"])
+                    ops.gemm_fp8_nt(x18, c.w18, c.cs_1, bias=c.b1, gelu_out_fp8=a, gelu_out_scale=f8["gelu"], out_pre=h if save else h_tmp)
+                    ops.gemm_fp8_nt(a, c.w28, c.cs_2, bias=c.b2, residual=x1_f32, out_f32=s2, drop=d_h2)
+                    x8_next = new(H, ops.FP8)
+                    ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next,
+                                      y_fp8=x8_next, fp8_scale=f8["ln"])
+                    x_fp8 = x8_next
+                else:
+                    x1_bf16 = new(H, BF16)
+                    ops.gemm_nt(x_bf16, c.wqkv, bias=c.bqkv, rank_u=ru, rank_v=rv, out_bf16=qkv)
+                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att)
+                    ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=s1, drop=d_h1)
+                    ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_bf16=x1_bf16, y_f32=x1_f32, stats=st1)
+                    ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
+                    ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1_f32, out_f32=s2, drop=d_h2)
+                    ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next)
                 if save:
                     rec = dict(x_bf16=x_bf16, t=t if has_lora else None, qkv=qkv, s1=s1, st1=st1, h=h, s2=s2, st2=st2,
                                d_att=d_att, d_h1=d_h1, d_h2=d_h2)

@@ -102,6 +102,18 @@ class SimpleCLIP(nn.Module):
         dna_output, image_output, language_output = outs
         return image_output, dna_output, language_output, self.logit_scale.exp(), self.logit_bias
 
+    def enable_fp8_forward(self, scales: Optional[dict] = None, enabled: bool = True):
+        """fp8-forward mode (BASELINE.json configs[4]; not in the reference, which trains under bf16 autocast): the towers'
+        forward GEMMs run on the fp8 MFMA, see TransformerStack.enable_fp8.  Needs frozen base weights (LoRA mode)."""
+        for enc in (self.image_encoder, self.dna_encoder, self.language_encoder):
+            if enc is not None and hasattr(enc, "tower"):
+                stack = enc.tower().stack
+                if enabled:
+                    stack.enable_fp8(scales)
+                else:
+                    stack.disable_fp8()
+        return self
+
     def join_streams(self):
         """Make the current stream wait for the towers' side streams (call after backward(): gradients written into the
         fused optimizer's flat buffers by a tower's backward are produced on that tower's stream)."""

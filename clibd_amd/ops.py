@@ -15,6 +15,7 @@ from ._lib import GemmEpilogue, check
 
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
+FP8 = torch.float8_e4m3fn  # OCP e4m3 (gfx950's fp8 MFMA operand format); max finite 448
 
 
 def _stream() -> int:
@@ -134,6 +135,79 @@ def gemm_nt(
     check(_lib.load().clibd_gemm_bf16_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, C.byref(ep), _stream()), "gemm_bf16_nt")
 
 
+def quantize_rows_fp8(w: torch.Tensor, act_scale: float):
+    """(w_fp8 [N,K] float8_e4m3fn, col_scale [N] fp32) for gemm_fp8_nt; see clibd_quantize_rows_fp8."""
+    _chk(w, F32, "w")
+    N, K = w.shape
+    w8 = torch.empty((N, K), dtype=torch.uint8, device=w.device).view(FP8)
+    cs = torch.empty((N,), dtype=F32, device=w.device)
+    check(_lib.load().clibd_quantize_rows_fp8(w.data_ptr(), N, K, float(act_scale), w8.data_ptr(), cs.data_ptr(), _stream()), "quantize_rows_fp8")
+    return w8, cs
+
+
+def gemm_fp8_nt(
+    a: torch.Tensor,
+    w: torch.Tensor,
+    col_scale: torch.Tensor,
+    *,
+    bias: torch.Tensor,
+    rank_u: Optional[torch.Tensor] = None,
+    rank_v: Optional[torch.Tensor] = None,
+    gelu_out_fp8: Optional[torch.Tensor] = None,
+    gelu_out_scale: float = 0.0,
+    out_pre: Optional[torch.Tensor] = None,
+    residual: Optional[torch.Tensor] = None,
+    out_bf16: Optional[torch.Tensor] = None,
+    out_f32: Optional[torch.Tensor] = None,
+    drop: Optional["Drop"] = None,
+) -> None:
+    """fp8-forward GEMM: epilogue((a[M,K] @ w[N,K]^T) * col_scale[n]) with OCP e4m3 operands; see clibd_gemm_fp8_nt.
+    Forms: -> out_bf16 (optionally + rank update) | gelu -> gelu_out_fp8 (= fp8(gelu * gelu_out_scale)) + out_pre (gelu') |
+    [dropout] + residual -> out_f32."""
+    _chk(a, FP8, "a", contiguous=False)
+    _chk(w, FP8, "w", contiguous=False)
+    _chk(col_scale, F32, "col_scale")
+    _chk(bias, F32, "bias")
+    lda, ldw = _rowmajor(a, "a"), _rowmajor(w, "w")
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2 or col_scale.numel() != N or bias.numel() != N:
+        raise ValueError("gemm_fp8_nt: shape mismatch")
+    ep = GemmEpilogue()
+    ep.split_k = 1
+    ep.bias = bias.data_ptr()
+    if drop is not None and drop.thr16 > 0:
+        ep.drop_seed, ep.drop_thr16, ep.drop_scale, ep.drop_ld = drop.seed, drop.thr16, drop.scale, N
+    if rank_u is not None or rank_v is not None:
+        _chk(rank_u, BF16, "rank_u", contiguous=False)
+        _chk(rank_v, BF16, "rank_v")
+        if rank_u.shape[0] != M or rank_u.shape[1] < 8 or tuple(rank_v.shape) != (N, 8):
+            raise ValueError("gemm_fp8_nt: rank_u must be [M,>=8], rank_v [N,8]")
+        ep.rank_u, ep.rank_v, ep.ld_rank_u = rank_u.data_ptr(), rank_v.data_ptr(), _rowmajor(rank_u, "rank_u")
+    for name, t, dt in (("out_pre", out_pre, BF16), ("out_bf16", out_bf16, BF16), ("out_f32", out_f32, F32), ("residual", residual, F32),
+                        ("gelu_out_fp8", gelu_out_fp8, FP8)):
+        if t is not None:
+            _chk(t, dt, name, contiguous=False)
+            if tuple(t.shape) != (M, N):
+                raise ValueError(f"gemm_fp8_nt: {name} must be [M,N]")
+    out_scale = 0.0
+    if gelu_out_fp8 is not None:
+        if out_pre is None or out_bf16 is not None or gelu_out_scale <= 0:
+            raise ValueError("gemm_fp8_nt: the gelu form needs out_pre and a positive gelu_out_scale, and no out_bf16")
+        ep.act = ACT_GELU_SAVE_GRAD
+        ep.out_pre_bf16, ep.ld_pre = out_pre.data_ptr(), _rowmajor(out_pre, "out_pre")
+        ep.out_bf16, ep.ld_out_bf16 = gelu_out_fp8.data_ptr(), _rowmajor(gelu_out_fp8, "gelu_out_fp8")
+        out_scale = float(gelu_out_scale)
+    elif out_bf16 is not None:
+        ep.out_bf16, ep.ld_out_bf16 = out_bf16.data_ptr(), _rowmajor(out_bf16, "out_bf16")
+    if residual is not None:
+        ep.residual_f32, ep.ld_res = residual.data_ptr(), _rowmajor(residual, "residual")
+    if out_f32 is not None:
+        ep.out_f32, ep.ld_out_f32 = out_f32.data_ptr(), _rowmajor(out_f32, "out_f32")
+    check(_lib.load().clibd_gemm_fp8_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, col_scale.data_ptr(), out_scale, C.byref(ep), _stream()),
+          "gemm_fp8_nt")
+
+
 def transpose_bf16(x: torch.Tensor, pad_to: int = 64, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[R,C] bf16 -> [C, R_pad] bf16 (zero padded along R to a multiple of `pad_to`).
     colsum (fp32 [C], accumulates): column sums of x in the same pass (bias gradient beside the weight gradient's dy^T)."""
@@ -168,17 +242,25 @@ def cast_transpose_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, lora_a=None, t_out=None, drop=None) -> None:
+def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, lora_a=None, t_out=None, drop=None,
+                  y_fp8=None, fp8_scale: float = 0.0) -> None:
+    """y_fp8 (fp8-forward mode): also / only emit e4m3(y * fp8_scale), the operand of the next gemm_fp8_nt."""
     _chk(x, F32, "x")
     M, H = x.shape
     _chk(gamma, F32, "gamma")
     _chk(beta, F32, "beta")
     for nm, t, dt, shape in (("y_bf16", y_bf16, BF16, (M, H)), ("y_f32", y_f32, F32, (M, H)), ("stats", stats, F32, (M, 2)),
-                             ("lora_a", lora_a, BF16, (8, H)), ("t_out", t_out, BF16, (M, 8))):
+                             ("lora_a", lora_a, BF16, (8, H)), ("t_out", t_out, BF16, (M, 8)), ("y_fp8", y_fp8, FP8, (M, H))):
         if t is not None:
             _chk(t, dt, nm)
             if tuple(t.shape) != shape:
                 raise ValueError(f"layernorm_fwd: {nm} must be {shape}, got {tuple(t.shape)}")
+    if y_fp8 is not None:
+        d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
+        check(_lib.load().clibd_layernorm_fwd_fp8(x.data_ptr(), M, H, gamma.data_ptr(), beta.data_ptr(), float(eps), _p(y_bf16), _p(y_f32),
+                                                  _p(stats), _p(lora_a), _p(t_out), d.seed, d.thr16, d.scale, y_fp8.data_ptr(), float(fp8_scale),
+                                                  _stream()), "layernorm_fwd_fp8")
+        return
     if drop is not None and drop.thr16 > 0:
         check(_lib.load().clibd_layernorm_fwd_drop(x.data_ptr(), M, H, gamma.data_ptr(), beta.data_ptr(), float(eps), _p(y_bf16), _p(y_f32),
                                                    _p(stats), _p(lora_a), _p(t_out), drop.seed, drop.thr16, drop.scale, _stream()),
@@ -225,10 +307,11 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, 
 
 
 def attention_fwd(qkv: torch.Tensor, B: int, S: int, nheads: int, key_mask: Optional[torch.Tensor], out: torch.Tensor,
-                  nq: Optional[int] = None, drop=None) -> None:
-    """nq: evaluate only the first nq query rows of every sequence; `out` is then [B*nq, H]."""
+                  nq: Optional[int] = None, drop=None, out_fp8_scale: float = 0.0) -> None:
+    """nq: evaluate only the first nq query rows of every sequence; `out` is then [B*nq, H].
+    out_fp8_scale > 0 (fp8-forward mode): `out` is float8_e4m3fn and receives e4m3(o * out_fp8_scale)."""
     _chk(qkv, BF16, "qkv")
-    _chk(out, BF16, "out")
+    _chk(out, FP8 if out_fp8_scale > 0 else BF16, "out")
     H = nheads * 64
     nq = S if nq is None else nq
     if tuple(qkv.shape) != (B * S, 3 * H) or tuple(out.shape) != (B * nq, H):
@@ -237,6 +320,11 @@ def attention_fwd(qkv: torch.Tensor, B: int, S: int, nheads: int, key_mask: Opti
         _chk(key_mask, I32, "key_mask")
         if tuple(key_mask.shape) != (B, S):
             raise ValueError("attention_fwd: key_mask must be [B,S]")
+    if out_fp8_scale > 0:
+        d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
+        check(_lib.load().clibd_attention_fwd_fp8(qkv.data_ptr(), B, S, nheads, _p(key_mask), out.data_ptr(), nq, nq, d.seed, d.thr16, d.scale,
+                                                  float(out_fp8_scale), _stream()), "attention_fwd_fp8")
+        return
     if drop is not None and drop.thr16 > 0:
         check(_lib.load().clibd_attention_fwd_drop(qkv.data_ptr(), B, S, nheads, _p(key_mask), out.data_ptr(), nq, nq, drop.seed, drop.thr16,
                                                    drop.scale, _stream()), "attention_fwd_drop")

@@ -270,9 +270,11 @@ class BertTower(_Tower):
             drop = (self.p_hidden, self.p_attn, base)
             d_emb = ops.Drop(self.p_hidden, ops.derive_seed(base, 255, 3))
         st_e = torch.empty((M, 2), dtype=F32, device=dev) if full else None
+        f8 = self.stack.fp8
+        x_fp8 = torch.empty((M, H), dtype=ops.FP8, device=dev) if f8 is not None else None
         ops.layernorm_fwd(e, _f32c(emb.LayerNorm.weight), _f32c(emb.LayerNorm.bias), float(emb.LayerNorm.eps), y_bf16=x_bf16, y_f32=x_f32,
-                          stats=st_e, lora_a=a0, t_out=t0, drop=d_emb)
-        x_f32, x_bf16, saved = self.stack.forward(x_f32, x_bf16, t0, B, S, key_mask, save, drop=drop, full=full)
+                          stats=st_e, lora_a=a0, t_out=t0, drop=d_emb, y_fp8=x_fp8, fp8_scale=f8["ln"] if f8 is not None else 0.0)
+        x_f32, x_bf16, saved = self.stack.forward(x_f32, x_bf16, t0, B, S, key_mask, save, drop=drop, full=full, x_fp8=x_fp8)
         state = dict(saved=saved, B=B, S=S, key_mask=key_mask, full=full) if save else None
         if full:
             state.update(e=e, st_e=st_e, d_emb=d_emb, ids=ids, tt=tt, x_top=x_bf16)

@@ -83,6 +83,21 @@ int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, in
 int clibd_gemm_bf16_nt_khole(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int hole_k0, int hole_len,
                              const clibd_gemm_epilogue* ep, void* stream);
 
+/* fp8-forward mode (BASELINE.json configs[4], "fp8 MFMA GEMM path"): the same product with OCP e4m3 operands on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), twice the bf16 MFMA rate.  A [M,K] and W [N,K] are fp8 bytes
+ * (lda, ldw, K in bytes; % 16, K % 256 == 0, K >= 512, N % 256 == 0); v = acc * col_scale[n] (the product of the
+ * activation's and the weight row's dequantisation factors) then the epilogue of clibd_gemm_bf16_nt, restricted to the
+ * forward forms of a transformer layer, all with a bias:  [rank update] -> out_bf16 | GELU_SAVE_GRAD -> out_pre_bf16 =
+ * bf16(gelu') and out_bf16 := fp8(gelu(x) * out_fp8_scale) (ld_out_bf16 in bytes; out_fp8_scale > 0 exactly for this form)
+ * | [dropout] + residual_f32 -> out_f32.  Replaces the same nn.Linear call sites as clibd_gemm_bf16_nt in forward only; backward stays bf16. */
+int clibd_gemm_fp8_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* col_scale,
+                      float out_fp8_scale, const clibd_gemm_epilogue* ep, void* stream);
+
+/* Operand image of a frozen nn.Linear weight for clibd_gemm_fp8_nt: per output channel n, s_n = 448 / max_k |w[n,k]|,
+ * w_fp8[n,k] = e4m3(w[n,k] * s_n), col_scale[n] = 1 / (s_n * act_scale) where act_scale is the (per-tensor) factor the
+ * producer of the activation operand applied before its e4m3 conversion.  w fp32 [N,K] dense, K % 4 == 0. */
+int clibd_quantize_rows_fp8(const float* w, int N, int K, float act_scale, void* w_fp8, float* col_scale, void* stream);
+
 /* bf16 transpose with zero padding: out[C, ld_out] (ld_out >= R) = in[R, C]^T; columns R..ld_out-1 zero.
  * Used to feed the weight-gradient GEMMs (contraction over the token dimension). */
 int clibd_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
@@ -112,6 +127,11 @@ int clibd_layernorm_fwd(const float* x, int M, int H, const float* gamma, const 
  * recomputes them.  Element index: row*H + col for [M,H] activations; ((b*heads+h)*S + q)*256 + key for attention.
  * _drop variants: y = dropout(LN(x)) (embeddings);  backward: the bf16 output only is masked (it is the gradient that
  * enters the dgrad GEMM of the dropped dense output; the fp32 output is the residual-path gradient). */
+/* fp8-forward mode: additionally (or only: y_bf16 / y_f32 may both be NULL) y_fp8[m,c] = e4m3(y * fp8_scale), saturating
+ * at +-448 — the operand of the next clibd_gemm_fp8_nt.  The LoRA down-projection still reads bf16(y). */
+int clibd_layernorm_fwd_fp8(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
+                            void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
+                            uint32_t drop_seed, int drop_thr16, float drop_scale, void* y_fp8, float fp8_scale, void* stream);
 int clibd_layernorm_fwd_drop(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
                              void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
                              uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
@@ -144,6 +164,11 @@ int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t
                         int nq, int out_seq, void* stream);
 int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
                         void* dqkv, int nq, int dout_seq, void* stream);
+/* fp8-forward mode: the attention output leaves as e4m3(o * out_fp8_scale) bytes [B*out_seq, H] (operand of the projection
+ * clibd_gemm_fp8_nt; the backward recomputes what it needs from qkv, so no bf16 copy is kept). */
+int clibd_attention_fwd_fp8(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out_fp8,
+                            int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, float out_fp8_scale,
+                            void* stream);
 /* same with dropout on the attention probabilities (see clibd_layernorm_fwd_drop for the mask definition) */
 int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
                              int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);

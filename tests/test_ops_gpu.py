@@ -380,7 +380,8 @@ def _softce_ref(x, y, labels, row0, scale):
     return -(T * torch.log_softmax(S, dim=1)).sum()
 
 
-@pytest.mark.parametrize("Nx,N,row0,dup", [(32, 32, 0, False), (64, 64, 0, True), (24, 96, 48, True), (256, 2048, 512, False), (10, 10, 0, True), (7, 21, 14, False)])
+@pytest.mark.parametrize("Nx,N,row0,dup", [(32, 32, 0, False), (64, 64, 0, True), (24, 96, 48, True), (256, 2048, 512, False), (10, 10, 0, True), (7, 21, 14, False),
+                                             (1024, 8192, 3072, True)])   # BASELINE configs[4]: rank 3's rows of a global batch of 8192
 def test_softce_rows_fwd_bwd(ops, dev, Nx, N, row0, dup):
     g = torch.Generator().manual_seed(N + Nx)
     D = 768

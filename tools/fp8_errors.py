@@ -1,0 +1,55 @@
+"""fp8-forward mode vs the bf16 path at full size: embedding / similarity / per-parameter gradient distances.
+    python tools/fp8_errors.py [--batch 16]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from clibd_amd.data import synthetic_batch
+from clibd_amd.model import ClipLoss, CLIBDDNAEncoder, CLIBDImageEncoder, SimpleCLIP, create_vit, load_pre_trained_bioscan_bert
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); args = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(11)
+model = SimpleCLIP(CLIBDImageEncoder(create_vit("vit_base_patch16_224"), r=4, num_classes=768),
+                   CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), r=4, num_classes=768), None)
+with torch.no_grad():
+    for n, p in model.named_parameters():
+        if "linear_b_" in n or ".w_b." in n:
+            p.normal_(0, 0.02)
+model = model.to(dev).eval()
+B = args.batch
+batch = synthetic_batch(B, dev, seed=5, rank=0, with_text=False)
+labels = (torch.arange(B) % 11).to(dev)
+crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+
+def run():
+    hi, hd, _, scale, _ = model(batch["image"], batch["dna"], None)
+    loss = crit(hi, hd, None, labels, scale)
+    ps = {n: p for n, p in model.named_parameters() if p.requires_grad}
+    gs = torch.autograd.grad(loss, list(ps.values()), allow_unused=True)
+    model.join_streams(); torch.cuda.synchronize()
+    return hi.detach().float().cpu(), hd.detach().float().cpu(), float(loss), {n: (torch.zeros_like(p) if g is None else g).float().cpu() for (n, p), g in zip(ps.items(), gs)}
+
+def cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float(a @ b / (a.norm() * b.norm() + 1e-30))
+
+i16, d16, l16, g16 = run()
+model.enable_fp8_forward()
+i8, d8, l8, g8 = run()
+print("loss", l16, l8)
+for nm, a, b in (("image", i8, i16), ("dna", d8, d16)):
+    print(nm, "max|d|", (a - b).abs().max().item(), "row cos min", ((a * b).sum(1)).min().item())
+    c16 = b - b.mean(0, keepdim=True); c8 = a - a.mean(0, keepdim=True)
+    print("   centred (row - batch mean): norm16", c16.norm(dim=1).mean().item(), "cos", cos(c8, c16))
+    print("   mutual cos of rows (bf16):", (b @ b.T).min().item())
+s16, s8 = i16 @ d16.T, i8 @ d8.T
+print("sim max|d|", (s16 - s8).abs().max().item(), "sim spread", (s16.max() - s16.min()).item())
+groups = {}
+for n in g16:
+    key = ("image" if n.startswith("image") else "dna") + ":" + ("lora_a" if ("linear_a" in n or "w_a" in n) else "lora_b" if ("linear_b" in n or "w_b" in n) else "head/other")
+    groups.setdefault(key, []).append(n)
+for k, ns in sorted(groups.items()):
+    a = torch.cat([g8[n].flatten() for n in ns]); b = torch.cat([g16[n].flatten() for n in ns])
+    print(f"{k:22s} cos {cos(a, b):.4f}  |g16| {b.norm().item():.3e} |g8| {a.norm().item():.3e}")
+a = torch.cat([g8[n].flatten() for n in sorted(g8)]); b = torch.cat([g16[n].flatten() for n in sorted(g16)])
+print("all", cos(a, b))
