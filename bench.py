@@ -239,10 +239,10 @@ def main():
     if args.full_finetune:
         for p_ in model.parameters():
             p_.requires_grad_(True)
-    if args.fp8_forward:
-        model.enable_fp8_forward()
     trainer = Trainer(model, lr=scale_learning_rate(1e-3, b, world_size=world), world_size=world, rank=rank, all_gather=True)
     batch = synthetic_batch(b, dev, seed=42, rank=rank, with_text=args.tri_modal)
+    if args.fp8_forward:   # per-layer activation scales from one bf16 forward over the batch (outside the timed region)
+        model.enable_fp8_forward(calibration_inputs=(batch["image"], batch["dna"], batch["text"]))
 
     timer = GemmTimer()
     if not args.no_gemm_timing:

@@ -157,6 +157,45 @@ __device__ __forceinline__ void gelu_and_grad_f(float x, float& y, float& dy) {
     y = x * cdf;
     dy = cdf + x * (0.3989422804014327f * e);
 }
+// The same for two elements, written on 2-vectors: the multiplies / fmas lower to v_pk_mul_f32 / v_pk_fma_f32 (packed fp32 issues
+// two lanes' worth per instruction).  tools/exp_fc1_epilogue.py, ViT fc1 at b=2048: the GELU form costs 2450 us against 1650 us
+// for the same GEMM with one plain bf16 store; with the arithmetic stubbed out 2110 us, i.e. ~450 us is the second 128-KB store
+// per tile and ~290 us the arithmetic.  Constants are folded to leave per element |x|, copysign, v_rcp, v_exp and 14
+// packed-pair multiplies / fmas (2400 us).
+//   exp(-x^2/2) = exp2(-(K|x|)^2), K = sqrt(log2(e)/2);  A&S 7.1.26 argument p*|x|/sqrt2 = P * (K|x|);  0.5 folded into the polynomial.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_and_grad_x2(f32x2 x, f32x2& y, f32x2& dy) {
+    constexpr float K = 0.84932180028801907f;
+    constexpr float P = 0.3275911f * 0.70710678118654752f / K;
+    f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    ax = ax * K;
+    const f32x2 d = ax * P + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 poly = ((((0.5307027145f * t - 0.7265760135f) * t + 0.7107068705f) * t - 0.142248368f) * t + 0.127414796f) * t;
+    const f32x2 s = ax * ax;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-s[0]), __builtin_amdgcn_exp2f(-s[1])};   // exp(-x^2/2)
+    const f32x2 h = 0.5f - poly * e;                                                    // erf(|x|/sqrt2) / 2 >= 0
+    const f32x2 hs = {copysignf(h[0], x[0]), copysignf(h[1], x[1])};
+    const f32x2 cdf = hs + 0.5f;
+    y = x * cdf;
+    dy = (x * e) * 0.3989422804014327f + cdf;
+}
+// two f32 rounded to bf16 and widened again (one v_cvt_pk_bf16_f32 + shift + mask)
+__device__ __forceinline__ f32x2 bfround2(float a, float b) {
+    const unsigned pk = pack2bf(a, b);
+    return (f32x2){__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+}
+// v[0..N) -> gelu(bf16(v)), dg = gelu'(bf16(v)), pairwise
+template <int N>
+__device__ __forceinline__ void gelu_and_grad_rows(float* v, float* dg) {
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+        f32x2 y, d;
+        gelu_and_grad_x2(bfround2(v[e], v[e + 1]), y, d);
+        v[e] = y[0]; v[e + 1] = y[1];
+        dg[e] = d[0]; dg[e + 1] = d[1];
+    }
+}
 // d/dx gelu(x) = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));

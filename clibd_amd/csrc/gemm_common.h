@@ -81,8 +81,7 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
     }
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
         float dg[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) gelu_and_grad_f(bfround(v[e]), v[e], dg[e]);
+        gelu_and_grad_rows<16>(v, dg);
         uint4 lo, hi;
         lo.x = pack2bf(dg[0], dg[1]);   lo.y = pack2bf(dg[2], dg[3]);   lo.z = pack2bf(dg[4], dg[5]);   lo.w = pack2bf(dg[6], dg[7]);
         hi.x = pack2bf(dg[8], dg[9]);   hi.y = pack2bf(dg[10], dg[11]); hi.z = pack2bf(dg[12], dg[13]); hi.w = pack2bf(dg[14], dg[15]);
@@ -192,8 +191,7 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
     }
     if (KIND == EPI_GELU_SAVE) {
         float dg[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) gelu_and_grad_f(bfround(v[e]), v[e], dg[e]);
+        gelu_and_grad_rows<8>(v, dg);
         *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(dg);
         *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
         return;
@@ -224,8 +222,7 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
     if (KIND == EPI_GENERIC) {
         if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
             float dg[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gelu_and_grad_f(bfround(v[e]), v[e], dg[e]);
+            gelu_and_grad_rows<8>(v, dg);
             *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(dg);
         } else if (ep.out_pre_bf16 != nullptr) {
             *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(v);
@@ -268,8 +265,7 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
 // fp8-forward fc1: gelu' saved as bf16 for the backward, the activation itself leaves as fp8 (fc2's operand)
 __device__ __forceinline__ void store_row8_gelu_fp8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8], float out_scale) {
     float dg[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) gelu_and_grad_f(bfround(v[e]), v[e], dg[e]);
+    gelu_and_grad_rows<8>(v, dg);
     *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(dg);
     *(uint2*)((unsigned char*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8fp8(v, out_scale);
 }

@@ -14,6 +14,7 @@ Reference arithmetic being replaced (all third-party model code the reference de
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -99,26 +100,53 @@ class TransformerStack:
         self.FF = layers[0].fc1_w.shape[0]
         self._cache: List[_LayerCache] = []
         self._cache_key = None
-        self.fp8 = None  # fp8-forward mode: {site: activation scale}; see enable_fp8
+        self.fp8 = None  # fp8-forward mode: [{site: activation scale}] per layer; see enable_fp8
+        self._calib = None
 
     # ---- fp8-forward mode (BASELINE.json configs[4]) ----------------------------------------------------------------
-    FP8_SCALES = dict(ln=8.0, attn=32.0, gelu=4.0)
+    # activation sites, named by the GEMM that consumes them
+    FP8_SITES = ("qkv_in", "proj_in", "fc1_in", "fc2_in")
+    FP8_SCALES = dict(qkv_in=8.0, proj_in=32.0, fc1_in=8.0, fc2_in=4.0)
 
-    def enable_fp8(self, scales: Optional[dict] = None):
+    def enable_fp8(self, scales: Optional[dict] = None, amax: Optional[list] = None, margin: float = 2.0):
         """The four forward GEMMs of every layer run on the fp8 MFMA (ops.gemm_fp8_nt): frozen weights are quantised per
-        output channel once, activations per tensor with the static power-of-two factors in `scales` (LayerNorm outputs,
-        attention outputs, GELU outputs; e4m3 saturates at 448 / scale) inside the kernels that produce them.  The backward
-        is unchanged bf16 (it needs gelu', qkv, statistics and — for the adapters — the bf16 LayerNorm output only), i.e.
-        gradients are those of the bf16 network evaluated at the fp8 forward's activations.  LoRA / frozen-base mode only."""
+        output channel once; activations per tensor, inside the kernels that produce them (LayerNorm, attention, fc1
+        epilogue), as e4m3(value * scale) saturating at +-448.  Scales are powers of two, per layer and site:
+          * amax = [{site: max |activation|} per layer] (from calibrate(): one bf16 forward over a representative batch):
+            scale = 2^floor(log2(448 / (margin * amax)));
+          * otherwise the static `scales` / FP8_SCALES for every layer (fits unit-variance LayerNorm outputs, random-init or
+            lightly trained towers; pretrained checkpoints with outlier channels want the calibration).
+        The backward is unchanged bf16 (it needs gelu', qkv, statistics and — for the adapters — the bf16 LayerNorm output
+        only): gradients are those of the bf16 network evaluated at the fp8 forward's activations.  LoRA / frozen-base mode only."""
         if self.full_mode():
             raise NotSupportedYet("fp8 forward needs frozen base weights (their gradients would need the bf16 GEMM inputs)")
         if self.H % 256 or self.H < 512 or self.FF % 256:
             raise NotSupportedYet("fp8 forward needs hidden % 256 == 0, hidden >= 512, intermediate % 256 == 0")
-        self.fp8 = dict(self.FP8_SCALES, **(scales or {}))
+        base = dict(self.FP8_SCALES, **(scales or {}))
+        per_layer = []
+        for i in range(len(self.layers)):
+            d = dict(base)
+            if amax is not None:
+                for site, v in amax[i].items():
+                    v = float(v)
+                    if v > 0.0 and math.isfinite(v):
+                        d[site] = 2.0 ** math.floor(math.log2(448.0 / (margin * v)))
+            per_layer.append(d)
+        self.fp8 = per_layer
         self._cache_key = None
 
     def disable_fp8(self):
         self.fp8 = None
+        self._cache_key = None
+
+    def calibrate(self, on: bool = True):
+        """on: the next bf16 forward records max |activation| per layer and fp8 site (device scalars, no sync);
+        off: returns them as [{site: float}] and stops recording."""
+        if on:
+            self._calib = []
+            return None
+        rec, self._calib = self._calib, None
+        return [{k: float(v) for k, v in d.items()} for d in (rec or [])]
 
     # ---- frozen-weight images ---------------------------------------------------------------------------------
     def _key(self):
@@ -152,11 +180,11 @@ class TransformerStack:
                 c.w2, c.w2_t, c.b2 = ops.cast_bf16(_f32c(L.fc2_w)), ops.cast_transpose_bf16(_f32c(L.fc2_w)), _f32c(L.fc2_b)
                 c.g1, c.be1, c.g2, c.be2 = _f32c(L.ln1_w), _f32c(L.ln1_b), _f32c(L.ln2_w), _f32c(L.ln2_b)
                 if self.fp8 is not None:
-                    f8 = self.fp8
-                    c.wqkv8, c.cs_qkv = ops.quantize_rows_fp8(wqkv.contiguous(), f8["ln"])
-                    c.wo8, c.cs_o = ops.quantize_rows_fp8(_f32c(L.proj_w), f8["attn"])
-                    c.w18, c.cs_1 = ops.quantize_rows_fp8(_f32c(L.fc1_w), f8["ln"])
-                    c.w28, c.cs_2 = ops.quantize_rows_fp8(_f32c(L.fc2_w), f8["gelu"])
+                    f8 = self.fp8[len(self._cache)]
+                    c.wqkv8, c.cs_qkv = ops.quantize_rows_fp8(wqkv.contiguous(), f8["qkv_in"])
+                    c.wo8, c.cs_o = ops.quantize_rows_fp8(_f32c(L.proj_w), f8["proj_in"])
+                    c.w18, c.cs_1 = ops.quantize_rows_fp8(_f32c(L.fc1_w), f8["fc1_in"])
+                    c.w28, c.cs_2 = ops.quantize_rows_fp8(_f32c(L.fc2_w), f8["fc2_in"])
                 c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = None
                 self._cache.append(c)
         self._cache_key = key
@@ -192,25 +220,30 @@ class TransformerStack:
         drop (post-LN only): (p_hidden, p_attention, base_seed) — HF BERT train-mode dropout; site seeds via ops.derive_seed.
         full: full fine-tune mode — every layer keeps its own attention output, MLP input and GELU output (the X operands of
         the weight gradients) instead of sharing temporaries.
-        x_fp8 (post-LN, fp8-forward mode): the e4m3 image of x (scale fp8["ln"]) from the embedding LayerNorm."""
+        x_fp8 (post-LN, fp8-forward mode): the e4m3 image of x (scale fp8[0]["qkv_in"]) from the embedding LayerNorm."""
         H, FF, M = self.H, self.FF, B * S
         dev = x_f32.device
         saved = []
         new = lambda cols, dt: torch.empty((M, cols), dtype=dt, device=dev)
         keep = save and full
-        f8 = self.fp8
-        if f8 is not None and full:
+        f8s = self.fp8
+        if f8s is not None and full:
             raise NotSupportedYet("fp8 forward with trainable base weights")
-        AT = ops.FP8 if f8 is not None else BF16    # dtype of the GEMM-operand temporaries
+        cal = self._calib if f8s is None else None      # calibration pass: bf16 forward recording max |operand| per site
+        amax = lambda t_: t_.abs().amax().float()
+        f8 = None
+        AT = ops.FP8 if f8s is not None else BF16    # dtype of the GEMM-operand temporaries
         o = None if keep else new(H, AT)            # attention output (temporary, reused by every layer)
         a = None if keep else new(FF, AT)           # post-GELU activation (temporary)
         xn2 = new(H, AT) if (self.pre_ln and not keep) else None
-        xn8 = new(H, ops.FP8) if f8 is not None else None   # fp8 image of the first LayerNorm's output (temporary)
-        h_tmp = new(FF, BF16) if (f8 is not None and not save) else None        # the fp8 fc1 form always writes gelu'
+        xn8 = new(H, ops.FP8) if f8s is not None else None   # fp8 image of the first LayerNorm's output (temporary)
+        h_tmp = new(FF, BF16) if (f8s is not None and not save) else None       # the fp8 fc1 form always writes gelu'
         t = t0
         for i, (L, c) in enumerate(zip(self.layers, self._cache)):
             has_lora = L.lora is not None
             rec = {}
+            f8 = f8s[i] if f8s is not None else None
+            crec = {} if cal is not None else None
             if keep:
                 o, a = new(H, BF16), new(FF, BF16)
                 xn2 = new(H, BF16) if self.pre_ln else None
@@ -221,11 +254,13 @@ class TransformerStack:
                 qkv = new(3 * H, BF16)
                 if f8 is not None:   # the full-size GEMM of this block; its class-row remainder stays bf16
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t,
-                                      y_fp8=xn8, fp8_scale=f8["ln"])
+                                      y_fp8=xn8, fp8_scale=f8["qkv_in"])
                     ops.gemm_fp8_nt(xn8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
                 else:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
                     ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
+                    if crec is not None:
+                        crec["qkv_in"] = amax(xn)
                 newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
                 o_cls = newB(H, BF16)
                 ops.attention_fwd(qkv, B, S, self.heads, key_mask, o_cls, nq=1)
@@ -257,12 +292,12 @@ class TransformerStack:
                 x2 = new(H, F32)
                 if f8 is not None:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t,
-                                      y_fp8=xn8, fp8_scale=f8["ln"])
+                                      y_fp8=xn8, fp8_scale=f8["qkv_in"])
                     ops.gemm_fp8_nt(xn8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
-                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, out_fp8_scale=f8["attn"])
+                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, out_fp8_scale=f8["proj_in"])
                     ops.gemm_fp8_nt(o, c.wo8, c.cs_o, bias=c.bo, residual=x_f32, out_f32=x1)
-                    ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, stats=st2, y_fp8=xn2, fp8_scale=f8["ln"])
-                    ops.gemm_fp8_nt(xn2, c.w18, c.cs_1, bias=c.b1, gelu_out_fp8=a, gelu_out_scale=f8["gelu"], out_pre=h if save else h_tmp)
+                    ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, stats=st2, y_fp8=xn2, fp8_scale=f8["fc1_in"])
+                    ops.gemm_fp8_nt(xn2, c.w18, c.cs_1, bias=c.b1, gelu_out_fp8=a, gelu_out_scale=f8["fc2_in"], out_pre=h if save else h_tmp)
                     ops.gemm_fp8_nt(a, c.w28, c.cs_2, bias=c.b2, residual=x1, out_f32=x2)
                 else:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
@@ -272,6 +307,8 @@ class TransformerStack:
                     ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
                     ops.gemm_nt(xn2, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                     ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1, out_f32=x2)
+                    if crec is not None:
+                        crec.update(qkv_in=amax(xn), proj_in=amax(o), fc1_in=amax(xn2), fc2_in=amax(a))
                 if save:
                     rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h)
                     if keep:
@@ -301,14 +338,14 @@ class TransformerStack:
                     x1_bf16 = None
                     x18 = xn8
                     ops.gemm_fp8_nt(x_fp8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=ru, rank_v=rv, out_bf16=qkv)
-                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att, out_fp8_scale=f8["attn"])
+                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att, out_fp8_scale=f8["proj_in"])
                     ops.gemm_fp8_nt(o, c.wo8, c.cs_o, bias=c.bo, residual=x_f32, out_f32=s1, drop=d_h1)
-                    ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_f32=x1_f32, stats=st1, y_fp8=x18, fp8_scale=f8["ln"])
-                    ops.gemm_fp8_nt(x18, c.w18, c.cs_1, bias=c.b1, gelu_out_fp8=a, gelu_out_scale=f8["gelu"], out_pre=h if save else h_tmp)
+                    ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_f32=x1_f32, stats=st1, y_fp8=x18, fp8_scale=f8["fc1_in"])
+                    ops.gemm_fp8_nt(x18, c.w18, c.cs_1, bias=c.b1, gelu_out_fp8=a, gelu_out_scale=f8["fc2_in"], out_pre=h if save else h_tmp)
                     ops.gemm_fp8_nt(a, c.w28, c.cs_2, bias=c.b2, residual=x1_f32, out_f32=s2, drop=d_h2)
                     x8_next = new(H, ops.FP8)
                     ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next,
-                                      y_fp8=x8_next, fp8_scale=f8["ln"])
+                                      y_fp8=x8_next, fp8_scale=f8s[min(i + 1, len(f8s) - 1)]["qkv_in"])
                     x_fp8 = x8_next
                 else:
                     x1_bf16 = new(H, BF16)
@@ -319,6 +356,8 @@ class TransformerStack:
                     ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                     ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1_f32, out_f32=s2, drop=d_h2)
                     ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next)
+                    if crec is not None:
+                        crec.update(qkv_in=amax(x_bf16), proj_in=amax(o), fc1_in=amax(x1_bf16), fc2_in=amax(a))
                 if save:
                     rec = dict(x_bf16=x_bf16, t=t if has_lora else None, qkv=qkv, s1=s1, st1=st1, h=h, s2=s2, st2=st2,
                                d_att=d_att, d_h1=d_h1, d_h2=d_h2)
@@ -326,6 +365,8 @@ class TransformerStack:
                         rec.update(o=o, x1_bf16=x1_bf16, a=a)
                 x_f32, x_bf16, t = x2_f32, x2_bf16, t_next
             saved.append(rec)
+            if cal is not None:
+                cal.append(crec)
         return x_f32, x_bf16, saved
 
     # ---- backward -----------------------------------------------------------------------------------------------

@@ -102,16 +102,29 @@ class SimpleCLIP(nn.Module):
         dna_output, image_output, language_output = outs
         return image_output, dna_output, language_output, self.logit_scale.exp(), self.logit_bias
 
-    def enable_fp8_forward(self, scales: Optional[dict] = None, enabled: bool = True):
+    def enable_fp8_forward(self, scales: Optional[dict] = None, enabled: bool = True, calibration_inputs=None, margin: float = 2.0):
         """fp8-forward mode (BASELINE.json configs[4]; not in the reference, which trains under bf16 autocast): the towers'
-        forward GEMMs run on the fp8 MFMA, see TransformerStack.enable_fp8.  Needs frozen base weights (LoRA mode)."""
-        for enc in (self.image_encoder, self.dna_encoder, self.language_encoder):
-            if enc is not None and hasattr(enc, "tower"):
-                stack = enc.tower().stack
-                if enabled:
-                    stack.enable_fp8(scales)
-                else:
-                    stack.disable_fp8()
+        forward GEMMs run on the fp8 MFMA, see TransformerStack.enable_fp8.  Needs frozen base weights (LoRA mode).
+        calibration_inputs = (image_input, dna_input, language_input): one bf16 no-grad forward over that batch measures
+        max |activation| per layer and site and sets the per-layer power-of-two scales with `margin` headroom; without it
+        the static FP8_SCALES are used."""
+        stacks = [enc.tower().stack for enc in (self.image_encoder, self.dna_encoder, self.language_encoder)
+                  if enc is not None and hasattr(enc, "tower")]
+        if not enabled:
+            for st in stacks:
+                st.disable_fp8()
+            return self
+        amax = [None] * len(stacks)
+        if calibration_inputs is not None:
+            for st in stacks:
+                st.disable_fp8()
+                st.calibrate(True)
+            with torch.no_grad():
+                self(*calibration_inputs)
+            self.join_streams()
+            amax = [st.calibrate(False) for st in stacks]
+        for st, am in zip(stacks, amax):
+            st.enable_fp8(scales, amax=am if am else None, margin=margin)
         return self
 
     def join_streams(self):

@@ -273,7 +273,7 @@ class BertTower(_Tower):
         f8 = self.stack.fp8
         x_fp8 = torch.empty((M, H), dtype=ops.FP8, device=dev) if f8 is not None else None
         ops.layernorm_fwd(e, _f32c(emb.LayerNorm.weight), _f32c(emb.LayerNorm.bias), float(emb.LayerNorm.eps), y_bf16=x_bf16, y_f32=x_f32,
-                          stats=st_e, lora_a=a0, t_out=t0, drop=d_emb, y_fp8=x_fp8, fp8_scale=f8["ln"] if f8 is not None else 0.0)
+                          stats=st_e, lora_a=a0, t_out=t0, drop=d_emb, y_fp8=x_fp8, fp8_scale=f8[0]["qkv_in"] if f8 is not None else 0.0)
         x_f32, x_bf16, saved = self.stack.forward(x_f32, x_bf16, t0, B, S, key_mask, save, drop=drop, full=full, x_fp8=x_fp8)
         state = dict(saved=saved, B=B, S=S, key_mask=key_mask, full=full) if save else None
         if full:

@@ -158,6 +158,47 @@ def test_full_size_fp8_forward_close_to_bf16_path(dev):
     assert gcos([n for n in sorted(g16) if n.startswith("dna") and ("w_a" in n or "w_b" in n)]) > 0.85
 
 
+def test_fp8_calibration_sets_per_layer_scales(dev):
+    """Calibrated per-layer scales are powers of two with headroom under 448 / amax and keep the embeddings within the mode's
+    tolerance.  Then one LayerNorm of the ViT gets a gain of 96: its output (max ~ 400) saturates e4m3 under the static
+    scale 8, while the calibrated scale of that layer drops and the result stays closer to the bf16 path."""
+    from clibd_amd.data import synthetic_batch
+
+    model = _full_size_pair(dev)
+    B = 8
+    batch = synthetic_batch(B, dev, seed=5, rank=0, with_text=False)
+    cal = (batch["image"], batch["dna"], None)
+
+    def emb():
+        with torch.no_grad():
+            hi, hd, _, _, _ = model(batch["image"], batch["dna"], None)
+        model.join_streams()
+        torch.cuda.synchronize()
+        return hi.float().cpu(), hd.float().cpu()
+
+    cosr = lambda a, b: ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).min().item()
+    i16, d16 = emb()
+    model.enable_fp8_forward(calibration_inputs=cal)
+    i_cal, d_cal = emb()
+    st = model.image_encoder.tower().stack
+    assert len(st.fp8) == 12 and all(set(d) == set(st.FP8_SITES) for d in st.fp8)
+    for d in st.fp8:
+        for v in d.values():
+            assert v > 0 and abs(torch.log2(torch.tensor(v)).item() - round(torch.log2(torch.tensor(v)).item())) < 1e-6
+    assert cosr(i_cal, i16) > 0.99 and cosr(d_cal, d16) > 0.99
+    scale2 = st.fp8[2]["qkv_in"]
+    model.enable_fp8_forward(enabled=False)
+    with torch.no_grad():
+        model.image_encoder.base_image_encoder.blocks[3].norm1.weight.mul_(96.0)
+    i16, _ = emb()
+    model.enable_fp8_forward()
+    i_static, _ = emb()
+    model.enable_fp8_forward(calibration_inputs=cal)
+    i_cal, _ = emb()
+    assert st.fp8[3]["qkv_in"] * 16 <= scale2                                      # the hot layer got a much smaller scale
+    assert (i_cal - i16).abs().max() < (i_static - i16).abs().max()               # saturation hurts the static scales
+
+
 def test_fp8_forward_needs_frozen_base_and_supported_width(dev):
     from clibd_amd.engine import NotSupportedYet
     from clibd_amd.model import CLIBDImageEncoder, create_vit
