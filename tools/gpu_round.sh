@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, the bench line on the metric's configuration, secondary configs, rocprofv3 summaries.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [steps to run, default "test bench b256 tri prof"]
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [steps to run, default "test bench b256 tri prof"; also: fp8 pmc]
 set -u
 TAG=${1:-run}
 WHAT=${2:-"test bench b256 tri prof"}
@@ -23,6 +23,12 @@ fi
 if has tri; then
   timeout 600 python bench.py --tri-modal --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_trimodal_b2048.json" 2> "$OUT/bench_trimodal.err"
   echo "tri exit $?"; tail -c 600 "$OUT/bench_trimodal_b2048.json"
+fi
+if has fp8; then   # BASELINE configs[4]: opt-in fp8-forward mode, at the metric's batch and at the per-GPU batch configs[4] names
+  timeout 600 python bench.py --fp8-forward --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --gemm-breakdown > "$OUT/bench_fp8_b2048.json" 2> "$OUT/bench_fp8_b2048.err"
+  echo "fp8 exit $?"; tail -c 600 "$OUT/bench_fp8_b2048.json"
+  timeout 600 python bench.py --fp8-forward --per-gpu-batch 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-h2d > "$OUT/bench_fp8_b1024.json" 2> "$OUT/bench_fp8_b1024.err"
+  echo "fp8 b1024 exit $?"; tail -c 600 "$OUT/bench_fp8_b1024.json"
 fi
 if has prof; then
   export CLIBD_TOWER_STREAMS=0
