@@ -144,7 +144,7 @@ def test_full_size_fp8_forward_close_to_bf16_path(dev):
     i8, d8, l8, g8 = run()
     model.enable_fp8_forward(enabled=False)
     i16b, d16b, l16b, _ = run()
-    assert torch.equal(i16, i16b) and torch.equal(d16, d16b) and l16 == l16b        # the mode switches off cleanly
+    assert torch.equal(i16, i16b) and torch.equal(d16, d16b) and abs(l16 - l16b) < 1e-5   # the mode switches off cleanly (the loss is an atomic sum)
     for a, b in ((i8, i16), (d8, d16)):
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() < 2e-2
