@@ -370,8 +370,15 @@ class TransformerStack:
         return x_f32, x_bf16, saved
 
     # ---- backward -----------------------------------------------------------------------------------------------
-    def backward(self, dx_f32, dx_bf16, saved, B: int, S: int, key_mask, grads: dict, full: bool = False):
+    def layer_params(self, i: int):
+        """Every parameter of layer i a gradient can be produced for (base weights + adapters)."""
+        L = self.layers[i]
+        return L.frozen() + (L.lora.tensors() if L.lora is not None else [])
+
+    def backward(self, dx_f32, dx_bf16, saved, B: int, S: int, key_mask, grads: dict, full: bool = False, on_layer_done=None):
         """dx = gradient w.r.t. the stack output (fp32 residual stream; pre-LN also needs its bf16 image).
+        on_layer_done(i): called once layer i's parameter gradients are complete (enqueued on the current stream) — the
+        trainer's hook for starting that layer's gradient all-reduce under the rest of the backward.
         Fills grads[id(param)] for the adapters — and, in full fine-tune mode, for every base weight / bias / LayerNorm
         parameter present in `grads`; returns the fp32 gradient w.r.t. the stack input then (None in LoRA mode, where the
         walk stops at the lowest adapted layer because nothing below it is trainable)."""
@@ -454,6 +461,8 @@ class TransformerStack:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
                                 residual=ds1_f32, out_f32=ndx)
                     dx_f32 = ndx
+            if on_layer_done is not None:
+                on_layer_done(i)
         return dx_f32 if full else None
 
     def _lora_grads(self, L, c, dqkv, x_bf16, t, dt, grads):

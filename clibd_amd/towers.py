@@ -40,6 +40,7 @@ class _TowerFn(torch.autograd.Function):
         if sink is not None and all(id(p) in sink for p in params):
             # trainer-owned flat gradient bucket (clibd_amd.optim.FusedAdamW): accumulate straight into it
             tower._backward(dout.contiguous().to(F32), state, sink)
+            tower._ready(None)  # every gradient of this tower is final
             ctx.state = None
             return (None, None, None, *([None] * len(params)))
         bucket = GradBucket(params)
@@ -55,6 +56,22 @@ class _Tower:
         raise NotImplementedError
 
     training = False  # set by the owning nn.Module before each call (module.training)
+
+    # Gradient-ready protocol (data-parallel full fine-tune: the trainer starts a group's all-reduce while the backward is
+    # still walking down the tower).  grad_groups(): parameter lists in the order their gradients become final; the backward
+    # calls on_grads_ready(k) after group k (None: everything), always from the stream the gradients were produced on.
+    on_grads_ready = None
+
+    def grad_groups(self) -> List[List[torch.nn.Parameter]]:
+        return [self.trainable_params()]
+
+    def _ready(self, k):
+        if self.on_grads_ready is not None:
+            self.on_grads_ready(k)
+
+    def _stack_groups(self, head, embed):
+        n = len(self.stack.layers)
+        return [head] + [self.stack.layer_params(i) for i in range(n - 1, -1, -1)] + [embed]
 
     def __call__(self, *inputs):
         params = _trainable(self.trainable_params())
@@ -110,6 +127,11 @@ class ViTTower(_Tower):
         v = self.vit
         return [v.patch_embed.proj.weight, v.patch_embed.proj.bias, v.cls_token, v.pos_embed, v.norm.weight, v.norm.bias]
 
+    def grad_groups(self):
+        v = self.vit
+        head = ([v.head.weight, v.head.bias] if isinstance(v.head, torch.nn.Linear) else []) + [v.norm.weight, v.norm.bias]
+        return self._stack_groups(head, [v.patch_embed.proj.weight, v.patch_embed.proj.bias, v.cls_token, v.pos_embed])
+
     def _full(self):
         return self.stack.full_mode() or any(p.requires_grad for p in self._frozen_extra())
 
@@ -161,7 +183,10 @@ class ViTTower(_Tower):
         full = state["full"]
         pg = dict(dgamma=grads[id(v.norm.weight)].view(-1), dbeta=grads[id(v.norm.bias)].view(-1)) if full and id(v.norm.weight) in grads else {}
         ops.layernorm_bwd(dxn, state["xcls"], state["st"], _f32c(v.norm.weight), dx_f32=dxcls, dx_bf16=dxcls_b, **pg)
-        dtok = self.stack.backward(dxcls, dxcls_b, state["saved"], B, S, None, grads, full=full)  # [B,H]: the last block runs class-row-only
+        self._ready(0)
+        nl = len(self.stack.layers)
+        dtok = self.stack.backward(dxcls, dxcls_b, state["saved"], B, S, None, grads, full=full,   # [B,H]: the last block runs class-row-only
+                                   on_layer_done=lambda i: self._ready(nl - i))
         if full:
             # tokens = [cls + pos[0] | patch_proj + pos[1:]]  (timm VisionTransformer._pos_embed)
             d3 = dtok.view(B, S, H)
@@ -227,6 +252,16 @@ class BertTower(_Tower):
 
     def _full(self):
         return self.stack.full_mode() or any(p.requires_grad for p in self._frozen_extra())
+
+    def grad_groups(self):
+        emb = self.bert.embeddings
+        if self.head_kind == "mlm":
+            head = [self.hm["decoder"].weight, self.hm["decoder"].bias, self.hm["transform_dense"].weight, self.hm["transform_dense"].bias,
+                    self.hm["transform_ln"].weight, self.hm["transform_ln"].bias]
+        else:
+            head = [self.hm["proj"].weight, self.hm["proj"].bias]
+        return self._stack_groups(head, [emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
+                                         emb.LayerNorm.weight, emb.LayerNorm.bias])
 
     def _head_images(self):
         if self.head_kind != "mlm":
@@ -326,7 +361,9 @@ class BertTower(_Tower):
             dmean = dense_head_backward(dout, state["mean"], proj.weight, proj.bias, grads, out_bf16=False)
             dx = ops.token_mean_bwd(dmean, S).view(M, H)
         full = state["full"]
-        dx0 = self.stack.backward(dx, None, state["saved"], B, S, state["key_mask"], grads, full=full)
+        self._ready(0)
+        nl = len(self.stack.layers)
+        dx0 = self.stack.backward(dx, None, state["saved"], B, S, state["key_mask"], grads, full=full, on_layer_done=lambda i: self._ready(nl - i))
         if full:
             # x0 = dropout(LayerNorm(word[ids] + position[s] + token_type[tt]))   (HF BertEmbeddings)
             emb = self.bert.embeddings

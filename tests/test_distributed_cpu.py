@@ -266,3 +266,128 @@ def test_trainer_world2_gloo_matches_full_batch_adamw():
     out = mgr.dict()
     mp.spawn(_trainer_worker, args=(2, 29622, out), nprocs=2, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------------------- Trainer: all-reduce in backward order
+class _SinkLinearFn(torch.autograd.Function):
+    """A tower in miniature: writes its parameter gradients straight into the trainer's flat bucket and reports each
+    gradient group as it completes (the protocol of clibd_amd.towers._Tower / _TowerFn)."""
+
+    @staticmethod
+    def forward(ctx, tower, x, w, b):
+        ctx.tower = tower
+        ctx.save_for_backward(x, w)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        tw = ctx.tower
+        tw.grad_sink[id(tw.lin.bias)].add_(dy.sum(0))
+        tw._ready(0)                                   # group 0 = [bias] ("head"), then group 1 = [weight] ("layer")
+        tw.grad_sink[id(tw.lin.weight)].add_(dy.t() @ x)
+        tw._ready(1)
+        tw._ready(None)
+        return None, None, None, None
+
+
+class _HookedTower(_ToyTower):
+    on_grads_ready = None
+
+    def grad_groups(self):
+        return [[self.lin.bias], [self.lin.weight]]
+
+    def _ready(self, k):
+        if self.on_grads_ready is not None:
+            self.on_grads_ready(k)
+
+
+class _HookedEnc(_ToyEnc):
+    def __init__(self, din, dout):
+        super().__init__(din, dout)
+        self._tower = _HookedTower(self.lin)
+
+    def forward(self, x):
+        return _SinkLinearFn.apply(self._tower, x, self.lin.weight, self.lin.bias)
+
+
+class _HookedCLIP(_ToyCLIP):
+    def __init__(self):
+        super().__init__()
+        self.image_encoder, self.dna_encoder = _HookedEnc(12, 16), _HookedEnc(9, 16)
+
+
+def _bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clibd_amd import optim, train
+        from clibd_amd.model import loss_func
+        from oracle import clibd_oracle as O
+
+        loss_func.ops = _FakeOps
+        optim.ops.adamw_step = _cpu_adamw_step
+        optim.FusedAdamW._check_params = staticmethod(lambda ps, dev: None)
+        torch.manual_seed(200 + rank)
+        model = _HookedCLIP()
+        torch.manual_seed(200)
+        ref_model = _ToyCLIP()                    # plain autograd, rank 0's initialisation
+        torch.manual_seed(200)
+        ref_model.load_state_dict(_HookedCLIP().state_dict())
+        b = 5
+        g = torch.Generator().manual_seed(4)
+        image, dna = torch.randn(world * b, 12, generator=g), torch.randn(world * b, 9, generator=g)
+        labels = torch.tensor([0, 1, 2, 2, 4, 5, 6, 0, 8, 9])
+        issued = []
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(t, *a, **k):
+            issued.append(t.numel())
+            return real_all_reduce(t, *a, **k)
+
+        train.dist.all_reduce = counting_all_reduce
+        tr = train.Trainer(model, lr=1e-2, world_size=world, rank=rank, all_gather=True, bucket_bytes=256)   # 64 elements: every group is a bucket
+        why = []
+        ok = tr._bucketed
+        # flat order follows the backward: per tower bias (group 0) then weight (group 1); logit_scale last
+        names = {id(p): n for n, p in model.named_parameters()}
+        order = [names[id(p)] for p in tr.optimizer.param_groups[0]["params"]]
+        if order != ["image_encoder.lin.bias", "image_encoder.lin.weight", "dna_encoder.lin.bias", "dna_encoder.lin.weight", "logit_scale"]:
+            why.append(("order", order))
+        ropt = torch.optim.AdamW([p for n, p in ref_model.named_parameters() if "unused" not in n], lr=1e-2, weight_decay=1e-2)
+        sl = slice(rank * b, (rank + 1) * b)
+        for _ in range(3):
+            issued.clear()
+            loss = tr.step(image[sl], dna[sl], None, labels[sl])
+            if not (len(issued) == 5 and sum(issued) == tr.optimizer.flat_comm.numel()):   # 2 towers x 2 groups during the backward + the tail; disjoint cover
+                why.append(("issued", list(issued), tr.optimizer.flat_comm.numel()))
+            ropt.zero_grad()
+            i, d, _, sc, _ = ref_model(image, dna, None)
+            rl = O.contrastive_loss([i, d, None], labels, sc)
+            rl.backward()
+            ropt.step()
+            if abs(float(loss.detach()) - float(rl.detach())) >= 1e-5:
+                why.append(("loss", float(loss.detach()), float(rl.detach())))
+        ref = dict(ref_model.named_parameters())
+        for n, p in model.named_parameters():
+            if not torch.allclose(p, ref[n], rtol=1e-4, atol=1e-6):
+                why.append(("param", n))
+        out[rank] = True if (ok and not why) else repr(why)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_world2_bucketed_allreduce_in_backward_order():
+    """Large gradient sets (full fine-tune) are all-reduced in pieces, each issued by the tower's backward as soon as a
+    gradient group is complete; here with toy towers that speak the same protocol and a 256-byte bucket: the flat bucket is
+    laid out in backward order, five disjoint collectives cover it, and three steps match single-process AdamW on the full
+    batch (reference: DDP's bucketed gradient all-reduce, scripts/train_cl.py:204)."""
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bucket_worker, args=(2, 29633, out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}

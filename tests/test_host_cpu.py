@@ -151,3 +151,35 @@ def test_load_clip_model_accepts_the_reference_simclr_checkpoint_key(tmp_path):
     torch.save({"state_dict": {"module.bogus": torch.zeros(1)}}, path)
     with pytest.raises(RuntimeError):
         load_clip_model(a)
+
+
+def test_gradient_groups_cover_the_trainable_parameters_in_backward_order():
+    """towers._Tower.grad_groups (the unit of the bucketed data-parallel all-reduce, train.Trainer): every parameter a tower
+    can produce a gradient for sits in exactly one group; head first, layers top -> bottom, embeddings last; and the trainer
+    lays the flat bucket out in that order, logit_scale at the end."""
+    from clibd_amd.model import (BertConfigLite, BertForMaskedLM, BertModel, CLIBDDNAEncoder, CLIBDImageEncoder, CLIBDLanguageEncoder,
+                                 SimpleCLIP, VisionTransformer)
+    from clibd_amd.train import _backward_order, _gradient_reachable
+
+    ie = CLIBDImageEncoder(VisionTransformer(embed_dim=64, depth=3, num_heads=1, num_classes=0), 4, 32)
+    cfg = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128)
+    de = CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, **cfg)), 4, 32)
+    te = CLIBDLanguageEncoder(BertModel(BertConfigLite(vocab_size=100, **cfg)), 4, 32)
+    model = SimpleCLIP(ie, de, te)
+    for p in model.parameters():
+        p.requires_grad_(True)                     # full fine-tune: every group is populated
+    for enc, depth in ((ie, 3), (de, 2), (te, 2)):
+        tw = enc.tower()
+        groups = tw.grad_groups()
+        assert len(groups) == depth + 2
+        flat = [id(p) for g in groups for p in g]
+        assert len(flat) == len(set(flat)) and set(flat) == {id(p) for p in tw.trainable_params()}
+        names = {id(p): n for n, p in enc.named_parameters()}
+        for k, g in enumerate(groups[1:-1]):       # layer groups: top layer first
+            layer = depth - 1 - k
+            assert all(f".{layer}." in names[id(p)] for p in g), (k, [names[id(p)] for p in g])
+    params = _gradient_reachable(model, None)
+    ordered, counts = _backward_order(model, params)
+    assert {id(p) for p in ordered} == {id(p) for p in params} and len(ordered) == len(params)
+    assert ordered[-1] is model.logit_scale and [len(c) for c in counts] == [5, 4, 4]
+    assert sum(sum(c) for c in counts) == len(ordered) - 1

@@ -531,6 +531,27 @@ def test_full_finetune_training_step_updates_base_weights(dev):
     assert (w.detach() - before).abs().max().item() > 0
     losses = [l0] + [float(tr.step(img, ids, None, labels)) for _ in range(7)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+    # gradient-ready protocol of the towers (the trainer's hook for the bucketed all-reduce at world_size > 1): head, then the
+    # layers from the top down, then "everything" — and at each call the gradients of that group are already in the bucket
+    seen = {}
+    for name, enc in (("image", model.image_encoder), ("dna", model.dna_encoder)):
+        tw = enc.tower()
+        groups = tw.grad_groups()
+        log = seen.setdefault(name, [])
+
+        def hook(k, tw=tw, groups=groups, log=log):
+            if k is not None and k > 0:   # layer groups: their weight gradients must be non-zero when the group is reported
+                g = groups[k][2]          # a weight matrix of that layer (ViT: proj_w; BERT: the value projection)
+                log.append((k, float(tw.grad_sink[id(g)].abs().sum()) > 0))
+            else:
+                log.append((k, True))
+        tw.on_grads_ready = hook
+    tr.step(img, ids, None, labels)
+    for name, enc in (("image", model.image_encoder), ("dna", model.dna_encoder)):
+        nl = len(enc.tower().stack.layers)
+        assert [k for k, _ in seen[name]] == list(range(nl + 1)) + [None], seen[name]
+        assert all(ok for _, ok in seen[name])
+        enc.tower().on_grads_ready = None
 
 
 # ------------------------------------------------------------------------------------------ streams / full-size properties
