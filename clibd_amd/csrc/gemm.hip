@@ -172,40 +172,53 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned shor
 }
 
 // fast form (C % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0, 16-byte aligned bases): 16-byte global loads and stores on both
-// sides, 64 x 64 tile in LDS with a 132-byte row stride (column reads of 8 rows hit 8 different banks), and — optionally —
+// sides, a (64 RB) x 64 tile in LDS with a 132-byte row stride (column reads of 8 rows hit 8 different banks), and — optionally —
 // the column sums of the input (the bias gradient of y = x W^T + b is colsum(dy); the weight gradient needs dy^T anyway, so
 // the full fine-tune backward gets db for free instead of a second pass over dy).  Rows R .. ld_out-1 of the output are zero.
+// RB = 4 (256-row tiles): 8 independent 16-byte loads per thread in flight before the barrier and 512 contiguous bytes per
+// output row and block; the 64-row tile of the first version (2 loads in flight, 16 KB per block) ran at 3.2 TB/s.
+template <int RB>
 __global__ __launch_bounds__(256) void transpose_colsum_bf16_kernel(const unsigned short* __restrict__ in, int ld_in, int R, int C,
                                                                     unsigned short* __restrict__ out, int ld_out,
                                                                     float* __restrict__ colsum) {
-    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * 66];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * RB * 66];
+    const int r0 = blockIdx.y * (64 * RB), c0 = blockIdx.x * 64;
     const int t = threadIdx.x;
+    uint4 v[2 * RB];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 2 * RB; ++k) {
         const int row = (t >> 3) + 32 * k, ch = t & 7;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r0 + row < R && c0 + 8 * ch < C) v = *(const uint4*)(in + (size_t)(r0 + row) * ld_in + c0 + 8 * ch);
+        v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + row < R && c0 + 8 * ch < C) v[k] = *(const uint4*)(in + (size_t)(r0 + row) * ld_in + c0 + 8 * ch);
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * RB; ++k) {
+        const int row = (t >> 3) + 32 * k, ch = t & 7;
         unsigned* d = (unsigned*)(tile + row * 66 + 8 * ch);   // 4-byte aligned: 132 * row + 16 * ch
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int c = (t >> 3) + 32 * k, rch = t & 7;
-        unsigned short e[8];
+        float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = tile[(8 * rch + j) * 66 + c];
-        if (c0 + c < C && r0 + 8 * rch < ld_out) {
-            uint4 o;
-            o.x = (unsigned)e[0] | ((unsigned)e[1] << 16); o.y = (unsigned)e[2] | ((unsigned)e[3] << 16);
-            o.z = (unsigned)e[4] | ((unsigned)e[5] << 16); o.w = (unsigned)e[6] | ((unsigned)e[7] << 16);
-            *(uint4*)(out + (size_t)(c0 + c) * ld_out + r0 + 8 * rch) = o;
+        for (int rb = 0; rb < RB; ++rb) {
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = tile[(64 * rb + 8 * rch + j) * 66 + c];
+            if (c0 + c < C && r0 + 64 * rb + 8 * rch < ld_out) {
+                uint4 o;
+                o.x = (unsigned)e[0] | ((unsigned)e[1] << 16); o.y = (unsigned)e[2] | ((unsigned)e[3] << 16);
+                o.z = (unsigned)e[4] | ((unsigned)e[5] << 16); o.w = (unsigned)e[6] | ((unsigned)e[7] << 16);
+                *(uint4*)(out + (size_t)(c0 + c) * ld_out + r0 + 64 * rb + 8 * rch) = o;
+            }
+            if (colsum != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += bf2f(e[j]);
+            }
         }
-        if (colsum != nullptr) {   // 8 adjacent lanes (rch = 0..7) hold the 64 rows of column c
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum += bf2f(e[j]);
+        if (colsum != nullptr) {   // 8 adjacent lanes (rch = 0..7) hold the 64 RB rows of column c
             sum += dpp_mov<DPP_QUAD_XOR1>(sum);
             sum += dpp_mov<DPP_QUAD_XOR2>(sum);
             sum += dpp_mov<DPP_ROW_HALF_MIRROR>(sum);
@@ -386,8 +399,14 @@ static int transpose_impl(const void* in, int ld_in, int R, int C, void* out, in
     if (grid.y > 65535u) return set_error(CLIBD_EINVAL, "transpose: too many rows for one launch");
     const bool fast = (C % 8 == 0) && (ld_in % 8 == 0) && (ld_out % 8 == 0) && aligned16(in) && aligned16(out);
     if (fast) {
-        hipLaunchKernelGGL(transpose_colsum_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, ld_in, R, C,
-                           (unsigned short*)out, ld_out, colsum);
+        if (ld_out >= 1024) {   // long row dimension (activations): 256-row tiles
+            dim3 grid4((C + 63) / 64, (ld_out + 255) / 256);
+            hipLaunchKernelGGL(transpose_colsum_bf16_kernel<4>, grid4, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, ld_in, R, C,
+                               (unsigned short*)out, ld_out, colsum);
+        } else {
+            hipLaunchKernelGGL(transpose_colsum_bf16_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, ld_in, R, C,
+                               (unsigned short*)out, ld_out, colsum);
+        }
         return check_launch("transpose_colsum_bf16");
     }
     if (colsum != nullptr) return set_error(CLIBD_EINVAL, "transpose_colsum: needs C, ld_in, ld_out multiples of 8 and 16-byte aligned bases");
