@@ -88,6 +88,7 @@ SIGNATURES = {
     "clibd_kmer_tokenize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "clibd_layernorm_param_grads": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),
     "clibd_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "clibd_gemm_bf16_tn_splitk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_gemm_bf16_nt_splitk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "clibd_dropout_apply_f32": (c_int, [c_void_p, c_size_t, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),
     "clibd_batch_sum_f32": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p]),

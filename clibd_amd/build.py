@@ -21,7 +21,7 @@ INCLUDE = HERE.parent / "include"
 LIB = HERE / "libclibd_hip.so"
 OBJ = CSRC / "build"
 ARCH = "gfx950"
-SOURCES = ["capi", "gemm", "gemm256", "layernorm", "attention", "lora", "elementwise", "loss", "topk", "paramgrad"]
+SOURCES = ["capi", "gemm", "gemm256", "gemm256_tn", "layernorm", "attention", "lora", "elementwise", "loss", "topk", "paramgrad"]
 
 
 def csrc_hash() -> str:

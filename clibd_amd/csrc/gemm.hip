@@ -393,6 +393,24 @@ extern "C" int clibd_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, 
     return check_launch("reduce_splits");
 }
 
+extern "C" int clibd_gemm_bf16_tn_splitk(const void* A, int lda, const void* B, int ldb, int M, int Na, int Nb, float* out_f32, int ld_out,
+                                         int accumulate, float* colsum_a, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !B || !out_f32 || !workspace) return set_error(CLIBD_EINVAL, "gemm_tn_splitk: null pointer");
+    if (M <= 0 || Na <= 0 || Nb <= 0 || lda < Na || ldb < Nb || ld_out != Nb) return set_error(CLIBD_EINVAL, "gemm_tn_splitk: bad shape (out must be dense [Na,Nb])");
+    if ((lda & 7) || (ldb & 7) || !aligned16(A) || !aligned16(B) || !aligned16(out_f32) || !aligned16(workspace))
+        return set_error(CLIBD_EINVAL, "gemm_tn_splitk: alignment");
+    const int splits = gemm256_tn_splitk_launch((const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, Na, Nb, (float*)workspace,
+                                                workspace_bytes / sizeof(float), colsum_a, (hipStream_t)stream);
+    if (splits <= 0) return set_error(CLIBD_EINVAL, "gemm_tn_splitk: shape not supported (need M % 128 == 0, M >= 256, Na % 256 == 0, Nb % 256 == 0, workspace)");
+    if (int e = check_launch("gemm256_tn")) return e;
+    const size_t n4 = (size_t)Na * Nb / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits, n4,
+                       out_f32, accumulate);
+    return check_launch("reduce_splits");
+}
+
 static int transpose_impl(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum, void* stream) {
     if (!in || !out || R <= 0 || C <= 0 || ld_in < C || ld_out < R) return set_error(CLIBD_EINVAL, "transpose: bad args");
     dim3 grid((C + 63) / 64, (ld_out + 63) / 64);

@@ -306,4 +306,9 @@ bool gemm256_fp8_launch(const GemmParams& p, hipStream_t stream);
 // split-K with a partials workspace; returns the number of splits (0: shape not taken)
 int gemm256_splitk_launch(const GemmParams& p, float* partials, size_t partials_elems, hipStream_t stream);
 
+// rows-contracting ("TN") split-M GEMM, gemm256_tn.hip: partials[s] (fp32 [Na, Nb]) = A[slice s, :Na]^T · B[slice s, :Nb];
+// returns the number of slices (0: shape not taken)
+int gemm256_tn_splitk_launch(const unsigned short* A, int lda, const unsigned short* B, int ldb, int M, int Na, int Nb, float* partials,
+                             size_t partials_elems, float* colsum, hipStream_t stream);
+
 }  // namespace clibd

@@ -484,7 +484,8 @@ class TransformerStack:
 
 def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], grads: dict):
     """Weight / bias gradients of y = x W^T + b for the parameters present in `grads` (accumulating):
-    dW [N,K] += dy^T x as the NT GEMM (dy^T [N,Mp]) (x^T [K,Mp])^T with the contraction over the (zero-padded) token rows,
+    dW [N,K] += dy^T x — read in place by the rows-contracting kernel when the shape allows (M % 128 == 0, N and K % 256 == 0:
+    every full-size layer), else as the NT GEMM (dy^T [N,Mp]) (x^T [K,Mp])^T over zero-padded transposes —
     db += column sums of dy.  `weights` may be the row-wise pieces of a fused projection (BERT query / key / value)."""
     if not any(id(w) in grads for w in weights) and not any(id(b) in grads for b in biases):
         return
@@ -493,7 +494,25 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
     M = dy_bf16.shape[0]
     want_b = [b is not None and id(b) in grads for b in biases]
     bias_done = False
-    if any(id(w) in grads for w in weights):
+    K = x_bf16.shape[1]
+    tn_ok = (M % 128 == 0 and M >= 256 and K % 256 == 0 and dy_bf16.stride(0) % 8 == 0 and x_bf16.stride(0) % 8 == 0
+             and all(w.shape[0] % 256 == 0 for w in weights))
+    if tn_ok and any(id(w) in grads for w in weights):
+        # in-place rows-contracting GEMM (gemm256_tn.hip): no dy^T / x^T; the bias gradient (column sums of dy) rides along
+        n0 = 0
+        done = []
+        for w, b, wb in zip(weights, biases, want_b):
+            n1 = n0 + w.shape[0]
+            if id(w) in grads:
+                cs = grads[id(b)].view(-1) if wb else None
+                if not ops.gemm_tn_splitk(dy_bf16[:, n0:n1], x_bf16, grads[id(w)].view(w.shape[0], -1), accumulate=True, colsum=cs):
+                    raise RuntimeError("gemm_tn_splitk refused a shape its guard accepted")
+                done.append(wb)
+            else:
+                done.append(False)
+            n0 = n1
+        want_b = [wb and not d for wb, d in zip(want_b, done)]   # biases whose weight is frozen still take the column-sum kernel
+    elif any(id(w) in grads for w in weights):
         N = dy_bf16.shape[1]
         csum, direct = None, False
         if any(want_b) and N % 8 == 0 and dy_bf16.stride(0) % 8 == 0:
@@ -527,9 +546,9 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
             bias_done = True
     if not bias_done:
         n0 = 0
-        for w, b in zip(weights, biases):
+        for w, b, wb in zip(weights, biases, want_b):
             n1 = n0 + w.shape[0]
-            if b is not None and id(b) in grads:
+            if wb:
                 ops.colsum_bf16(dy_bf16[:, n0:n1], grads[id(b)])
             n0 = n1
 

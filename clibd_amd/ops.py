@@ -642,6 +642,33 @@ def dropout_apply(x: torch.Tensor, drop: Drop) -> torch.Tensor:
 _splitk_ws = {}
 
 
+def gemm_tn_splitk(a: torch.Tensor, b: torch.Tensor, out_f32: torch.Tensor, accumulate: bool = True, colsum: Optional[torch.Tensor] = None) -> bool:
+    """out[Na,Nb] (+)= a[M,Na]^T @ b[M,Nb], both operands read in place (clibd_gemm_bf16_tn_splitk): the weight gradient
+    dW = dy^T x without transposes; colsum (fp32 [Na]) += column sums of a in the same pass (the bias gradient).
+    Returns False (nothing launched) when the shape is outside the kernel's."""
+    _chk(a, BF16, "a", contiguous=False); _chk(b, BF16, "b", contiguous=False); _chk(out_f32, F32, "out_f32")
+    M, Na = a.shape
+    Nb = b.shape[1]
+    if b.shape[0] != M or tuple(out_f32.shape) != (Na, Nb):
+        raise ValueError("gemm_tn_splitk: shape mismatch")
+    if M % 128 or M < 256 or Na % 256 or Nb % 256:
+        return False
+    lib = _lib.load()
+    need = lib.clibd_gemm_splitk_workspace_bytes(Na, Nb)
+    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream)
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(((need + 3) // 4,), dtype=F32, device=a.device)   # one workspace per (device, stream), shared with the NT mode
+        _splitk_ws[key] = ws
+    if colsum is not None:
+        _chk(colsum, F32, "colsum")
+        if colsum.numel() != Na:
+            raise ValueError("gemm_tn_splitk: colsum must have Na elements")
+    check(lib.clibd_gemm_bf16_tn_splitk(a.data_ptr(), _rowmajor(a, "a"), b.data_ptr(), _rowmajor(b, "b"), M, Na, Nb, out_f32.data_ptr(), Nb,
+                                        int(accumulate), _p(colsum), ws.data_ptr(), ws.numel() * 4, _stream()), "gemm_bf16_tn_splitk")
+    return True
+
+
 def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, out_f32: torch.Tensor, accumulate: bool = True) -> bool:
     """out (+)= a @ w.T for a long contraction and few output tiles (weight gradients), through the split-K workspace path
     of the 256x256 kernel.  Returns False (nothing launched) when the shape is outside that path — use gemm_nt(split_k=)."""

@@ -281,6 +281,13 @@ size_t clibd_gemm_splitk_workspace_bytes(int M, int N);
 int clibd_gemm_bf16_nt_splitk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, float* out_f32, int ld_out,
                               int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same product with both operands read in place: out[Na,Nb] (+)= A[M,Na]^T · B[M,Nb] (bf16, contraction over the token
+ * rows through transposing LDS reads; the weight gradient dW = dY^T X without materialising dY^T and X^T).
+ * colsum_a (optional, fp32 [Na], accumulates atomically): column sums of A in the same pass (the bias gradient db = dY^T 1).
+ * M % 128 == 0, M >= 256, Na % 256 == 0, Nb % 256 == 0, lda / ldb % 8 == 0; workspace >= clibd_gemm_splitk_workspace_bytes(Na, Nb). */
+int clibd_gemm_bf16_tn_splitk(const void* A, int lda, const void* B, int ldb, int M, int Na, int Nb, float* out_f32, int ld_out,
+                              int accumulate, float* colsum_a, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- full fine-tune mode (model_config.disable_lora): parameter gradients that are not GEMM-shaped.
  * Every output ACCUMULATES (atomicAdd) into fp32 buffers the caller zeroes once per step.
  * Replaces the autograd of nn.LayerNorm (timm Block.norm1/2, VisionTransformer.norm; HF Bert*LayerNorm), of nn.Embedding

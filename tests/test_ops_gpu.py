@@ -711,6 +711,32 @@ def test_gemm_splitk_workspace_exact(ops, dev, M, N, K):
     assert not ops.gemm_nt_splitk(ad[:, :448], wd[:, :448], out2)   # K < 512: caller falls back to gemm_nt(split_k=)
 
 
+@pytest.mark.parametrize("M,Na,Nb,ld_extra", [(50432, 768, 768, 0), (34048, 3072, 768, 0), (256, 256, 256, 0), (4096 + 128, 768, 2304, 8),
+                                              (640, 512, 256, 0), (50432, 2304, 768, 0)])
+def test_gemm_tn_splitk_exact(ops, dev, M, Na, Nb, ld_extra):
+    """Rows-contracting GEMM (weight gradient without transposes): out[Na,Nb] (+)= a[M,Na]^T b[M,Nb] — exact small-integer
+    products (every k-slot of every fragment matters: position-dependent values), accumulate semantics, operands that are
+    column slices of wider buffers, bit-identical across repeats."""
+    g = torch.Generator().manual_seed(M + Na + Nb)
+    a = torch.randint(-2, 3, (M, Na + ld_extra), generator=g).float()
+    b = torch.randint(-2, 3, (M, Nb + ld_extra), generator=g).float()
+    ad, bd = a.to(dev, BF16)[:, :Na], b.to(dev, BF16)[:, ld_extra:]
+    ref = (a[:, :Na].double().T @ b[:, ld_extra:].double()).float()   # |sums| <= 4 M < 2^24: exact in fp32 in any order
+    out = torch.full((Na, Nb), 3.0, device=dev)
+    assert ops.gemm_tn_splitk(ad, bd, out, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref + 3.0)
+    out2 = torch.empty((Na, Nb), device=dev)
+    assert ops.gemm_tn_splitk(ad, bd, out2, accumulate=False)
+    assert torch.equal(out2.cpu(), ref)
+    out3 = torch.empty((Na, Nb), device=dev)
+    cs = torch.full((Na,), 2.0, device=dev)
+    assert ops.gemm_tn_splitk(ad, bd, out3, accumulate=False, colsum=cs) and torch.equal(out3, out2)
+    assert torch.equal(cs.cpu(), a[:, :Na].sum(0) + 2.0)               # column sums of a (bias gradient), exact on integers
+    assert not ops.gemm_tn_splitk(ad[:192], bd[:192], out2)             # M % 128 != 0: the caller takes the transposing path
+    assert not ops.gemm_tn_splitk(ad[:, :128], bd, out2[:128])          # Na % 256 != 0
+
+
 # ----------------------------------------------------------------------------------------------- round 2: full fine-tune fusions
 @pytest.mark.parametrize("R,C,ld_extra", [(300, 256, 0), (50432, 768, 0), (133 * 7 + 3, 3072, 8), (64, 64, 0), (1000, 72, 16)])
 def test_transpose_with_column_sums(ops, dev, R, C, ld_extra):
