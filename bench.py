@@ -208,12 +208,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # CLIBD_BENCH_SHARED_GPU=1 (debugging only): run the N-rank code path on a box with fewer GPUs than ranks — ranks share
+    # devices and gloo moves the device tensors (RCCL refuses two ranks per device).  The line it prints is marked invalid.
+    shared_gpu = os.environ.get("CLIBD_BENCH_SHARED_GPU") == "1" and torch.cuda.device_count() < world
+    if shared_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from clibd_amd.data import synthetic_batch
     from clibd_amd.model import (CLIBDDNAEncoder, CLIBDImageEncoder, CLIBDLanguageEncoder, SimpleCLIP, create_vit,
@@ -390,6 +398,8 @@ def main():
                        "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW"},
             "loss": loss_val, "roofline": roof,
         }
+        if shared_gpu:
+            out["invalid"] = "CLIBD_BENCH_SHARED_GPU: ranks shared a GPU over gloo (code-path check, not a measurement)"
         if h2d is not None:
             out["h2d_inclusive"] = h2d
         if world == 1 and not args.no_cpu_baseline:

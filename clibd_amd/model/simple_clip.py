@@ -123,6 +123,12 @@ class SimpleCLIP(nn.Module):
                 self(*calibration_inputs)
             self.join_streams()
             amax = [st.calibrate(False) for st in stacks]
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                # data-parallel replicas must quantise alike: take the maximum over the ranks' calibration batches
+                flat = torch.tensor([v for am in amax for d in am for k, v in sorted(d.items())], dtype=torch.float32, device=self.logit_scale.device)
+                torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.MAX)
+                it = iter(flat.tolist())
+                amax = [[{k: next(it) for k, _ in sorted(d.items())} for d in am] for am in amax]
         for st, am in zip(stacks, amax):
             st.enable_fp8(scales, amax=am if am else None, margin=margin)
         return self
