@@ -69,12 +69,16 @@ def _backward_order(model, params):
 class Trainer:
     def __init__(self, model, lr: float = 1e-3, world_size: int = 1, rank: int = 0, all_gather: bool = True,
                  fix_temperature: Optional[float] = None, bind_to=None, no_image_text_loss=False, weight_decay: float = 1e-2,
-                 broadcast_parameters: bool = True, bucket_bytes: int = 64 << 20):
+                 broadcast_parameters: bool = True, bucket_bytes: int = 64 << 20, fp8_recalibrate_every: int = 0):
         """bucket_bytes: at world_size > 1, when the gradients are at least two buckets long (full fine-tune: 694 MB), the
         all-reduce is issued in pieces of about this size as the backward completes them, each on the stream that produced
-        it, so RCCL runs under the rest of the backward; smaller gradient sets (LoRA: 6 MB) keep the single all-reduce."""
+        it, so RCCL runs under the rest of the backward; smaller gradient sets (LoRA: 6 MB) keep the single all-reduce.
+        fp8_recalibrate_every = N > 0: fp8-forward mode (SimpleCLIP.enable_fp8_forward) re-measures its per-layer activation
+        scales on the incoming batch before steps 0, N, 2N, ... (one extra bf16 forward each time), so the static scales of
+        a long run follow the activations as the adapters train."""
         self.model, self.world_size, self.rank = model, world_size, rank
         self.fix_temperature = fix_temperature
+        self.fp8_recalibrate_every, self._steps_done = int(fp8_recalibrate_every), 0
         ordered, counts = _backward_order(model, _gradient_reachable(model, fix_temperature))
         self.optimizer = FusedAdamW(ordered, lr=lr, weight_decay=weight_decay)
         self._plan_buckets(counts, bucket_bytes)
@@ -140,6 +144,9 @@ class Trainer:
         """forward (all towers) -> loss -> backward -> gradient all-reduce -> AdamW.  Returns the (device) loss.
         Collectives per step at world_size > 1: one packed all-gather (embeddings + labels), one reduce-scatter (feature
         gradients), one all-reduce (flat gradient bucket + the loss value)."""
+        if self.fp8_recalibrate_every > 0 and self._steps_done % self.fp8_recalibrate_every == 0:
+            self.model.enable_fp8_forward(calibration_inputs=(image, dna, text))
+        self._steps_done += 1
         self.optimizer.zero_grad()
         image_out, dna_out, text_out, logit_scale, _ = self.model(image, dna, text)
         if self.fix_temperature is not None:

@@ -221,6 +221,8 @@ def test_fp8_training_steps_reduce_loss(dev):
     model.enable_fp8_forward()
     B = 32
     batch = synthetic_batch(B, dev, seed=3, rank=0, with_text=False)
-    tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True)
+    tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True, fp8_recalibrate_every=3)   # scales re-measured before steps 0 and 3
     losses = [float(tr.step(batch["image"], batch["dna"], None, batch["labels"])) for _ in range(6)]
     assert all(l == l and l < 1e4 for l in losses) and losses[-1] < losses[0]
+    st = model.dna_encoder.tower().stack
+    assert st.fp8 is not None and len(st.fp8) == 12 and all(v > 0 for d in st.fp8 for v in d.values())
