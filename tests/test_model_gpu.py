@@ -509,6 +509,51 @@ def test_image_tower_full_finetune_gradients(dev):
     assert_grads(got, go, rel_tol=3e-2, cos_tol=0.999, what="image full fine-tune", zero_tol=2e-6, zero_rel=1e-4)
 
 
+def test_full_finetune_gradients_through_the_tn_kernel(dev):
+    """Token counts that are multiples of 128 with widths that are multiples of 256 take the rows-contracting weight-gradient
+    kernel (gemm256_tn.hip: dy and x read in place, bias gradient from the all-ones MFMA) instead of the transposing path the
+    tiny fixtures exercise: a 2-block ViT (width 256, 4 heads, batch 128 -> 25 216 token rows) against the oracle, every
+    parameter."""
+    from oracle import clibd_oracle as O
+    from clibd_amd import ops
+    from clibd_amd.model import CLIBDImageEncoder, VisionTransformer
+
+    torch.manual_seed(9)
+    om = O.ImageEncoder(O.VisionTransformer(img_size=224, patch=16, dim=256, depth=2, heads=4, num_classes=0), 4, 256)
+    with torch.no_grad():
+        for n, p in om.named_parameters():
+            if "linear_b_" in n:
+                p.normal_(0, 0.02)
+    m = CLIBDImageEncoder(VisionTransformer(embed_dim=256, depth=2, num_heads=4, num_classes=0), r=4, num_classes=256)
+    m.load_state_dict(om.state_dict(), strict=True)
+    m = m.to(dev).eval()
+    calls = []
+    inner = ops.gemm_tn_splitk
+
+    def spy(a, b, out, accumulate=True, colsum=None):
+        ok = inner(a, b, out, accumulate=accumulate, colsum=colsum)
+        calls.append((tuple(a.shape), tuple(b.shape), colsum is not None, ok))
+        return ok
+
+    ops.gemm_tn_splitk = spy
+    try:
+        g = torch.Generator().manual_seed(10)
+        img = torch.rand(128, 3, 224, 224, generator=g)
+        cot = torch.randn(128, 256, generator=g)
+        y, yo, got, go = _full_grads(m, om, lambda mm: mm(img.to(dev)), lambda oo: oo(img), cot, dev, O.precision("bf16"))
+    finally:
+        ops.gemm_tn_splitk = inner
+    big = [c for c in calls if c[0][0] == 128 * 197]
+    assert len(big) == 5 and all(c[3] for c in calls) and all(c[2] for c in big)     # qkv, proj, fc1, fc2 of block 0 + qkv of the class-row-only block 1, each with its bias
+    assert rel(y.cpu(), yo.detach()) < 4e-3
+    # 4e-2: the q adapter of the class-row-only block sees 128 query rows (its gradient is small and bf16-noisy: 3.2e-2 here)
+    assert_grads(got, go, rel_tol=4e-2, cos_tol=0.999, what="image full fine-tune (TN weight gradients)", zero_tol=2e-6, zero_rel=1e-4)
+    base = [n for n in got if ".attn.qkv.qkv.weight" in n or ".mlp.fc" in n or ".attn.proj." in n or "patch_embed" in n]
+    assert len(base) >= 14
+    for n in base:                                   # the matrices the TN kernel produced (and their biases): well inside the gate
+        assert rel(got[n], go[n]) < 1.5e-2, (n, rel(got[n], go[n]))
+
+
 def test_full_finetune_training_step_updates_base_weights(dev):
     """One fused-optimizer step in full fine-tune mode: base weights move, the next forward sees the new weights (the bf16
     weight images are rebuilt every step because the in-place optimizer does not bump tensor versions)."""
