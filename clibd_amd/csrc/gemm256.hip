@@ -330,12 +330,71 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         PHASE(4, false, 2); PHASE(5, false, 0); PHASE(6, false, 0); PHASE(7, false, 0);
         if (wm == 0) BARRIER();  // group 0 matches group 1's extra barrier; every LDS read of this tile is complete
         STAMP(4);
-        if (has_next) PROLOGUE_ISSUE();  // next tile's first eight half-tiles fly while this tile's epilogue runs
-
         // lane coordinates made opaque per tile: everything the epilogue derives from them (16 row offsets x several
         // leading dimensions) is rebuilt here instead of being hoisted out of the persistent loop into spilled registers
         int erow = frow, egrp = fch;
         asm volatile("" : "+v"(erow), "+v"(egrp));
+        int nb = n0 + 128 * wm + 8 * erow;  // < N: N % 256 == 0 (host-checked)
+        int mb = m0 + 64 * wn + 4 * egrp;
+        // ---- Epilogue operands are requested BEFORE the next tile's prologue and awaited with an exact count after it.
+        // vmcnt retires in issue order: a compiler-generated wait for a load issued after the 16 prologue LDS-DMA loads
+        // waits for all of those to land first, and (worse) a wait inside each guarded row block — where hipcc put the
+        // first use of the bias — is a vmcnt(0) that also waits for the previous row's store: one store in flight per
+        // wave, 16 (fc1: 32) serial write round trips per tile.  The bias is therefore an inline-asm load (invisible to the
+        // waitcnt pass), and the first row group of the two-pass kinds is loaded up here as well.
+        constexpr bool TWO_PASS = (KIND == EPI_MUL_AUX || KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP);
+        constexpr bool PRELOAD_ROWS = TWO_PASS && !LORA && !FP8;  // (the LoRA / fp8 instantiations have no room for a row group)
+        f32x4 bias_q[2];
+        uint4 in_aux[8];
+        f32x4 in_res[8][2];
+#define GLOAD128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off ; EPI_OPERAND_LOAD" : "=&v"(dst) : "v"(ptr) : "memory")
+        constexpr bool BIAS_ASM = BIAS && !FP8;  // (the fp8 instantiations spill with 8 more registers live across the dequantisation)
+        if constexpr (BIAS_ASM) {
+            const float* bp = ep.bias + nb;
+            GLOAD128(bias_q[0], bp);
+            GLOAD128(bias_q[1], bp + 4);
+        }
+        if constexpr (PRELOAD_ROWS) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mc = min(mb + 16 * n + r, p.M - 1);
+                    if constexpr (KIND == EPI_MUL_AUX) {
+                        in_aux[4 * n + r] = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
+                    } else {
+                        const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)mc * ep.ld_res + nb);
+                        in_res[4 * n + r][0] = rs[0];
+                        in_res[4 * n + r][1] = rs[1];
+                    }
+                }
+        }
+        if (has_next) PROLOGUE_ISSUE();  // next tile's first eight half-tiles fly while this tile's epilogue runs
+        // (rebuilt, so that only the requested operands — not the coordinates — are live across the prologue issue)
+        erow = frow; egrp = fch;
+        asm volatile("" : "+v"(erow), "+v"(egrp));
+        nb = n0 + 128 * wm + 8 * erow;
+        mb = m0 + 64 * wn + 4 * egrp;
+        // queue now: [bias / LoRA asm loads] [first row group: 8 (aux) or 16 (residual) loads] [16 LDS-DMA loads if has_next]
+#define EPI_TIED_WAIT(N)                                                                                             \
+    do {                                                                                                             \
+        if constexpr (BIAS_ASM) asm volatile("s_waitcnt vmcnt(" #N ") ; EPI_OPERAND_WAIT" : "+v"(bias_q[0]), "+v"(bias_q[1])); \
+    } while (0)
+        // ONE tied wait statement on every path (two of them, one per branch, make hipcc merge their results through copies it
+        // places BEFORE the wait: stale bias).  Without a next tile there is no LDS-DMA behind the operands: an untied wait for
+        // the operands themselves comes first and the tied one is then a no-op that only carries the data dependence.
+        if constexpr (PRELOAD_ROWS && KIND == EPI_MUL_AUX) {
+            if (!has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            EPI_TIED_WAIT(24);
+        } else if constexpr (PRELOAD_ROWS) {
+            if (!has_next) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            EPI_TIED_WAIT(32);
+        } else {
+            if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            EPI_TIED_WAIT(16);
+        }
+#undef EPI_TIED_WAIT
+#undef GLOAD128
         // ---- FP8: dequantise in place, before the (bf16, unscaled) rank update: acc[.., column e] *= col_scale[nb + e]
         if constexpr (FP8) {
             const float* csp = p.col_scale + n0 + 128 * wm + 8 * erow;
@@ -352,6 +411,8 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         // ---- LoRA rank-8 update: one extra zero-padded k-step (lanes with k-chunk 0 carry U[m,0:8] / V[n,0:8])
         // (compile-time flag: a run-time test here puts all 128 accumulators behind a phi the register allocator
         //  cannot coalesce -> 26 spilled VGPRs and vmcnt(0) drains around their reloads)
+        // The operand loads sit behind the prologue LDS-DMA in the in-order queue (their wait also waits for those to land):
+        // requesting them ahead of it, as the bias is, costs 48 live registers that the LoRA instantiations do not have.
         if (LORA) {
             bf16x8 uf[2][2];  // Q side (output rows): [hn][n]
 #pragma unroll
@@ -370,7 +431,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                 for (int t = 0; t < 4; ++t) {
                     bf16x8 vf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};  // P side (output columns)
                     if (egrp == 0) {
-                        const int gn = n0 + 128 * wm + 8 * erow + 4 * hm + t;
+                        const int gn = nb + 4 * hm + t;
                         vf = *(const bf16x8*)((const unsigned short*)ep.rank_v + (size_t)gn * 8);
                     }
 #pragma unroll
@@ -382,18 +443,33 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
 
         // ---- epilogue: lane (c = frow, g = fch) owns rows m0 + 64wn + 32hn + 16n + 4g + r, columns nb .. nb+7 (e = 4hm + t)
         {
-            const int nb = n0 + 128 * wm + 8 * erow;  // < N: N % 256 == 0 (host-checked)
-            const int mb = m0 + 64 * wn + 4 * egrp;
             float bias[8];
-            if (BIAS) load_bias8(ep, nb, bias);  // compile-time: without a bias the 128 adds (and the moves pairing them) vanish
+            if constexpr (BIAS_ASM) {  // compile-time: without a bias the 128 adds (and the moves pairing them) vanish
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bias[e] = bias_q[0][e]; bias[4 + e] = bias_q[1][e]; }
+            } else if constexpr (BIAS) {
+                load_bias8(ep, nb, bias);
+                // one wait HERE (it also waits for the prologue loads to land), not one vmcnt(0) in every guarded row block
+                if constexpr (!TWO_PASS) {  // (the two-pass kinds use the bias in their load-only pass: no store waits behind it)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bias[e]));
+                }
+            }
 #define EPV(hm, t) (BIAS ? acc[hm][t][hn][n][r] + bias[4 * (hm) + (t)] : acc[hm][t][hn][n][r])
-#define FOR_ROWS(...)                                                                                        \
-    _Pragma("unroll") for (int hn = 0; hn < 2; ++hn)                                                         \
+#define FOR_ROWS_HN(HN0, HN1, ...)                                                                           \
+    _Pragma("unroll") for (int hn = (HN0); hn < (HN1); ++hn)                                                 \
         _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                        \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                  \
                 const int m = mb + 32 * hn + 16 * n + r;                                                     \
                 __VA_ARGS__                                                                                  \
             }
+#define FOR_ROWS(...) FOR_ROWS_HN(0, 2, __VA_ARGS__)
+            // pin the folded values of row group hn: left alone, LLVM sinks the adds / multiplies into pass 2's row predicates
+            // and keeps every loaded vector alive instead
+#define PIN_GROUP(hn_)                                                                                       \
+    _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)                                                         \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                        \
+            _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) asm volatile("" : "+v"(acc[hm][t][hn_][n2]))
             if (KIND == EPI_SPLITK_F32) {
                 float* outp = ep.out_f32 + (size_t)split_cur * (size_t)p.split_stride;
                 FOR_ROWS({
@@ -403,12 +479,24 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                         o[1] = (f32x4){acc[1][0][hn][n][r], acc[1][1][hn][n][r], acc[1][2][hn][n][r], acc[1][3][hn][n][r]};
                     }
                 })
-            } else if (KIND == EPI_MUL_AUX || KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP) {
+            } else if (TWO_PASS) {
                 // Two passes so that no store sits between the epilogue's loads: vmcnt retires in order, and a load
                 // waited behind earlier stores would pay their HBM write latency once per row (16 serial round trips).
-                // Pass 1 folds bias / dropout / aux / residual into the accumulators in place (loads only, rows clamped),
-                // pass 2 only stores.
-                FOR_ROWS({
+                // Pass 1 folds bias / dropout / aux / residual into the accumulators in place (loads only, rows clamped):
+                // row group hn = 0 from the operands requested before the prologue, group hn = 1 loads its own (8 aux /
+                // 16 residual 16-B loads in flight); pass 2 only stores.
+                FOR_ROWS_HN(0, 1, {
+                    const int mc = min(m, p.M - 1);
+                    float v[8];
+                    _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = EPV(hm, t);
+                    if constexpr (PRELOAD_ROWS) fold_row8_in<KIND>(ep, mc, nb, v, in_aux[4 * n + r], in_res[4 * n + r][0], in_res[4 * n + r][1]);
+                    else fold_row8<KIND>(ep, mc, nb, v);
+                    _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[hm][t][hn][n][r] = v[4 * hm + t];
+                })
+                PIN_GROUP(0);
+                FOR_ROWS_HN(1, 2, {
                     const int mc = min(m, p.M - 1);
                     float v[8];
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
@@ -416,14 +504,8 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     fold_row8<KIND>(ep, mc, nb, v);
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
                         _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[hm][t][hn][n][r] = v[4 * hm + t];
-                    if (n == 1 && r == 3) {  // 8 rows (8 aux / 16 residual 16-B loads) in flight per group
-                        // pin the folded values here: left alone, LLVM sinks the adds / multiplies into pass 2's row
-                        // predicates and keeps all 32 loaded vectors (128 VGPRs) alive instead
-                        _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
-                            _Pragma("unroll") for (int t = 0; t < 4; ++t)
-                                _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) asm volatile("" : "+v"(acc[hm][t][hn][n2]));
-                    }
                 })
+                PIN_GROUP(1);
                 FOR_ROWS({
                     if (m < p.M) {
                         float v[8];
@@ -449,6 +531,8 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     }
                 })
             }
+#undef PIN_GROUP
+#undef FOR_ROWS_HN
 #undef FOR_ROWS
 #undef EPV
         }

@@ -270,12 +270,13 @@ __device__ __forceinline__ void store_row8_gelu_fp8(const clibd_gemm_epilogue& e
     *(uint2*)((unsigned char*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8fp8(v, out_scale);
 }
 
-// Pass 1 of the two-pass epilogues (gemm256): everything of store_row8<KIND> up to, not including, the stores.
+// Pass 1 of the two-pass epilogues (gemm256): everything of store_row8<KIND> up to, not including, the stores, on operands
+// the caller has already loaded (ax: 8 bf16 of aux for EPI_MUL_AUX; r0, r1: 8 fp32 of the residual otherwise).
 template <int KIND>
-__device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
+__device__ __forceinline__ void fold_row8_in(const clibd_gemm_epilogue& ep, int m, int nb, float v[8], const uint4& ax, const f32x4& r0,
+                                             const f32x4& r1) {
     if (KIND == EPI_MUL_AUX) {
-        const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
-        const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
+        const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[2 * e] *= bf2f((unsigned short)(xs[e] & 0xffffu));
@@ -292,11 +293,24 @@ __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, 
                 v[e + 1] *= f1;
             }
         }
-        const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
-        const f32x4 r0 = rs[0], r1 = rs[1];
         v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
         v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
     }
+}
+
+// the same with the loads
+template <int KIND>
+__device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
+    uint4 ax = make_uint4(0u, 0u, 0u, 0u);
+    f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;
+    if (KIND == EPI_MUL_AUX) {
+        ax = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+    } else {
+        const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
+        r0 = rs[0];
+        r1 = rs[1];
+    }
+    fold_row8_in<KIND>(ep, m, nb, v, ax, r0, r1);
 }
 
 // host side (gemm256.hip): returns true when the 256x256 kernel took the launch
