@@ -30,10 +30,10 @@ __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 +
 
 // stage rows [0,S_pad) x 64 bf16 of one head (global row stride `ld` elements) into an LDS tile
 __device__ __forceinline__ void stage_head_tile(char* lds_tile, const unsigned short* gbase, size_t ld, int S, int S_pad,
-                                                int wave, int lane) {
+                                                int wave, int lane, int nwaves = ATT_WAVES) {
     const int prow = lane >> 3;
     const int chunk = (lane & 7) ^ prow;
-    for (int p = wave; p < (S_pad >> 3); p += ATT_WAVES) {
+    for (int p = wave; p < (S_pad >> 3); p += nwaves) {
         const int row = min(p * 8 + prow, S - 1);
         glds16(gbase + (size_t)row * ld + chunk * 8, lds_tile + p * 1024);
     }
@@ -66,6 +66,26 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
 // across the 4 lane groups (lane>>4) at fixed lane&15: v_permlane swaps, not ds_bpermute (common.h)
 __device__ __forceinline__ float group4_sum(float v) { return rows4_sum(v); }
 __device__ __forceinline__ float group4_max(float v) { return rows4_max(v); }
+
+// One 16-row x 64-column output tile of a wave: lane (i = lane & 15, g = lane >> 4) holds v[dt][r] = element (row i, column
+// 16 dt + 4 g + r) — 8 bytes per (lane, dt).  Written that way (four dwordx2 per lane) a store instruction covers 32-byte pieces
+// and the output tail of the attention kernels is store-issue bound.  A v_permlane16_swap between the lane rows g and g ^ 1 (a
+// 2 x 2 transpose of the (dt, dt + 1) chunks) leaves every lane 16 contiguous bytes, and each of the TWO dwordx4 stores of a tile
+// then covers 64 contiguous bytes of all 16 rows.  Every lane must call this (the swap is a full-wave operation); `on` guards
+// the stores only (it is a function of the row, identical in the lanes that exchange).  Values, and so results, are unchanged.
+__device__ __forceinline__ void permlane16_swap_u32(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void store_rows16(unsigned short* row, const f32x4 (&v)[4], float mul, bool on, int g) {
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        unsigned a0 = pack2bf(v[2 * pr][0] * mul, v[2 * pr][1] * mul), a1 = pack2bf(v[2 * pr][2] * mul, v[2 * pr][3] * mul);
+        unsigned b0 = pack2bf(v[2 * pr + 1][0] * mul, v[2 * pr + 1][1] * mul), b1 = pack2bf(v[2 * pr + 1][2] * mul, v[2 * pr + 1][3] * mul);
+        permlane16_swap_u32(a0, b0);   // even g: (a, b) = columns 4g .. 4g+7 of tile dt = 2 pr;  odd g: columns 4(g-1) .. 4(g-1)+7 of dt = 2 pr + 1
+        permlane16_swap_u32(a1, b1);
+        if (on) *(uint4*)(row + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1)) = make_uint4(a0, a1, b0, b1);
+    }
+}
 
 constexpr float NEG_BIG = -1.0e30f;
 
@@ -214,24 +234,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int q = (2 * p + t) * 16 + i;
-                if (q < nq) {
-                    const size_t oidx = ((size_t)b * out_seq + q) * H + h * DH;
-                    if (out_fp8_scale > 0.f) {
+                const size_t oidx = ((size_t)b * out_seq + min(q, nq - 1)) * H + h * DH;
+                if (out_fp8_scale > 0.f) {
+                    if (q < nq) {
                         unsigned char* orow8 = (unsigned char*)out + oidx;
                         const float sc8 = inv[t] * out_fp8_scale;
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt)
                             *(unsigned*)(orow8 + 16 * dt + 4 * g) = pack4fp8(o[t][dt][0] * sc8, o[t][dt][1] * sc8, o[t][dt][2] * sc8, o[t][dt][3] * sc8);
-                    } else {
-                        unsigned short* orow = out + oidx;
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) {
-                            uint2 pk;
-                            pk.x = pack2bf(o[t][dt][0] * inv[t], o[t][dt][1] * inv[t]);
-                            pk.y = pack2bf(o[t][dt][2] * inv[t], o[t][dt][3] * inv[t]);
-                            *(uint2*)(orow + 16 * dt + 4 * g) = pk;
-                        }
                     }
+                } else {
+                    store_rows16(out + oidx, o[t], inv[t], q < nq, g);
                 }
             }
         }
@@ -304,25 +317,171 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
             for (int dt = 0; dt < 4; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(vt_lds, s, dt, lane), pf, o[dt], 0, 0, 0);
         }
-        if (q < nq) {
-            const size_t oidx = ((size_t)b * out_seq + q) * H + h * DH;
+        {
+            const size_t oidx = ((size_t)b * out_seq + min(q, nq - 1)) * H + h * DH;
             if (out_fp8_scale > 0.f) {
-                unsigned char* orow8 = (unsigned char*)out + oidx;
-                const float sc8 = inv * out_fp8_scale;
+                if (q < nq) {
+                    unsigned char* orow8 = (unsigned char*)out + oidx;
+                    const float sc8 = inv * out_fp8_scale;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        *(unsigned*)(orow8 + 16 * dt + 4 * g) = pack4fp8(o[dt][0] * sc8, o[dt][1] * sc8, o[dt][2] * sc8, o[dt][3] * sc8);
+                }
+            } else {
+                store_rows16(out + oidx, o, inv, q < nq, g);
+            }
+        }
+    }
+}
+
+// ============================================ forward, persistent =================================================
+// Long sequences (S > 144: ViT 197, and anything up to 256).  The per-head kernel above spends 39 of its 88 us (ViT, b = 256) waiting
+// for its K / V tiles: the two workgroups of a CU are launched together and last equally long, so they stage together and
+// compute together (tools/exp_attn_parts.py: the time against the number of query tiles evaluated is a 39-us floor plus the
+// compute, not their maximum).  Here ONE workgroup of 16 waves per CU walks heads blockIdx.x, + gridDim.x, ...: the K / V image
+// is double-buffered (2 x 2 x S_pad x 128 B <= 112 KiB), the LDS-DMA of the NEXT head is issued before the current head's
+// query tiles are evaluated, and one barrier per head hands the buffers over.  A head has at most 16 query tiles: wave w takes
+// tile (w + 3 i) mod 16 of the workgroup's i-th head (the idle slots of a 13-tile head rotate over the SIMDs), one 16-query tile
+// per wave — four waves per SIMD (<= 128 VGPRs) hide each other's LDS and MFMA latencies, so the two-tile sweep of the kernel
+// above is not needed (the LDS array is 8 % busy in that kernel: SQ_LDS_IDX_ACTIVE).  Arithmetic per element, and therefore
+// every result bit, is that of the per-head kernel.
+constexpr int ATTP_WAVES = 16;
+template <int NKT, bool MASK, bool DROP>
+__global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kernel(const unsigned short* __restrict__ qkv, int S, int nheads,
+                                                                               int total_heads, const int* __restrict__ key_mask,
+                                                                               unsigned short* __restrict__ out, float scale, int nq,
+                                                                               int out_seq, unsigned drop_seed, int drop_thr16,
+                                                                               float drop_scale, float out_fp8_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int S_pad = 16 * NKT;
+    constexpr int BUF = 2 * S_pad * 128;   // K then V of one head
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = nheads * DH;
+    const size_t ld = (size_t)3 * H;
+    const int g = lane >> 4, i = lane & 15;
+    const int nqt = (nq + 15) >> 4;
+    const float c2 = scale * 1.4426950408889634f;
+    const bool last_live = S > 16 * (NKT - 1);
+
+    auto head_base = [&](int head) { return qkv + (size_t)(head / nheads) * S * ld + (size_t)(head % nheads) * DH; };
+    auto stage = [&](int head, char* buf) {
+        const unsigned short* qb = head_base(head);
+        stage_head_tile(buf, qb + H, ld, S, S_pad, wave, lane, ATTP_WAVES);
+        stage_head_tile(buf + S_pad * 128, qb + 2 * H, ld, S, S_pad, wave, lane, ATTP_WAVES);
+    };
+
+    int head = blockIdx.x;
+    if (head >= total_heads) return;
+    stage(head, smem);
+    // Query fragments are requested one head ahead, BEFORE the current head's output stores: vmcnt retires in issue order, so the
+    // wait at the top of a head (this wave's LDS-DMA pieces and query fragments) can then leave the four stores in flight.
+    auto load_q = [&](int hd, int it_, bf16x8 (&qf_)[2]) {
+        const int qt_ = (wave + 3 * it_) & 15;
+        if (qt_ < nqt) {
+            const unsigned short* qb = head_base(hd);
+            const int qc = min(qt_ * 16 + i, S - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf_[ks] = *(const bf16x8*)(qb + (size_t)qc * ld + 32 * ks + 8 * g);
+        }
+    };
+    bf16x8 qf[2] = {}, qn[2] = {};
+    load_q(head, 0, qf);
+    bool stored = false;   // wave-uniform: this wave issued its four output stores in the previous head
+    for (int it = 0; head < total_heads; ++it, head += gridDim.x) {
+        char* kt_lds = smem + (it & 1) * BUF;
+        char* vt_lds = kt_lds + S_pad * 128;
+        const int b = head / nheads, h = head - b * nheads;
+        const int qt = (wave + 3 * it) & 15;
+        const bool mine = qt < nqt;
+        const int q = qt * 16 + i;
+        // this head's image: issued one head ago (or just above); the wave's own pieces are awaited, the barrier publishes the rest
+        if (stored) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int next = head + (int)gridDim.x;
+        if (next < total_heads) {
+            stage(next, smem + ((it + 1) & 1) * BUF);  // flies under this head's arithmetic
+            load_q(next, it + 1, qn);
+        }
+        stored = mine;
+        if (mine) {
+            f32x4 sc[NKT];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                sc[kt] = (f32x4){0, 0, 0, 0};
+                if (kt == NKT - 1 && !last_live) continue;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(kt_lds, kt * 16 + i, ks, g), qf[ks], sc[kt], 0, 0, 0);
+            }
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kt == NKT - 1 && !last_live) continue;
+                if (MASK || (kt >= NKT - 2 && kt * 16 + 15 >= S)) {  // only tiles that can hold masked keys pay for the test
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + 4 * g + r;
+                        bool ok = key < S;
+                        if (MASK) ok = ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
+                        if (!ok) sc[kt][r] = NEG_BIG;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+            }
+            mx = group4_max(mx);
+            const float mc = mx * c2;
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kt == NKT - 1 && !last_live) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c2, -mc));  // masked scores underflow to exactly 0
+                    sc[kt][r] = e;
+                    sum += e;
+                }
+            }
+            sum = group4_sum(sum);
+            const float inv = 1.0f / sum;
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NKT / 2; ++s) {
+                if (DROP) {  // dropout on the probabilities (HF BertSelfAttention.dropout); index ((b*nh+h)*S+q)*256+key
+                    const unsigned base = (((unsigned)head * (unsigned)S + (unsigned)q) << 8) + 32u * s + 4u * g;
+                    float f0, f1, f2, f3;
+                    drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
+                    drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
+                    sc[2 * s][0] *= f0; sc[2 * s][1] *= f1; sc[2 * s][2] *= f2; sc[2 * s][3] *= f3;
+                    drop_pair(drop_seed, base + 16, (unsigned)drop_thr16, drop_scale, f0, f1);
+                    drop_pair(drop_seed, base + 18, (unsigned)drop_thr16, drop_scale, f2, f3);
+                    sc[2 * s + 1][0] *= f0; sc[2 * s + 1][1] *= f1; sc[2 * s + 1][2] *= f2; sc[2 * s + 1][3] *= f3;
+                }
+                const bf16x8 pf = pack_frag(sc[2 * s], sc[2 * s + 1]);  // un-normalised probabilities (<= 1/(1-p)); 1/sum is applied to O
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    *(unsigned*)(orow8 + 16 * dt + 4 * g) = pack4fp8(o[dt][0] * sc8, o[dt][1] * sc8, o[dt][2] * sc8, o[dt][3] * sc8);
-            } else {
-                unsigned short* orow = out + oidx;
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(vt_lds, s, dt, lane), pf, o[dt], 0, 0, 0);
+            }
+            {
+                const size_t oidx = ((size_t)b * out_seq + min(q, nq - 1)) * H + h * DH;
+                if (out_fp8_scale > 0.f) {
+                    if (q < nq) {
+                        unsigned char* orow8 = (unsigned char*)out + oidx;
+                        const float sc8 = inv * out_fp8_scale;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    uint2 pk;
-                    pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
-                    pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-                    *(uint2*)(orow + 16 * dt + 4 * g) = pk;
+                        for (int dt = 0; dt < 4; ++dt)
+                            *(unsigned*)(orow8 + 16 * dt + 4 * g) = pack4fp8(o[dt][0] * sc8, o[dt][1] * sc8, o[dt][2] * sc8, o[dt][3] * sc8);
+                    }
+                } else {
+                    store_rows16(out + oidx, o, inv, q < nq, g);
                 }
             }
         }
+        qf[0] = qn[0]; qf[1] = qn[1];
     }
 }
 
@@ -477,16 +636,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] *= sinv;
-        if (q < S) {
-            unsigned short* orow = dqbase + (size_t)q * ld;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 pk;
-                pk.x = pack2bf(dq[dt][0], dq[dt][1]);
-                pk.y = pack2bf(dq[dt][2], dq[dt][3]);
-                *(uint2*)(orow + 16 * dt + 4 * g) = pk;
-            }
-        }
+        store_rows16(dqbase + (size_t)min(q, S - 1) * ld, dq, 1.0f, q < S, g);
     }
     ATT_STAMP(2);
     __syncthreads();  // every wave is done reading K/V tiles; statistics are visible
@@ -597,19 +747,10 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (keyv[j] < S) {
-                unsigned short* krow = dqbase + H + (size_t)keyv[j] * ld;
-                unsigned short* vrow = dqbase + 2 * H + (size_t)keyv[j] * ld;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    uint2 pk;
-                    pk.x = pack2bf(dk[j][dt][0] * scale, dk[j][dt][1] * scale);
-                    pk.y = pack2bf(dk[j][dt][2] * scale, dk[j][dt][3] * scale);
-                    *(uint2*)(krow + 16 * dt + 4 * g) = pk;
-                    pk.x = pack2bf(dv[j][dt][0], dv[j][dt][1]);
-                    pk.y = pack2bf(dv[j][dt][2], dv[j][dt][3]);
-                    *(uint2*)(vrow + 16 * dt + 4 * g) = pk;
-                }
+            {
+                const size_t roff = (size_t)min(keyv[j], S - 1) * ld;
+                store_rows16(dqbase + H + roff, dk[j], scale, keyv[j] < S, g);
+                store_rows16(dqbase + 2 * H + roff, dv[j], 1.0f, keyv[j] < S, g);
             }
         }
     }
@@ -683,19 +824,10 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(t0, s, dt, lane), dsf, dk[dt], 0, 0, 0);
             }
         }
-        if (key < S) {
-            unsigned short* krow = dqbase + H + (size_t)key * ld;
-            unsigned short* vrow = dqbase + 2 * H + (size_t)key * ld;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 pk;
-                pk.x = pack2bf(dk[dt][0] * scale, dk[dt][1] * scale);
-                pk.y = pack2bf(dk[dt][2] * scale, dk[dt][3] * scale);
-                *(uint2*)(krow + 16 * dt + 4 * g) = pk;
-                pk.x = pack2bf(dv[dt][0], dv[dt][1]);
-                pk.y = pack2bf(dv[dt][2], dv[dt][3]);
-                *(uint2*)(vrow + 16 * dt + 4 * g) = pk;
-            }
+        {
+            const size_t roff = (size_t)min(key, S - 1) * ld;
+            store_rows16(dqbase + H + roff, dk, scale, key < S, g);
+            store_rows16(dqbase + 2 * H + roff, dv, 1.0f, key < S, g);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
@@ -740,12 +872,29 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
     const size_t lds = (size_t)2 * nkt * 16 * 128;
     const float scale = 0.125f;  // 1/sqrt(64)
     hipStream_t st = (hipStream_t)stream;
+    static const int num_cus = [] {
+        int dev = 0, n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+        return n;
+    }();
+    // many heads of a long sequence: the persistent kernel (K / V of the next head land under the current head's arithmetic)
+    const int total = B * nheads;
+    const size_t ldsp = (size_t)2 * lds;
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
+        if (N >= 10 && total >= 2 * num_cus) {                                                                    \
+            constexpr int NP = N >= 10 ? N : 10;   /* (only the long-sequence forms are instantiated) */             \
+            hipFuncSetAttribute((const void*)attention_fwd_persistent_kernel<NP, MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
+            hipLaunchKernelGGL((attention_fwd_persistent_kernel<NP, MSK, DRP>), dim3(num_cus), dim3(64 * ATTP_WAVES), ldsp, st, \
+                               (const unsigned short*)qkv, S, nheads, total, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
+                               drop_seed, drop_thr16, drop_scale, out_fp8_scale);                                 \
+        } else {                                                                                                  \
         hipFuncSetAttribute((const void*)attention_fwd_kernel<N, (N >= 10), MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((attention_fwd_kernel<N, (N >= 10), MSK, DRP>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,       \
                            (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
                            drop_seed, drop_thr16, drop_scale, out_fp8_scale);                                     \
+        }                                                                                                         \
     } while (0)
 #define LAUNCH(N)                                                        \
     do {                                                                 \

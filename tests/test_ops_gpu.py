@@ -230,6 +230,43 @@ def test_attention_fwd_bwd(ops, dev, B, S, nh, masked):
         assert rel_err(got[:, sl], gref[:, sl]) < 1.5e-2, name
 
 
+@pytest.mark.parametrize("S,masked,p_drop", [(197, False, 0.0), (133, False, 0.1), (224, True, 0.0), (150, True, 0.1), (256, False, 0.0)])
+def test_attention_persistent_kernels_match_per_head_kernels(ops, dev, S, masked, p_drop):
+    """A forward launch with many heads (B * heads >= 2 x CUs) and S > 144 takes the persistent kernel (one workgroup of 16 waves per
+    CU walking heads, K / V double-buffered); few heads take the per-head kernel.  The arithmetic per element is the same, so the
+    first sequences of a big launch must equal a small launch on those sequences bit for bit — masks and dropout included (the
+    dropout index is a function of the global head, so the small launch covers the same heads).  The backward (one kernel family)
+    is held to the same batch-split invariance."""
+    B, nh, Bs = 48, 12, 2
+    H = nh * 64
+    g = torch.Generator().manual_seed(S)
+    qkv = (torch.randn(B * S, 3 * H, generator=g) * 0.7).to(dev, BF16)
+    do = torch.randn(B * S, H, generator=g).to(dev, BF16)
+    mask = None
+    if masked:
+        lens = torch.randint(S // 3, S + 1, (B,), generator=g)
+        mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int32).to(dev)
+    drop = ops.Drop(p_drop, 1234) if p_drop > 0 else None
+    out = torch.empty((B * S, H), dtype=BF16, device=dev)
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=BF16, device=dev)
+    ops.attention_fwd(qkv, B, S, nh, mask, out, drop=drop)
+    ops.attention_bwd(qkv, do, B, S, nh, mask, dqkv, drop=drop)
+    out_s = torch.empty((Bs * S, H), dtype=BF16, device=dev)
+    dqkv_s = torch.full((Bs * S, 3 * H), float("nan"), dtype=BF16, device=dev)
+    ms = None if mask is None else mask[:Bs].contiguous()
+    ops.attention_fwd(qkv[: Bs * S].contiguous(), Bs, S, nh, ms, out_s, drop=drop)
+    ops.attention_bwd(qkv[: Bs * S].contiguous(), do[: Bs * S].contiguous(), Bs, S, nh, ms, dqkv_s, drop=drop)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all()
+    assert torch.equal(out[: Bs * S], out_s)
+    assert torch.equal(dqkv[: Bs * S], dqkv_s)
+    # and against torch on the unmasked, undropped case
+    if not masked and p_drop == 0.0:
+        qd = qkv[: Bs * S].cpu().double().requires_grad_(True)
+        oref = _attn_ref(qd, Bs, S, nh, None)
+        assert rel_err(out[: Bs * S].cpu().float(), oref.detach()) < 5e-3
+
+
 # ----------------------------------------------------------------------------------------------- LoRA
 def test_lora_pack_and_wgrad(ops, dev):
     g = torch.Generator().manual_seed(11)
