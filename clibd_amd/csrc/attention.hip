@@ -335,7 +335,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 }
 
 // ============================================ forward, persistent =================================================
-// Long sequences (S > 144: ViT 197, and anything up to 256).  The per-head kernel above spends 39 of its 88 us (ViT, b = 256) waiting
+// Long sequences (S > 160: ViT 197, and anything up to 256).  The per-head kernel above spends 39 of its 88 us (ViT, b = 256) waiting
 // for its K / V tiles: the two workgroups of a CU are launched together and last equally long, so they stage together and
 // compute together (tools/exp_attn_parts.py: the time against the number of query tiles evaluated is a 39-us floor plus the
 // compute, not their maximum).  Here ONE workgroup of 16 waves per CU walks heads blockIdx.x, + gridDim.x, ...: the K / V image
@@ -375,7 +375,8 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
     if (head >= total_heads) return;
     stage(head, smem);
     // Query fragments are requested one head ahead, BEFORE the current head's output stores: vmcnt retires in issue order, so the
-    // wait at the top of a head (this wave's LDS-DMA pieces and query fragments) can then leave the four stores in flight.
+    // wait at the top of a head (this wave's LDS-DMA pieces) can leave the output stores (two 16-byte stores per lane, four 4-byte
+    // ones in fp8 mode) in flight; the compiler's own wait in front of the first MFMA covers the fragments.
     auto load_q = [&](int hd, int it_, bf16x8 (&qf_)[2]) {
         const int qt_ = (wave + 3 * it_) & 15;
         if (qt_ < nqt) {
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
     };
     bf16x8 qf[2] = {}, qn[2] = {};
     load_q(head, 0, qf);
-    bool stored = false;   // wave-uniform: this wave issued its four output stores in the previous head
+    bool stored = false;   // wave-uniform: this wave issued output stores in the previous head
     for (int it = 0; head < total_heads; ++it, head += gridDim.x) {
         char* kt_lds = smem + (it & 1) * BUF;
         char* vt_lds = kt_lds + S_pad * 128;
@@ -883,8 +884,8 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
     const size_t ldsp = (size_t)2 * lds;
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
-        if (N >= 10 && total >= 2 * num_cus) {                                                                    \
-            constexpr int NP = N >= 10 ? N : 10;   /* (only the long-sequence forms are instantiated) */             \
+        if (N >= 12 && total >= 2 * num_cus) {   /* S > 160: at S = 133 only 9 of the 16 waves have a tile and the per-head kernel wins */ \
+            constexpr int NP = N >= 12 ? N : 12;   /* (only the long-sequence forms are instantiated) */             \
             hipFuncSetAttribute((const void*)attention_fwd_persistent_kernel<NP, MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
             hipLaunchKernelGGL((attention_fwd_persistent_kernel<NP, MSK, DRP>), dim3(num_cus), dim3(64 * ATTP_WAVES), ldsp, st, \
                                (const unsigned short*)qkv, S, nheads, total, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \

@@ -156,6 +156,122 @@ __global__ __launch_bounds__(1024) void lora_wgrad_kernel(const unsigned short* 
     lw_reduce_emit<true>(accAv, red, outl, grp, ct, cthreads, dA_v, c, H);
 }
 
+// ---- MFMA form of the same contractions (large M): Z[3H, 16] = L^T R with L = [dq | dv | x] (one row per token) and
+// R = [t (8) | dt (8)]: rows dq x cols 0-3 = dB_q, rows dv x cols 4-7 = dB_v, rows x x cols 8-11 / 12-15 = dA_q^T / dA_v^T.
+// The VALU kernel above spends 16 FMAs and ~10 conversions per loaded element and streams at 4 TB/s; here a 32-token slab of
+// one COLUMN SEGMENT of L (H/2 columns: blockIdx.y = 2 x {dq, dv, x} + half) is loaded with plain 16-byte loads (three slabs in
+// flight per lane: LDS-DMA, one 8-row piece per instruction, tops out near 4 TB/s on this part), written to LDS as [32][64] bf16
+// tiles (R beside it), and every 16-column group costs ONE v_mfma_f32_16x16x32_bf16 per slab on transposed fragments
+// (ds_read_b64_tr_b16, the attention kernels' tile image): the kernel is its loads.  A workgroup keeps its segment of Z in
+// accumulators over all its slabs and adds it to the outputs once.
+typedef __attribute__((ext_vector_type(4))) short lw_s16x4;
+typedef __attribute__((address_space(3))) lw_s16x4 lw_lds_s16x4;
+__device__ __forceinline__ int lwm_tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// fragment whose MFMA row index is the image COLUMN 16 dt + (lane & 15) and whose k-slots walk the 32 image rows
+__device__ __forceinline__ bf16x8 lwm_tr_frag(const char* tile, int dt, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int q = i >> 2, pp = i & 3;
+    const int r0 = 4 * g + q;
+    const int ch = 2 * dt + (pp >> 1);
+    const lw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lw_lds_s16x4*)(tile + lwm_tile_off(r0, ch) + 8 * (pp & 1)));
+    const lw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lw_lds_s16x4*)(tile + lwm_tile_off(r0 + 16, ch) + 8 * (pp & 1)));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+constexpr int LWM_ROWS = 32;
+template <int TILES>   // 64-column tiles per segment = H / 128
+__global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const unsigned short* __restrict__ dqkv, int ld,
+                                                              const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ t,
+                                                              const unsigned short* __restrict__ dt, int ld_dt, int M, int H,
+                                                              float* __restrict__ dA_q, float* __restrict__ dA_v,
+                                                              float* __restrict__ dB_q, float* __restrict__ dB_v) {
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    constexpr int BUF = (TILES + 1) * 4096;    // TILES tiles of L, then the R tile ([32][64] images, only chunks 0, 1 of R are used)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int which = blockIdx.y >> 1, half = blockIdx.y & 1;
+    const int col0 = half * (H >> 1);          // first column of this segment inside its matrix
+    const unsigned short* Lbase = (which == 2) ? x + col0 : dqkv + (which == 1 ? 2 * H : 0) + col0;
+    const size_t ldl = (which == 2) ? (size_t)H : (size_t)ld;
+    const int nslab = M / LWM_ROWS;            // host-checked: M % 32 == 0
+    // this lane's share of a slab: row 8 wave + (lane >> 3), 16-byte chunk lane & 7 of every tile; of R, chunk 0 (t) or 1 (dt)
+    const int prow = lane >> 3, chk = lane & 7;
+    const int lrow = 8 * wave + prow;
+    const int lds_off = lwm_tile_off(lrow, chk);
+    constexpr int MYT = (TILES + 3) / 4;       // tiles of this wave: wave, wave + 4, ...
+    f32x4 acc[MYT][4];
+#pragma unroll
+    for (int a = 0; a < MYT; ++a)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[a][d] = (f32x4){0, 0, 0, 0};
+    // (macros, not lambdas over a struct: the slab registers must stay scalar-replaced, a by-reference aggregate goes to scratch)
+#define LWM_FETCH(slab_, L_, R_)                                                                                      \
+    do {                                                                                                              \
+        const size_t m_ = (size_t)min((slab_), nslab - 1) * LWM_ROWS + lrow; /* slabs past the end re-read the last one and are not accumulated */ \
+        const unsigned short* src_ = Lbase + m_ * ldl + chk * 8;                                                      \
+        _Pragma("unroll") for (int tl = 0; tl < TILES; ++tl) L_[tl] = *(const bf16x8*)(src_ + 64 * tl);               \
+        R_ = (chk == 1) ? *(const bf16x8*)(dt + m_ * ld_dt) : *(const bf16x8*)(t + m_ * 8);                             \
+    } while (0)
+    // one slab: registers -> LDS image (buffer kb), barrier, refill the registers with the slab three ahead, fragments + MFMAs
+#define LWM_STEP(slab_, kb_, L_, R_)                                                                                  \
+    do {                                                                                                              \
+        char* b_ = lsm + (kb_) * BUF;                                                                                 \
+        _Pragma("unroll") for (int tl = 0; tl < TILES; ++tl) *(bf16x8*)(b_ + tl * 4096 + lds_off) = L_[tl];           \
+        if (chk < 2) *(bf16x8*)(b_ + TILES * 4096 + lds_off) = R_;                                                     \
+        __syncthreads(); /* the image is complete; every wave has finished the reads of the image two slabs back (same buffer) */ \
+        LWM_FETCH((slab_) + 3 * G, L_, R_);                                                                           \
+        if ((slab_) < nslab) {                                                                                        \
+            const bf16x8 rf_ = lwm_tr_frag(b_ + TILES * 4096, 0, lane);                                               \
+            _Pragma("unroll") for (int a = 0; a < MYT; ++a) {                                                         \
+                const int tl = wave + 4 * a;                                                                          \
+                if (tl < TILES) {                                                                                     \
+                    _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                     \
+                        acc[a][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lwm_tr_frag(b_ + tl * 4096, d, lane), rf_, acc[a][d], 0, 0, 0); \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+    const int first = blockIdx.x, G = gridDim.x;
+    if (first >= nslab) return;
+    bf16x8 l0[TILES], l1[TILES], l2[TILES], r0, r1, r2;   // three slabs in flight per lane (registers are the prefetch queue; the LDS image only transposes)
+    LWM_FETCH(first, l0, r0);
+    LWM_FETCH(first + G, l1, r1);
+    LWM_FETCH(first + 2 * G, l2, r2);
+    for (int slab = first; slab < nslab; slab += 6 * G) {   // six steps per trip: register set (mod 3) and LDS buffer (mod 2) are compile-time
+        LWM_STEP(slab, 0, l0, r0);
+        LWM_STEP(slab + G, 1, l1, r1);
+        LWM_STEP(slab + 2 * G, 0, l2, r2);
+        LWM_STEP(slab + 3 * G, 1, l0, r0);
+        LWM_STEP(slab + 4 * G, 0, l1, r1);
+        LWM_STEP(slab + 5 * G, 1, l2, r2);
+    }
+#undef LWM_STEP
+#undef LWM_FETCH
+    // lane (c = lane & 15, g = lane >> 4) holds Z[64 tl + 16 d + 4 g + r][c]
+    const int c = lane & 15, g = lane >> 4;
+    const bool use = (which == 0) ? (c < 4) : (which == 1) ? (c >= 4 && c < 8) : (c >= 8);
+    if (use) {
+#pragma unroll
+        for (int a = 0; a < MYT; ++a) {
+            const int tl = wave + 4 * a;
+            if (tl < TILES) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = col0 + 64 * tl + 16 * d + 4 * g + r;
+                        float* dst = (which == 0) ? dB_q + (size_t)col * 4 + c
+                                   : (which == 1) ? dB_v + (size_t)col * 4 + (c - 4)
+                                   : (c < 12)     ? dA_q + (size_t)(c - 8) * H + col
+                                                  : dA_v + (size_t)(c - 12) * H + col;
+                        atomicAdd(dst, acc[a][d][r]);
+                    }
+            }
+        }
+    }
+}
+
 }  // namespace clibd
 
 using namespace clibd;
@@ -179,6 +295,32 @@ extern "C" int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf1
     if (ld_dqkv < 3 * H || ld_dqkv % 8 || ld_dt < 8 || ld_dt % 8) return set_error(CLIBD_EINVAL, "lora_wgrad: bad leading dimension");
     if (!aligned16(dqkv) || !aligned16(x_bf16) || !aligned16(t_bf16) || !aligned16(dt_bf16))
         return set_error(CLIBD_EINVAL, "lora_wgrad: alignment");
+    // large M: the MFMA form (needs whole 32-token slabs, 128-column segments and the dt rows at 16-byte pitch)
+    if (M % LWM_ROWS == 0 && M >= 8192 && H % 128 == 0 && (H / 128 == 3 || H / 128 == 4 || H / 128 == 6 || H / 128 == 8) && ld_dt % 8 == 0) {
+        static const int num_cus = [] {
+            int dev = 0, n = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+            return n;
+        }();
+        const int tiles = H / 128;
+        const int want = (2 * num_cus + 5) / 6;   // x 6 segments: two workgroups (2 x 56 KiB of LDS at H = 768) per CU
+        const int groups = want < M / LWM_ROWS ? want : M / LWM_ROWS;
+        const size_t ldsm = (size_t)2 * (tiles + 1) * 4096;
+#define LWM_LAUNCH(T)                                                                                                 \
+    do {                                                                                                              \
+        hipFuncSetAttribute((const void*)lora_wgrad_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);   \
+        hipLaunchKernelGGL((lora_wgrad_mfma_kernel<T>), dim3(groups, 6), dim3(256), ldsm, (hipStream_t)stream,        \
+                           (const unsigned short*)dqkv, ld_dqkv, (const unsigned short*)x_bf16, (const unsigned short*)t_bf16, \
+                           (const unsigned short*)dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v);                      \
+    } while (0)
+        if (tiles == 3) LWM_LAUNCH(3);
+        else if (tiles == 4) LWM_LAUNCH(4);
+        else if (tiles == 6) LWM_LAUNCH(6);
+        else LWM_LAUNCH(8);
+#undef LWM_LAUNCH
+        return check_launch("lora_wgrad");
+    }
     const int blocks = (M + LW_ROWS - 1) / LW_ROWS;
     const size_t lds = ((size_t)3 * (H / 4) * 16 + (size_t)4 * H + (size_t)(4 * H) / 32 + 32) * sizeof(float);
     hipLaunchKernelGGL(lora_wgrad_kernel, dim3(blocks), dim3(H), lds, (hipStream_t)stream, (const unsigned short*)dqkv, ld_dqkv,

@@ -72,3 +72,15 @@ def test_product_path_has_no_cpu_fallback():
         ops.l2norm_fwd(torch.zeros(4, 8))
     for py in (ROOT / "clibd_amd").rglob("*.py"):
         assert "oracle" not in re.sub(r"#.*|\"\"\".*?\"\"\"", "", py.read_text(), flags=re.S), f"{py} references the oracle"
+
+
+def test_gemm256_asynchronous_operands_are_not_touched_before_their_wait():
+    """gemm256's epilogue bias is an inline-asm load awaited by an inline-asm s_waitcnt (hipcc does not know the registers are
+    written asynchronously): no instruction of any instantiation may touch them in between (tools/check_gemm256_isa.py, hipcc -S)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("check_gemm256_isa", os.path.join(os.path.dirname(__file__), "..", "tools", "check_gemm256_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0

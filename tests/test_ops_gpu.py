@@ -230,9 +230,9 @@ def test_attention_fwd_bwd(ops, dev, B, S, nh, masked):
         assert rel_err(got[:, sl], gref[:, sl]) < 1.5e-2, name
 
 
-@pytest.mark.parametrize("S,masked,p_drop", [(197, False, 0.0), (133, False, 0.1), (224, True, 0.0), (150, True, 0.1), (256, False, 0.0)])
+@pytest.mark.parametrize("S,masked,p_drop", [(197, False, 0.0), (133, False, 0.1), (224, True, 0.0), (170, True, 0.1), (256, False, 0.0)])
 def test_attention_persistent_kernels_match_per_head_kernels(ops, dev, S, masked, p_drop):
-    """A forward launch with many heads (B * heads >= 2 x CUs) and S > 144 takes the persistent kernel (one workgroup of 16 waves per
+    """A forward launch with many heads (B * heads >= 2 x CUs) and S > 160 takes the persistent kernel (one workgroup of 16 waves per
     CU walking heads, K / V double-buffered); few heads take the per-head kernel.  The arithmetic per element is the same, so the
     first sequences of a big launch must equal a small launch on those sequences bit for bit — masks and dropout included (the
     dropout index is a function of the global head, so the small launch covers the same heads).  The backward (one kernel family)
@@ -313,6 +313,26 @@ def test_lora_pack_and_wgrad(ops, dev):
     assert rel_err(dB_v.cpu(), dqkv[:, 2 * H :].T @ t[:, 4:]) < 1e-5
     assert rel_err(dA_q.cpu(), dtf[:, :4].T @ x) < 1e-5
     assert rel_err(dA_v.cpu(), dtf[:, 4:8].T @ x) < 1e-5
+
+
+@pytest.mark.parametrize("M,H", [(8192, 768), (8192 + 32 * 37, 512), (16384, 1024), (8192, 384)])
+def test_lora_wgrad_mfma_form(ops, dev, M, H):
+    """Large M (whole 32-token slabs, H a multiple of 128) takes the MFMA form of the adapter weight gradients; same contract as
+    the VALU kernel (accumulates into the caller's buffers), checked against fp64 products of the same bf16 operands."""
+    g = torch.Generator().manual_seed(M + H)
+    dqkv = bfr(torch.randn(M, 3 * H, generator=g))
+    x = bfr(torch.randn(M, H, generator=g))
+    t = bfr(torch.randn(M, 8, generator=g))
+    dt = bfr(torch.randn(M, 16, generator=g))
+    dt[:, 8:] = 0
+    init = [torch.randn(4, H, generator=g), torch.randn(4, H, generator=g), torch.randn(H, 4, generator=g), torch.randn(H, 4, generator=g)]
+    dA_q, dA_v, dB_q, dB_v = [v.clone().to(dev) for v in init]
+    ops.lora_wgrad(dqkv.to(dev, BF16), x.to(dev, BF16), t.to(dev, BF16), dt.to(dev, BF16), dA_q, dA_v, dB_q, dB_v)
+    torch.cuda.synchronize()
+    d64, x64, t64, g64 = dqkv.double(), x.double(), t.double(), dt.double()
+    refs = [g64[:, :4].T @ x64, g64[:, 4:8].T @ x64, d64[:, :H].T @ t64[:, :4], d64[:, 2 * H :].T @ t64[:, 4:]]
+    for name, got, ref, i0 in zip(("dA_q", "dA_v", "dB_q", "dB_v"), (dA_q, dA_v, dB_q, dB_v), refs, init):
+        assert rel_err(got.cpu().double() - i0.double(), ref) < 2e-5, name
 
 
 # ----------------------------------------------------------------------------------------------- embeddings / heads

@@ -1,15 +1,17 @@
-"""lora_wgrad timing at the bench shapes."""
+"""lora_wgrad timing at the bench shapes; M + 8 rows (not a multiple of 32) takes the VALU kernel, M the MFMA form."""
 import sys
 import torch
 sys.path.insert(0, ".")
 from clibd_amd import ops
 from tools.bench_ops import timeit
 dev = torch.device("cuda:0"); BF16 = torch.bfloat16
-for M in (50432, 34048):
-    H = 768
-    dqkv = torch.randn(M, 3 * H, device=dev).to(BF16); x = torch.randn(M, H, device=dev).to(BF16)
-    t = torch.randn(M, 8, device=dev).to(BF16); dt = torch.randn(M, 16, device=dev).to(BF16)
-    dA_q, dA_v = torch.zeros((4, H), device=dev), torch.zeros((4, H), device=dev)
-    dB_q, dB_v = torch.zeros((H, 4), device=dev), torch.zeros((H, 4), device=dev)
-    a = timeit(lambda: ops.lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v))
-    print(f"M={M}: lora_wgrad {a*1e3:7.1f} us  ({(M*H*2*3)/a/1e9:5.2f} TB/s)", flush=True)
+for M0 in (50432, 34048, 403456, 272384):
+    for M in (M0, M0 + 8):
+        H = 768
+        dqkv = torch.randn(M, 3 * H, device=dev).to(BF16); x = torch.randn(M, H, device=dev).to(BF16)
+        t = torch.randn(M, 8, device=dev).to(BF16); dt = torch.randn(M, 16, device=dev).to(BF16)
+        dA_q, dA_v = torch.zeros((4, H), device=dev), torch.zeros((4, H), device=dev)
+        dB_q, dB_v = torch.zeros((H, 4), device=dev), torch.zeros((H, 4), device=dev)
+        a = timeit(lambda: ops.lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v))
+        print(f"M={M}: lora_wgrad {a*1e3:7.1f} us  ({(M*H*2*3)/a/1e9:5.2f} TB/s)  {'MFMA' if M % 32 == 0 else 'VALU'}", flush=True)
+        del dqkv, x, t, dt
