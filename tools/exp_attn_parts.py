@@ -1,6 +1,6 @@
 """Attention forward / backward time against the number of query rows evaluated (nq): the intercept is staging + launch, the
 slope the per-query-tile cost.  python tools/exp_attn_parts.py [B]"""
-import os, sys
+import sys
 import torch
 sys.path.insert(0, ".")
 from clibd_amd import ops
@@ -18,4 +18,4 @@ for S in (197, 133):
         f = timeit(lambda: ops.attention_fwd(qkv, B, S, nh, None, out, nq=nq))
         b = timeit(lambda: ops.attention_bwd(qkv, do, B, S, nh, None, dqkv, nq=nq))
         row.append(f"nq={nq}: fwd {f*1e3:6.1f} bwd {b*1e3:6.1f}")
-    print(f"W8={os.environ.get('CLIBD_ATT_W8','-')} B={B} S={S} | " + " | ".join(row), flush=True)
+    print(f"B={B} S={S} | " + " | ".join(row), flush=True)
