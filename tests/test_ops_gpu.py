@@ -267,6 +267,29 @@ def test_attention_persistent_kernels_match_per_head_kernels(ops, dev, S, masked
         assert rel_err(out[: Bs * S].cpu().float(), oref.detach()) < 5e-3
 
 
+@pytest.mark.parametrize("S,nq", [(197, 1), (224, 40), (200, 17)])
+def test_attention_persistent_forward_query_prefix(ops, dev, S, nq):
+    """The [CLS]-only last ViT block at the metric's batch is a persistent-kernel launch with nq = 1: only the first nq query rows
+    are evaluated (`out` is [B * nq, H]).  Bit-equal to the per-head kernel on the same sequences, and the rows beyond B * nq of a
+    larger buffer stay untouched."""
+    B, nh, Bs = 48, 12, 2
+    H = nh * 64
+    g = torch.Generator().manual_seed(S + nq)
+    qkv = (torch.randn(B * S, 3 * H, generator=g) * 0.7).to(dev, BF16)
+    buf = torch.full((B * nq + 8, H), 7.0, dtype=BF16, device=dev)
+    out = buf[: B * nq]
+    ops.attention_fwd(qkv, B, S, nh, None, out, nq=nq)
+    out_s = torch.empty((Bs * nq, H), dtype=BF16, device=dev)
+    ops.attention_fwd(qkv[: Bs * S].contiguous(), Bs, S, nh, None, out_s, nq=nq)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out[: Bs * nq], out_s)
+    assert bool((buf[B * nq :].float() == 7.0).all())
+    qd = qkv[: Bs * S].cpu().double()
+    oref = _attn_ref(qd, Bs, S, nh, None).view(Bs, S, H)[:, :nq].reshape(Bs * nq, H)
+    assert rel_err(out_s.cpu().float(), oref) < 5e-3
+
+
 # ----------------------------------------------------------------------------------------------- LoRA
 def test_lora_pack_and_wgrad(ops, dev):
     g = torch.Generator().manual_seed(11)
