@@ -67,6 +67,7 @@ SIGNATURES = {
     "clibd_attention_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "clibd_lora_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_lora_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clibd_lora_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_patchify": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "clibd_vit_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "clibd_gelu_bwd_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -185,12 +185,14 @@ __global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ t,
                                                               const unsigned short* __restrict__ dt, int ld_dt, int M, int H,
                                                               float* __restrict__ dA_q, float* __restrict__ dA_v,
-                                                              float* __restrict__ dB_q, float* __restrict__ dB_v) {
+                                                              float* __restrict__ dB_q, float* __restrict__ dB_v, int which0) {
+    // which0: first matrix of the launch (0: dq, dv and x segments, grid.y = 6;  2: the x segments only, grid.y = 2 — dB then
+    // comes from lora_dt_db_kernel)
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     constexpr int BUF = (TILES + 1) * 4096;    // TILES tiles of L, then the R tile ([32][64] images, only chunks 0, 1 of R are used)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int which = blockIdx.y >> 1, half = blockIdx.y & 1;
+    const int which = which0 + (blockIdx.y >> 1), half = blockIdx.y & 1;
     const int col0 = half * (H >> 1);          // first column of this segment inside its matrix
     const unsigned short* Lbase = (which == 2) ? x + col0 : dqkv + (which == 1 ? 2 * H : 0) + col0;
     const size_t ldl = (which == 2) ? (size_t)H : (size_t)ld;
@@ -272,6 +274,135 @@ __global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const unsigned sho
     }
 }
 
+// ---- dt AND dB in one pass over dq, dv (large M): the backward needs dt = [dq B_q | dv B_v] (rank-8 operand of the QKV dgrad
+// and of dA) before anything else, and used to get it from a skinny GEMM (N = 16) that streams dq, dv once — which the weight
+// gradient kernel then streamed again.  Here a workgroup owns 32-token slabs and walks their dq, dv columns in 256-column chunks
+// (registers -> [32][64] LDS tiles, four chunks in flight per lane): every chunk feeds (a) dB += chunk^T t (transposed
+// fragments, as above) and (b) dt += chunk W_dt^T (row fragments against the [16, 2H] image of w_dt resident in LDS); at the end of
+// a slab the four waves' dt partials are summed in a fixed order, rounded to bf16 and stored.  dq, dv cross the fabric once;
+// results do not depend on the grid (dB: float atomics once per workgroup, as before).
+template <int NCH>   // 256-column chunks per slab = 2H / 256 (even: H % 256 == 0)
+__global__ __launch_bounds__(256) void lora_dt_db_kernel(const unsigned short* __restrict__ dqkv, int ld,
+                                                         const unsigned short* __restrict__ t,
+                                                         const unsigned short* __restrict__ w_dt,   // [16, 3H]
+                                                         unsigned short* __restrict__ dt, int ld_dt, int M, int H,
+                                                         float* __restrict__ dB_q, float* __restrict__ dB_v) {
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    constexpr int IMG = 4 * 4096;                 // one chunk: four [32][64] tiles
+    char* img = lsm;                              // 2 x IMG
+    char* rimg = lsm + 2 * IMG;                   // 2 x 4096: R tile (chunk 0 of its rows = t[m, 0:8])
+    char* wimg = rimg + 2 * 4096;                 // 4 NCH tiles of [16][64]: w_dt's q then v segment
+    float* red = (float*)(wimg + 4 * NCH * 2048); // [4 waves][2 row tiles][64 lanes][4]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int nslab = M / LWM_ROWS;
+    const int prow = lane >> 3, chk = lane & 7;
+    const int lrow = 8 * wave + prow;
+    const int lds_off = lwm_tile_off(lrow, chk);
+    // w_dt image: tile T (64 columns of the q segment for T < 2 NCH, of the v segment after) row r at lwm_tile_off(r, chunk)
+    for (int e = threadIdx.x; e < 4 * NCH * 16 * 8; e += 256) {
+        const int T = e >> 7, r = (e >> 3) & 15, ch = e & 7;
+        const int col = (T < 2 * NCH ? 0 : H) + 64 * T + 8 * ch;   // (v segment starts at 2H: T - 2 NCH tiles into it)
+        *(bf16x8*)(wimg + T * 2048 + lwm_tile_off(r, ch)) = *(const bf16x8*)(w_dt + (size_t)r * 3 * H + col);
+    }
+    f32x4 accB[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) accB[c][d] = (f32x4){0, 0, 0, 0};
+    f32x4 dtp[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
+    const int first = blockIdx.x, G = gridDim.x;
+    if (first >= nslab) return;
+    constexpr int RING = 4;
+    constexpr int LCM = (NCH % 4 == 0) ? NCH : (NCH % 2 == 0 ? 2 * NCH : 4 * NCH);   // steps after which ring slot, chunk and buffer repeat
+    bf16x8 ring[RING][5];
+    // chunk stream j of this workgroup: slab first + (j / NCH) G, chunk j % NCH (columns 256 c of [dq | dv])
+#define LDB_FETCH(j_, slot_)                                                                                          \
+    do {                                                                                                              \
+        const int sj_ = min(first + ((j_) / NCH) * G, nslab - 1);   /* chunks past the end re-read the last slab and are not accumulated */ \
+        const int cj_ = (j_) % NCH;                                                                                   \
+        const size_t m_ = (size_t)sj_ * LWM_ROWS + lrow;                                                              \
+        const unsigned short* src_ = dqkv + m_ * (size_t)ld + (2 * cj_ < NCH ? 0 : H) + 256 * cj_ + chk * 8;          \
+        _Pragma("unroll") for (int tl = 0; tl < 4; ++tl) ring[slot_][tl] = *(const bf16x8*)(src_ + 64 * tl);          \
+        ring[slot_][4] = *(const bf16x8*)(t + m_ * 8);                                                                \
+    } while (0)
+    int jbase = 0;
+    LDB_FETCH(0, 0); LDB_FETCH(1, 1); LDB_FETCH(2, 2); LDB_FETCH(3, 3);
+    const int nchunks = ((nslab - first + G - 1) / G) * NCH;
+    __syncthreads();   // the w_dt image
+    for (; jbase < nchunks; jbase += LCM) {
+#pragma unroll
+        for (int u = 0; u < LCM; ++u) {
+            constexpr int dummy = 0; (void)dummy;
+            const int j = jbase + u;
+            const int slot = u % RING, c = u % NCH, kb = u & 1;   // compile-time after unrolling (LCM is a multiple of 4, NCH and 2)
+            char* b = img + kb * IMG;
+            char* rb = rimg + kb * 4096;
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) *(bf16x8*)(b + tl * 4096 + lds_off) = ring[slot][tl];
+            if (chk == 0) *(bf16x8*)(rb + lds_off) = ring[slot][4];
+            __syncthreads();   // images complete; every wave has finished the reads of the images two chunks back (same buffers)
+            LDB_FETCH(j + RING, slot);
+            if (j < nchunks) {
+                const char* tile = b + wave * 4096;   // this wave's 64 columns of the chunk
+                // (a) dB: Z[col][0:8] += tile^T t
+                const bf16x8 rf = lwm_tr_frag(rb, 0, lane);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) accB[c][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lwm_tr_frag(tile, d, lane), rf, accB[c][d], 0, 0, 0);
+                // (b) dt[row][0:16] += tile (rows) . w_dt[:, these 64 columns]^T
+                const char* wt = wimg + (4 * c + wave) * 2048;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 wf = *(const bf16x8*)(wt + lwm_tile_off(i, 4 * ks + g));
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        dtp[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tile + lwm_tile_off(16 * rt + i, 4 * ks + g)), wf, dtp[rt], 0, 0, 0);
+                }
+                if (c == NCH - 1) {   // the slab is complete: fixed-order sum of the four waves' partials, bf16, store
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        *(f32x4*)(red + ((wave * 2 + rt) * 64 + lane) * 4) = dtp[rt];
+                        dtp[rt] = (f32x4){0, 0, 0, 0};
+                    }
+                }
+            }
+            if (c == NCH - 1) {
+                __syncthreads();
+                if (j < nchunks) {
+                    const int row = threadIdx.x >> 3, cp = (threadIdx.x & 7) * 2;   // 32 rows x 16 columns, two columns per thread
+                    const int rt = row >> 4, rl = row & 15;
+                    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        v0 += red[((w * 2 + rt) * 64 + (rl >> 2) * 16 + cp) * 4 + (rl & 3)];
+                        v1 += red[((w * 2 + rt) * 64 + (rl >> 2) * 16 + cp + 1) * 4 + (rl & 3)];
+                    }
+                    const size_t m = (size_t)(first + (j / NCH) * G) * LWM_ROWS + row;
+                    *(unsigned*)(dt + m * ld_dt + cp) = pack2bf(v0, v1);
+                }
+            }
+        }
+    }
+#undef LDB_FETCH
+    // lane (cc = lane & 15, g) holds Z[256 c + 64 wave + 16 d + 4 g + r][cc] of [dq | dv]
+    const int cc = lane & 15;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool isv = 2 * c >= NCH;
+        const bool use = isv ? (cc >= 4 && cc < 8) : (cc < 4);
+        if (use) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 256 * c - (isv ? H : 0) + 64 * wave + 16 * d + 4 * g + r;
+                    atomicAdd((isv ? dB_v : dB_q) + (size_t)col * 4 + (isv ? cc - 4 : cc), accB[c][d][r]);
+                }
+        }
+    }
+}
+
 }  // namespace clibd
 
 using namespace clibd;
@@ -312,7 +443,7 @@ extern "C" int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf1
         hipFuncSetAttribute((const void*)lora_wgrad_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);   \
         hipLaunchKernelGGL((lora_wgrad_mfma_kernel<T>), dim3(groups, 6), dim3(256), ldsm, (hipStream_t)stream,        \
                            (const unsigned short*)dqkv, ld_dqkv, (const unsigned short*)x_bf16, (const unsigned short*)t_bf16, \
-                           (const unsigned short*)dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v);                      \
+                           (const unsigned short*)dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, 0);                   \
     } while (0)
         if (tiles == 3) LWM_LAUNCH(3);
         else if (tiles == 4) LWM_LAUNCH(4);
@@ -327,4 +458,73 @@ extern "C" int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf1
                        (const unsigned short*)x_bf16, (const unsigned short*)t_bf16, (const unsigned short*)dt_bf16, ld_dt, M, H,
                        dA_q, dA_v, dB_q, dB_v);
     return check_launch("lora_wgrad");
+}
+
+extern "C" int clibd_gemm_bf16_nt_khole(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int hole_k0, int hole_len,
+                                        const clibd_gemm_epilogue* ep, void* stream);
+
+extern "C" int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* w_dt_bf16,
+                                   void* dt_bf16, int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v,
+                                   void* stream) {
+    if (!dqkv || !x_bf16 || !t_bf16 || !w_dt_bf16 || !dt_bf16 || !dA_q || !dA_v || !dB_q || !dB_v)
+        return set_error(CLIBD_EINVAL, "lora_backward: null pointer");
+    if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "lora_backward: H must be a multiple of 64, <= 1024");
+    if (ld_dqkv < 3 * H || ld_dqkv % 8 || ld_dt < 16 || ld_dt % 8) return set_error(CLIBD_EINVAL, "lora_backward: bad leading dimension");
+    if (!aligned16(dqkv) || !aligned16(x_bf16) || !aligned16(t_bf16) || !aligned16(w_dt_bf16) || !aligned16(dt_bf16))
+        return set_error(CLIBD_EINVAL, "lora_backward: alignment");
+    const int nch = 2 * H / 256;
+    // fused: whole slabs, a 256-column chunk must not straddle dq | dv, and enough slabs per workgroup (>= 16 on a 256-CU part) to
+    // amortise its w_dt image and its 6 k float atomics at the end (M = 50 432: 157 us fused against 91 us in two calls;
+    // M = 403 456: 384 against 613 us)
+    const bool fused = M % LWM_ROWS == 0 && M >= 131072 && H % 256 == 0 && (nch == 4 || nch == 6 || nch == 8);
+    if (!fused) {   // small or ragged M: the skinny GEMM (k segment of dqkv skipped) and the VALU / per-segment weight-gradient kernel
+        clibd_gemm_epilogue ep{};
+        ep.out_bf16 = dt_bf16;
+        ep.ld_out_bf16 = ld_dt;
+        ep.split_k = 1;
+        if (int e = clibd_gemm_bf16_nt_khole(dqkv, ld_dqkv, w_dt_bf16, 3 * H, M, 16, 3 * H, H, H, &ep, stream)) return e;
+        return clibd_lora_wgrad(dqkv, ld_dqkv, x_bf16, t_bf16, dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, stream);
+    }
+    static const int num_cus = [] {
+        int dev = 0, n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+        return n;
+    }();
+    const int nslab = M / LWM_ROWS;
+    {   // dt and dB: one workgroup per CU
+        const int groups = num_cus < nslab ? num_cus : nslab;
+        const size_t lds1 = (size_t)2 * 4 * 4096 + 2 * 4096 + (size_t)4 * nch * 2048 + 4 * 2 * 64 * 16;
+#define LDB_LAUNCH(N_)                                                                                                \
+    do {                                                                                                              \
+        hipFuncSetAttribute((const void*)lora_dt_db_kernel<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);       \
+        hipLaunchKernelGGL((lora_dt_db_kernel<N_>), dim3(groups), dim3(256), lds1, (hipStream_t)stream,              \
+                           (const unsigned short*)dqkv, ld_dqkv, (const unsigned short*)t_bf16, (const unsigned short*)w_dt_bf16, \
+                           (unsigned short*)dt_bf16, ld_dt, M, H, dB_q, dB_v);                                        \
+    } while (0)
+        if (nch == 4) LDB_LAUNCH(4);
+        else if (nch == 6) LDB_LAUNCH(6);
+        else LDB_LAUNCH(8);
+#undef LDB_LAUNCH
+        if (int e = check_launch("lora_backward (dt, dB)")) return e;
+    }
+    {   // dA from x and the finished dt: the x segments of the per-segment kernel
+        const int tiles = H / 128;
+        const int want = (2 * num_cus + 1) / 2;
+        const int groups = want < nslab ? want : nslab;
+        const size_t ldsm = (size_t)2 * (tiles + 1) * 4096;
+#define LWM_LAUNCH2(T)                                                                                                \
+    do {                                                                                                              \
+        hipFuncSetAttribute((const void*)lora_wgrad_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);   \
+        hipLaunchKernelGGL((lora_wgrad_mfma_kernel<T>), dim3(groups, 2), dim3(256), ldsm, (hipStream_t)stream,        \
+                           (const unsigned short*)dqkv, ld_dqkv, (const unsigned short*)x_bf16, (const unsigned short*)t_bf16, \
+                           (const unsigned short*)dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, 2);                   \
+    } while (0)
+        if (tiles == 3) LWM_LAUNCH2(3);
+        else if (tiles == 4) LWM_LAUNCH2(4);
+        else if (tiles == 6) LWM_LAUNCH2(6);
+        else LWM_LAUNCH2(8);
+#undef LWM_LAUNCH2
+    }
+    return check_launch("lora_backward (dA)");
 }

@@ -467,17 +467,17 @@ class TransformerStack:
 
     def _lora_grads(self, L, c, dqkv, x_bf16, t, dt, grads):
         H = self.H
-        # dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v; the k segment of dqkv meets zero weights in w_dt and is not read
-        ops.gemm_nt(dqkv, c.w_dt, out_bf16=dt, k_hole=(H, H))
+        # dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v (the rank-8 operand of the QKV dgrad that follows) and the four adapter gradients in
+        # one call: dq and dv are streamed once for dt and dB together (clibd_lora_backward); the k segment of dqkv is never read
         lp = L.lora
         r = lp.a_q.shape[0]
         if r == 4:
-            ops.lora_wgrad(dqkv, x_bf16, t, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
+            ops.lora_backward(dqkv, x_bf16, t, c.w_dt, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
         else:   # ranks 1-3: rank-4 scratch gradients (the padded rows / columns receive exact zeros' worth of signal), sliced back
             dev = dqkv.device
             ga_q, ga_v = torch.zeros((4, H), dtype=F32, device=dev), torch.zeros((4, H), dtype=F32, device=dev)
             gb_q, gb_v = torch.zeros((H, 4), dtype=F32, device=dev), torch.zeros((H, 4), dtype=F32, device=dev)
-            ops.lora_wgrad(dqkv, x_bf16, t, dt, ga_q, ga_v, gb_q, gb_v)
+            ops.lora_backward(dqkv, x_bf16, t, c.w_dt, dt, ga_q, ga_v, gb_q, gb_v)
             grads[id(lp.a_q)].add_(ga_q[:r]); grads[id(lp.a_v)].add_(ga_v[:r])
             grads[id(lp.b_q)].add_(gb_q[:, :r]); grads[id(lp.b_v)].add_(gb_v[:, :r])
 

@@ -381,6 +381,24 @@ def lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v) -> None:
                                        dA_q.data_ptr(), dA_v.data_ptr(), dB_q.data_ptr(), dB_v.data_ptr(), _stream()), "lora_wgrad")
 
 
+def lora_backward(dqkv, x, t, w_dt, dt, dA_q, dA_v, dB_q, dB_v) -> None:
+    """dt = dqkv . w_dt^T (written, bf16 [M,16]) and the adapters' four parameter gradients (accumulated); see clibd_lora_backward."""
+    _chk(dqkv, BF16, "dqkv")
+    _chk(x, BF16, "x")
+    _chk(t, BF16, "t")
+    _chk(w_dt, BF16, "w_dt")
+    _chk(dt, BF16, "dt")
+    M, H = x.shape
+    if tuple(dqkv.shape) != (M, 3 * H) or tuple(t.shape) != (M, 8) or tuple(w_dt.shape) != (16, 3 * H) or tuple(dt.shape) != (M, 16):
+        raise ValueError("lora_backward: shapes")
+    for nm, g, shape in (("dA_q", dA_q, (4, H)), ("dA_v", dA_v, (4, H)), ("dB_q", dB_q, (H, 4)), ("dB_v", dB_v, (H, 4))):
+        _chk(g, F32, nm)
+        if tuple(g.shape) != shape:
+            raise ValueError(f"lora_backward: {nm} must be {shape}")
+    check(_lib.load().clibd_lora_backward(dqkv.data_ptr(), 3 * H, x.data_ptr(), t.data_ptr(), w_dt.data_ptr(), dt.data_ptr(), 16, M, H,
+                                          dA_q.data_ptr(), dA_v.data_ptr(), dB_q.data_ptr(), dB_v.data_ptr(), _stream()), "lora_backward")
+
+
 def patchify(image: torch.Tensor) -> torch.Tensor:
     _chk(image, F32, "image")
     if image.dim() != 4 or tuple(image.shape[1:]) != (3, 224, 224):

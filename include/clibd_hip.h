@@ -195,6 +195,13 @@ int clibd_lora_pack(const float* a_q, const float* a_v, const float* b_q, const 
                     void* v_fwd_bf16, void* v_bwd_bf16, void* a_cat_bf16, void* w_dt_bf16, void* stream);
 int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* dt_bf16,
                      int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v, void* stream);
+/* The adapters' whole backward in one call: dt[M, 0:16] = dqkv . w_dt^T (bf16; columns 8..15 zero: the rank-8 operand of the QKV
+ * dgrad), then the four parameter gradients of clibd_lora_wgrad (accumulating).  For large M (whole 32-token slabs, H % 128 == 0)
+ * dq and dv are read ONCE: a first kernel produces dt and dB together, a second one dA from x and dt; otherwise it is the skinny
+ * GEMM (clibd_gemm_bf16_nt_khole against w_dt) followed by clibd_lora_wgrad.  Replaces the autograd of _LoRA_qkv_timm.forward /
+ * _LoRALayer.forward (image_encoder.py:40-46, dna_encoder.py:75-77) with respect to the adapter weights. */
+int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* w_dt_bf16,
+                        void* dt_bf16, int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Embeddings.

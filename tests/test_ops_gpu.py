@@ -358,6 +358,38 @@ def test_lora_wgrad_mfma_form(ops, dev, M, H):
         assert rel_err(got.cpu().double() - i0.double(), ref) < 2e-5, name
 
 
+@pytest.mark.parametrize("M,H", [(131072, 768), (131072 + 32 * 41, 512), (131072, 1024), (8192, 768), (8192, 384), (700, 128)])
+def test_lora_backward_one_pass_over_dq_dv(ops, dev, M, H):
+    """clibd_lora_backward: dt = dqkv . w_dt^T and the adapters' parameter gradients in one call.  Large M (>= 131 072 whole slabs' worth of rows) with H % 256 == 0 takes the
+    fused kernels (dq, dv read once for dt and dB; dA from x and the finished dt), the rest the skinny GEMM + weight-gradient kernels;
+    both against fp64 products of the same bf16 operands, dt bit-equal to the GEMM's (fp32 accumulation in another order: a bf16 ulp)."""
+    g = torch.Generator().manual_seed(M + H)
+    a_q, a_v = torch.randn(4, H, generator=g), torch.randn(4, H, generator=g)
+    b_q, b_v = torch.randn(H, 4, generator=g) * 0.2, torch.randn(H, 4, generator=g) * 0.2
+    v_fwd = torch.empty((3 * H, 8), dtype=BF16, device=dev); v_bwd = torch.empty((H, 8), dtype=BF16, device=dev)
+    a_cat = torch.empty((8, H), dtype=BF16, device=dev); w_dt = torch.empty((16, 3 * H), dtype=BF16, device=dev)
+    ops.lora_pack(a_q.to(dev), a_v.to(dev), b_q.to(dev), b_v.to(dev), v_fwd, v_bwd, a_cat, w_dt)
+    dqkv = bfr(torch.randn(M, 3 * H, generator=g))
+    x = bfr(torch.randn(M, H, generator=g))
+    t = bfr(torch.randn(M, 8, generator=g))
+    init = [torch.randn(4, H, generator=g), torch.randn(4, H, generator=g), torch.randn(H, 4, generator=g), torch.randn(H, 4, generator=g)]
+    dA_q, dA_v, dB_q, dB_v = [v.clone().to(dev) for v in init]
+    dt = torch.full((M, 16), float("nan"), dtype=BF16, device=dev)
+    ops.lora_backward(dqkv.to(dev, BF16), x.to(dev, BF16), t.to(dev, BF16), w_dt, dt, dA_q, dA_v, dB_q, dB_v)
+    dt_gemm = torch.empty((M, 16), dtype=BF16, device=dev)
+    ops.gemm_nt(dqkv.to(dev, BF16), w_dt, out_bf16=dt_gemm, k_hole=(H, H))
+    torch.cuda.synchronize()
+    dt_ref = torch.cat([dqkv[:, :H].double() @ bfr(b_q).double(), dqkv[:, 2 * H :].double() @ bfr(b_v).double()], dim=1)
+    dtf = dt.cpu().float()
+    assert torch.equal(dtf[:, 8:], torch.zeros(M, 8))
+    assert rel_err(dtf[:, :8].double(), dt_ref) < 4e-3
+    assert rel_err(dtf, dt_gemm.cpu().float()) < 2e-3     # both are bf16 roundings of the same fp32-accumulated products
+    d64, x64, t64, g64 = dqkv.double(), x.double(), t.double(), dtf.double()
+    refs = [g64[:, :4].T @ x64, g64[:, 4:8].T @ x64, d64[:, :H].T @ t64[:, :4], d64[:, 2 * H :].T @ t64[:, 4:]]
+    for name, got, ref, i0 in zip(("dA_q", "dA_v", "dB_q", "dB_v"), (dA_q, dA_v, dB_q, dB_v), refs, init):
+        assert rel_err(got.cpu().double() - i0.double(), ref) < 2e-5, name
+
+
 # ----------------------------------------------------------------------------------------------- embeddings / heads
 def test_patchify_matches_conv_unfold(ops, dev):
     g = torch.Generator().manual_seed(12)
