@@ -648,14 +648,36 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
     // Every Q / dO fragment read from LDS (row form for S and dP, transposed form for dK and dV) feeds two MFMAs, one per
     // key tile: half the LDS traffic per MFMA of a one-tile sweep (this phase was LDS-bandwidth bound: 1 KiB per MFMA).
     // Arithmetic per element is unchanged.
+    // This wave's key tiles (at most two pairs: S_pad <= 256, four waves) as MFMA row fragments, taken from the K / V images before
+    // they are released — not re-read from global memory (a quarter of the kernel's fetches, and their latency at the head of a pair)
+    const int nkt = (S + 15) >> 4;
+    bf16x8 kfs[2][2][2], vfs[2][2][2];   // [pair of this wave][key tile][k-step]
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        if (wave + ATT_WAVES * pi < ((nkt + 1) >> 1)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kr = min((2 * (wave + ATT_WAVES * pi) + j) * 16 + i, S_pad - 1);   // rows S .. S_pad-1 are copies of row S-1 (never stored)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    kfs[pi][j][ks] = lds_row_frag(t0, kr, ks, g);
+                    vfs[pi][j][ks] = lds_row_frag(t1, kr, ks, g);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave holds its fragments: the images may be overwritten
     stage_head_tile(t0, qbase, ld, S, S_pad, wave, lane);
     stage_head_tile(t1, dobase, (size_t)H, nq, S_pad, wave, lane);  // rows >= nq are clamped copies, masked below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ATT_STAMP(4);
 
-    const int nkt = (S + 15) >> 4;
-    for (int p = wave; p < ((nkt + 1) >> 1); p += ATT_WAVES) {
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int p = wave + ATT_WAVES * pi;
+        if (p >= ((nkt + 1) >> 1)) break;
         bf16x8 kf[2][2], vf[2][2];
         bool key_ok[2];
         int keyv[2];
@@ -666,12 +688,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
             bool ok = key < S;
             if (MASK) ok = ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
             key_ok[j] = ok;
-            const int kc = min(key, S - 1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                kf[j][ks] = *(const bf16x8*)(qbase + H + (size_t)kc * ld + 32 * ks + 8 * g);
-                vf[j][ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kc * ld + 32 * ks + 8 * g);
-            }
+            for (int ks = 0; ks < 2; ++ks) { kf[j][ks] = kfs[pi][j][ks]; vf[j][ks] = vfs[pi][j][ks]; }
         }
         f32x4 dv[2][4], dk[2][4];
 #pragma unroll
@@ -758,33 +776,38 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
     ATT_STAMP(5);
     } else {
     // ---------------- phase 2: per 16-key tile: dV, dK (query on the MFMA row, key on the lane) ----------------
-    bf16x8 kf[2], vf[2], kfn[2], vfn[2];
-    {
-        const int kc0 = min(wave * 16 + i, S - 1);
+    // This wave's key tiles (at most NKT / 4 rounded up) as MFMA row fragments, taken from the K / V images before they are released
+    const int nkt = (S + 15) >> 4;
+    constexpr int MYK = (NKT + ATT_WAVES - 1) / ATT_WAVES;
+    bf16x8 kfs[MYK][2], vfs[MYK][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kf[ks] = *(const bf16x8*)(qbase + H + (size_t)kc0 * ld + 32 * ks + 8 * g);
-            vf[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kc0 * ld + 32 * ks + 8 * g);
+    for (int ki = 0; ki < MYK; ++ki) {
+        if (wave + ATT_WAVES * ki < nkt) {
+            const int kr = min((wave + ATT_WAVES * ki) * 16 + i, S_pad - 1);   // rows S .. S_pad-1 are copies of row S-1 (never stored)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kfs[ki][ks] = lds_row_frag(t0, kr, ks, g);
+                vfs[ki][ks] = lds_row_frag(t1, kr, ks, g);
+            }
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave holds its fragments: the images may be overwritten
     stage_head_tile(t0, qbase, ld, S, S_pad, wave, lane);
     stage_head_tile(t1, dobase, (size_t)H, nq, S_pad, wave, lane);  // rows >= nq are clamped copies, masked below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nkt = (S + 15) >> 4;
-    for (int kt = wave; kt < nkt; kt += ATT_WAVES) {
+#pragma unroll
+    for (int ki = 0; ki < MYK; ++ki) {
+        const int kt = wave + ATT_WAVES * ki;
+        if (kt >= nkt) break;
         const int key = kt * 16 + i;
         bool key_ok = key < S;
         if (MASK) key_ok = key_ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
-        {   // next key tile's K / V fragments fly during this tile's sweep over the queries
-            const int kn = min((kt + ATT_WAVES) * 16 + i, S - 1);
+        bf16x8 kf[2], vf[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                kfn[ks] = *(const bf16x8*)(qbase + H + (size_t)kn * ld + 32 * ks + 8 * g);
-                vfn[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kn * ld + 32 * ks + 8 * g);
-            }
-        }
+        for (int ks = 0; ks < 2; ++ks) { kf[ks] = kfs[ki][ks]; vf[ks] = vfs[ki][ks]; }
         f32x4 dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
@@ -830,8 +853,6 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
             store_rows16(dqbase + H + roff, dk, scale, key < S, g);
             store_rows16(dqbase + 2 * H + roff, dv, 1.0f, key < S, g);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
     }
     }
 }
