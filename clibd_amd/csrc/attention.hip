@@ -776,38 +776,33 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
     ATT_STAMP(5);
     } else {
     // ---------------- phase 2: per 16-key tile: dV, dK (query on the MFMA row, key on the lane) ----------------
-    // This wave's key tiles (at most NKT / 4 rounded up) as MFMA row fragments, taken from the K / V images before they are released
-    const int nkt = (S + 15) >> 4;
-    constexpr int MYK = (NKT + ATT_WAVES - 1) / ATT_WAVES;
-    bf16x8 kfs[MYK][2], vfs[MYK][2];
+    bf16x8 kf[2], vf[2], kfn[2], vfn[2];
+    {
+        const int kc0 = min(wave * 16 + i, S - 1);
 #pragma unroll
-    for (int ki = 0; ki < MYK; ++ki) {
-        if (wave + ATT_WAVES * ki < nkt) {
-            const int kr = min((wave + ATT_WAVES * ki) * 16 + i, S_pad - 1);   // rows S .. S_pad-1 are copies of row S-1 (never stored)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                kfs[ki][ks] = lds_row_frag(t0, kr, ks, g);
-                vfs[ki][ks] = lds_row_frag(t1, kr, ks, g);
-            }
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[ks] = *(const bf16x8*)(qbase + H + (size_t)kc0 * ld + 32 * ks + 8 * g);
+            vf[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kc0 * ld + 32 * ks + 8 * g);
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();  // every wave holds its fragments: the images may be overwritten
     stage_head_tile(t0, qbase, ld, S, S_pad, wave, lane);
     stage_head_tile(t1, dobase, (size_t)H, nq, S_pad, wave, lane);  // rows >= nq are clamped copies, masked below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-#pragma unroll
-    for (int ki = 0; ki < MYK; ++ki) {
-        const int kt = wave + ATT_WAVES * ki;
-        if (kt >= nkt) break;
+    const int nkt = (S + 15) >> 4;
+    for (int kt = wave; kt < nkt; kt += ATT_WAVES) {
         const int key = kt * 16 + i;
         bool key_ok = key < S;
         if (MASK) key_ok = key_ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
-        bf16x8 kf[2], vf[2];
+        {   // next key tile's K / V fragments fly during this tile's sweep over the queries
+            const int kn = min((kt + ATT_WAVES) * 16 + i, S - 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { kf[ks] = kfs[ki][ks]; vf[ks] = vfs[ki][ks]; }
+            for (int ks = 0; ks < 2; ++ks) {
+                kfn[ks] = *(const bf16x8*)(qbase + H + (size_t)kn * ld + 32 * ks + 8 * g);
+                vfn[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kn * ld + 32 * ks + 8 * g);
+            }
+        }
         f32x4 dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
@@ -853,6 +848,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
             store_rows16(dqbase + H + roff, dk, scale, key < S, g);
             store_rows16(dqbase + 2 * H + roff, dv, 1.0f, key < S, g);
         }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
     }
     }
 }
