@@ -80,6 +80,8 @@ def test_gemm256_asynchronous_operands_are_not_touched_before_their_wait():
     import importlib.util
     import os
 
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed: the ISA cannot be generated here")
     spec = importlib.util.spec_from_file_location("check_gemm256_isa", os.path.join(os.path.dirname(__file__), "..", "tools", "check_gemm256_isa.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
