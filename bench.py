@@ -197,14 +197,33 @@ def cpu_baseline(batch: int, steps: int):
                       f"then median of {len(times)} steps at {threads} threads ({', '.join(f'{t:.1f}' for t in times)} s), loss {loss:.4f}"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher (the reference starts its own ranks too: scripts/train_cl.py:365 mp.spawn):
+    start `torch.distributed.run` with N fresh rank processes as a CHILD of this process — which has not touched the GPU
+    (no HIP call is made before this point, and nothing is exec'ed) — pass its stdout through (rank 0's JSON line is the only
+    thing any rank prints there) and return its exit code: a failed rank fails the launcher, which fails this process."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's peer mappings need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")

@@ -46,6 +46,7 @@ class GemmEpilogue(C.Structure):
 SIGNATURES = {
     "clibd_last_error": (C.c_char_p, []),
     "clibd_abi_version": (c_int, []),
+    "clibd_build_hash": (C.c_char_p, []),
     "clibd_gemm_bf16_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
     "clibd_gemm_bf16_nt_khole": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
     "clibd_gemm_fp8_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, C.POINTER(GemmEpilogue), c_void_p]),
@@ -127,8 +128,22 @@ def load() -> C.CDLL:
             raise ClibdHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    _check_build_hash(lib)
     _lib = lib
     return lib
+
+
+def _check_build_hash(lib) -> None:
+    """The library must have been built from the kernel sources that sit beside it (mtime-based rebuilds can be fooled by a
+    checkout or a copied tree).  CLIBD_HIP_LIB (an explicitly chosen library) and a source-less installation skip the check."""
+    if "CLIBD_HIP_LIB" in os.environ or not (_HERE / "csrc").is_dir():
+        return
+    from .build import csrc_hash
+
+    built, cur = (lib.clibd_build_hash() or b"").decode(), csrc_hash()
+    if built != cur:
+        raise ClibdHipError(f"{LIB_PATH} was built from other kernel sources (library {built}, clibd_amd/csrc {cur}): "
+                            "rebuild it with `python -m clibd_amd.build`")
 
 
 def check(code: int, what: str) -> None:

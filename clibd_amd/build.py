@@ -57,6 +57,8 @@ def _compile_one(name: str, report: bool) -> tuple[str, str]:
     src = CSRC / f"{name}.hip"
     obj = OBJ / f"{name}.o"
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", str(src), "-o", str(obj)]
+    if name == "capi":
+        cmd.append(f'-DCLIBD_CSRC_HASH="{csrc_hash()}"')   # clibd_build_hash(): checked by _lib.load() against the sources
     if os.environ.get("CLIBD_GEMM_DIAG") == "1":
         cmd.append("-DCLIBD_GEMM_DIAG")  # tools/gemm_stamps.py: s_memtime stamps + start-up skew knob (never in the product build)
     if report:
@@ -95,6 +97,10 @@ def build(force: bool = False, report: bool = False, verbose: bool = True) -> Pa
     OBJ.mkdir(parents=True, exist_ok=True)
     deps = _deps()
     todo = [n for n in SOURCES if force or report or _stale(OBJ / f"{n}.o", [CSRC / f"{n}.hip"] + deps)]
+    # the unit that carries the source hash is rebuilt whenever the hash it was built with differs (content, not mtime)
+    stamp = OBJ / "capi.hash"
+    if "capi" not in todo and (not stamp.exists() or stamp.read_text().strip() != csrc_hash()):
+        todo.append("capi")
     if todo:
         if verbose:
             print(f"[clibd_amd.build] hipcc --offload-arch={ARCH}: {', '.join(todo)}", flush=True)
@@ -103,6 +109,8 @@ def build(force: bool = False, report: bool = False, verbose: bool = True) -> Pa
                 if report:
                     print(f"== {name}")
                     print("\n".join(_summarise(err)))
+    if "capi" in todo:
+        stamp.write_text(csrc_hash())
     objs = [OBJ / f"{n}.o" for n in SOURCES]
     if force or todo or _stale(LIB, objs):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]

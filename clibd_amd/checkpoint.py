@@ -84,12 +84,39 @@ def initialize_model_and_load_from_checkpoint(args, device=None):
     return model
 
 
+def export_reference_state_dict(model: torch.nn.Module) -> dict:
+    """`model.state_dict()` in the form the REFERENCE loads strictly (simple_clip.py:263/279 `model.load_state_dict(checkpoint)`):
+    under its pinned transformers==4.29.2 `BertEmbeddings.position_ids` is a persistent buffer, so both BERT towers' state
+    dicts carry `...embeddings.position_ids` = arange(max_position_embeddings)[None] (int64); the modules here recompute it and
+    do not store it.  (`token_type_ids` is registered persistent=False there and is not part of a checkpoint.)"""
+    sd = dict(model.state_dict())
+    for key in list(sd.keys()):
+        if key.endswith("embeddings.position_embeddings.weight"):
+            n = sd[key].shape[0]
+            sd[key[: -len("position_embeddings.weight")] + "position_ids"] = torch.arange(n, dtype=torch.int64).unsqueeze(0)
+    return sd
+
+
+def save_reference_checkpoint(model: torch.nn.Module, path: str) -> None:
+    """What train_cl.py:292-318 writes (`torch.save(model.state_dict(), best.pth / last.pth)`), loadable by the reference."""
+    torch.save({k: v.detach().cpu() for k, v in export_reference_state_dict(model).items()}, path)
+
+
+def _optimizer_layout(model: torch.nn.Module, optimizer) -> list:
+    """[(parameter name, flat offset, numel)] of the fused optimizer's bucket: its order depends on the towers present, on
+    fix_temperature and on the backward order (train._backward_order), so the raw flat moments alone do not say which
+    parameter a slice belongs to."""
+    names = {id(p): n for n, p in model.named_parameters()}
+    return [(names.get(id(p), f"<unnamed {i}>"), int(off), int(p.numel()))
+            for i, (p, off) in enumerate(zip(optimizer.param_groups[0]["params"], optimizer._offsets))]
+
+
 def save_training_state(path: str, model: torch.nn.Module, optimizer=None, scheduler=None, epoch: Optional[int] = None):
     state = {"model": model.state_dict(), "epoch": epoch}
     if optimizer is not None and hasattr(optimizer, "exp_avg"):
         state["optimizer"] = {"exp_avg": optimizer.exp_avg.detach().cpu(), "exp_avg_sq": optimizer.exp_avg_sq.detach().cpu(),
-                              "step_count": optimizer.step_count, "param_groups": [{k: v for k, v in g.items() if k != "params"}
-                                                                                   for g in optimizer.param_groups]}
+                              "step_count": optimizer.step_count, "layout": _optimizer_layout(model, optimizer),
+                              "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in optimizer.param_groups]}
     if scheduler is not None:
         state["scheduler"] = scheduler.state_dict()
     torch.save(state, path)
@@ -100,11 +127,35 @@ def load_training_state(path: str, model: torch.nn.Module, optimizer=None, sched
     model.load_state_dict(_normalise(state["model"]))
     if optimizer is not None and "optimizer" in state:
         o = state["optimizer"]
-        optimizer.exp_avg.copy_(o["exp_avg"])
-        optimizer.exp_avg_sq.copy_(o["exp_avg_sq"])
+        cur = _optimizer_layout(model, optimizer)
+        saved = o.get("layout")
+        if saved is None:
+            # a state written before the layout was recorded: only a bucket of the same size can be taken as is
+            if o["exp_avg"].numel() != optimizer.exp_avg.numel():
+                raise ValueError("training state has no optimizer layout and its moment buffers do not match this optimizer "
+                                 f"({o['exp_avg'].numel()} vs {optimizer.exp_avg.numel()} values): it was saved with a different set of "
+                                 "towers / fix_temperature; re-create it or start the moments from zero")
+            optimizer.exp_avg.copy_(o["exp_avg"])
+            optimizer.exp_avg_sq.copy_(o["exp_avg_sq"])
+        elif [tuple(e) for e in saved] == cur:
+            optimizer.exp_avg.copy_(o["exp_avg"])
+            optimizer.exp_avg_sq.copy_(o["exp_avg_sq"])
+        else:
+            # same parameters in another order / a subset: move every moment slice to where its parameter lives now
+            where = {n: (off, k) for n, off, k in (tuple(e) for e in saved)}
+            missing = [n for n, _, k in cur if n not in where or where[n][1] != k]
+            if missing:
+                raise ValueError(f"training state lacks optimizer moments for {len(missing)} parameters (first: {missing[0]}); "
+                                 "it was saved with a different set of trainable parameters")
+            optimizer.exp_avg.zero_()
+            optimizer.exp_avg_sq.zero_()
+            for n, off, k in cur:
+                s_off = where[n][0]
+                optimizer.exp_avg[off : off + k].copy_(o["exp_avg"][s_off : s_off + k])
+                optimizer.exp_avg_sq[off : off + k].copy_(o["exp_avg_sq"][s_off : s_off + k])
         optimizer.step_count = o["step_count"]
-        for g, saved in zip(optimizer.param_groups, o["param_groups"]):
-            g.update(saved)
+        for g, saved_g in zip(optimizer.param_groups, o["param_groups"]):
+            g.update(saved_g)
         # the flat parameter bucket aliases the parameters, which load_state_dict just overwrote in place
     if scheduler is not None and "scheduler" in state:
         scheduler.load_state_dict(state["scheduler"])

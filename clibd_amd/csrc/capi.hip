@@ -11,3 +11,10 @@ char* last_error_buf() {
 
 extern "C" const char* clibd_last_error(void) { return clibd::last_error_buf(); }
 extern "C" int clibd_abi_version(void) { return 1; }
+
+// sha256/16 of clibd_amd/csrc/*.{hip,h} + include/clibd_hip.h at build time (clibd_amd/build.py passes it; this unit is rebuilt
+// whenever it changes): the Python binding refuses a library that was not built from the sources beside it.
+#ifndef CLIBD_CSRC_HASH
+#define CLIBD_CSRC_HASH "unknown"
+#endif
+extern "C" const char* clibd_build_hash(void) { return CLIBD_CSRC_HASH; }

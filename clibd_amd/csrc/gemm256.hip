@@ -709,18 +709,8 @@ int gemm256_splitk_launch(const GemmParams& p0, float* partials, size_t partials
         }
         return n;
     }();
-    int splits = num_cus / tiles;                   // one round of work items over the CUs
-    if (splits < 1) splits = 1;
-    if (splits > nk / 4) splits = nk / 4;
-    int nks = (nk + splits - 1) / splits;
-    nks += nks & 1;                                  // even
-    if (nks < 4) nks = 4;
-    splits = (nk + nks - 1) / nks;
-    if (nk - (splits - 1) * nks < 4) {               // the last slice must keep >= 4 K-tiles (it is even: nk and nks are)
-        nks += 2;
-        splits = (nk + nks - 1) / nks;
-        if (nk - (splits - 1) * nks < 4) return 0;
-    }
+    int nks = 0;
+    const int splits = plan_k_slices(nk, tiles, num_cus, &nks);   // nk is even and >= 8: never refuses
     if ((size_t)splits * (size_t)q.M * (size_t)q.N > partials_elems) return 0;
     q.splits = splits;
     q.nk_split = nks;

@@ -313,6 +313,29 @@ __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, 
     fold_row8_in<KIND>(ep, m, nb, v, ax, r0, r1);
 }
 
+// K-slice plan shared by the two split-K launchers: nk (even, >= 4) 64-deep K-tiles over about one round of work items
+// (tiles x splits ~ CUs); every slice is an even number of K-tiles and the LAST one keeps >= 4 (the kernels' pipeline
+// prologue needs two K-tile pairs).  Always succeeds: nks grows by 2 until the tail is long enough, and nks = nk
+// (one slice) ends the walk at the latest.  Returns the number of slices, *nks_out = K-tiles per slice.
+inline int plan_k_slices(int nk, int tiles, int num_cus, int* nks_out) {
+    int splits = num_cus / (tiles > 0 ? tiles : 1);
+    if (splits < 1) splits = 1;
+    if (splits > nk / 4) splits = nk / 4;
+    if (splits < 1) splits = 1;
+    int nks = (nk + splits - 1) / splits;
+    nks += nks & 1;
+    if (nks < 4) nks = 4;
+    if (nks > nk) nks = nk;
+    splits = (nk + nks - 1) / nks;
+    while (nk - (splits - 1) * nks < 4 && nks < nk) {
+        nks += 2;
+        if (nks > nk) nks = nk;
+        splits = (nk + nks - 1) / nks;
+    }
+    *nks_out = nks;
+    return splits;
+}
+
 // host side (gemm256.hip): returns true when the 256x256 kernel took the launch
 bool gemm256_try_launch(const GemmParams& p, hipStream_t stream);
 // fp8 operands (p.fp8, p.col_scale set; K / lda / ldw in bytes): true when launched

@@ -497,22 +497,23 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
     K = x_bf16.shape[1]
     tn_ok = (M % 128 == 0 and M >= 256 and K % 256 == 0 and dy_bf16.stride(0) % 8 == 0 and x_bf16.stride(0) % 8 == 0
              and all(w.shape[0] % 256 == 0 for w in weights))
-    if tn_ok and any(id(w) in grads for w in weights):
-        # in-place rows-contracting GEMM (gemm256_tn.hip): no dy^T / x^T; the bias gradient (column sums of dy) rides along
+    pending = [id(w) in grads for w in weights]   # weight gradients still to be produced
+    if tn_ok and any(pending):
+        # in-place rows-contracting GEMM (gemm256_tn.hip): no dy^T / x^T; the bias gradient (column sums of dy) rides along.
+        # A piece the kernel declines (ops.gemm_tn_splitk returns False) stays pending and takes the transpose path below.
         n0 = 0
         done = []
-        for w, b, wb in zip(weights, biases, want_b):
+        for j, (w, b, wb) in enumerate(zip(weights, biases, want_b)):
             n1 = n0 + w.shape[0]
-            if id(w) in grads:
+            took = False
+            if pending[j]:
                 cs = grads[id(b)].view(-1) if wb else None
-                if not ops.gemm_tn_splitk(dy_bf16[:, n0:n1], x_bf16, grads[id(w)].view(w.shape[0], -1), accumulate=True, colsum=cs):
-                    raise RuntimeError("gemm_tn_splitk refused a shape its guard accepted")
-                done.append(wb)
-            else:
-                done.append(False)
+                took = ops.gemm_tn_splitk(dy_bf16[:, n0:n1], x_bf16, grads[id(w)].view(w.shape[0], -1), accumulate=True, colsum=cs)
+                pending[j] = not took
+            done.append(took and wb)
             n0 = n1
         want_b = [wb and not d for wb, d in zip(want_b, done)]   # biases whose weight is frozen still take the column-sum kernel
-    elif any(id(w) in grads for w in weights):
+    if any(pending):
         N = dy_bf16.shape[1]
         csum, direct = None, False
         if any(want_b) and N % 8 == 0 and dy_bf16.stride(0) % 8 == 0:
@@ -525,9 +526,9 @@ def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[
         Mp = dyT.shape[1]
         split = max(1, min(32, Mp // 2048))
         n0 = 0
-        for w in weights:
+        for j, w in enumerate(weights):
             n1 = n0 + w.shape[0]
-            if id(w) in grads:
+            if pending[j]:
                 gw = grads[id(w)].view(w.shape[0], -1)
                 if Mp >= 4096 and ops.gemm_nt_splitk(dyT[n0:n1], xT, gw, accumulate=True):
                     pass  # 256x256 kernel, one (tile, K-slice) per CU, partials summed by a second kernel

@@ -682,8 +682,11 @@ def gemm_tn_splitk(a: torch.Tensor, b: torch.Tensor, out_f32: torch.Tensor, accu
         _chk(colsum, F32, "colsum")
         if colsum.numel() != Na:
             raise ValueError("gemm_tn_splitk: colsum must have Na elements")
-    check(lib.clibd_gemm_bf16_tn_splitk(a.data_ptr(), _rowmajor(a, "a"), b.data_ptr(), _rowmajor(b, "b"), M, Na, Nb, out_f32.data_ptr(), Nb,
-                                        int(accumulate), _p(colsum), ws.data_ptr(), ws.numel() * 4, _stream()), "gemm_bf16_tn_splitk")
+    rc = lib.clibd_gemm_bf16_tn_splitk(a.data_ptr(), _rowmajor(a, "a"), b.data_ptr(), _rowmajor(b, "b"), M, Na, Nb, out_f32.data_ptr(), Nb,
+                                       int(accumulate), _p(colsum), ws.data_ptr(), ws.numel() * 4, _stream())
+    if rc != 0 and b"shape not supported" in (lib.clibd_last_error() or b""):
+        return False    # declined before anything was enqueued: the caller takes the transpose + NT path
+    check(rc, "gemm_bf16_tn_splitk")
     return True
 
 
@@ -704,6 +707,9 @@ def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, out_f32: torch.Tensor, accu
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(((need + 3) // 4,), dtype=F32, device=a.device)   # one workspace per (device, stream)
         _splitk_ws[key] = ws
-    check(lib.clibd_gemm_bf16_nt_splitk(a.data_ptr(), _rowmajor(a, "a"), w.data_ptr(), _rowmajor(w, "w"), M, N, K, out_f32.data_ptr(), N,
-                                        int(accumulate), ws.data_ptr(), ws.numel() * 4, _stream()), "gemm_bf16_nt_splitk")
+    rc = lib.clibd_gemm_bf16_nt_splitk(a.data_ptr(), _rowmajor(a, "a"), w.data_ptr(), _rowmajor(w, "w"), M, N, K, out_f32.data_ptr(), N,
+                                       int(accumulate), ws.data_ptr(), ws.numel() * 4, _stream())
+    if rc != 0 and b"shape not supported" in (lib.clibd_last_error() or b""):
+        return False    # declined before anything was enqueued: the caller uses gemm_nt(split_k=)
+    check(rc, "gemm_bf16_nt_splitk")
     return True

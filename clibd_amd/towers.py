@@ -69,6 +69,14 @@ class _Tower:
         if self.on_grads_ready is not None:
             self.on_grads_ready(k)
 
+    def invalidate_weight_images(self):
+        """Forget every cached bf16 / fp8 image of the frozen weights (they were rewritten in place behind autograd's back,
+        e.g. by the trainer's start-up broadcast through `.data`): the next forward rebuilds them."""
+        self.stack._cache_key = None
+        for attr in ("_patch_key", "_head_key"):
+            if hasattr(self, attr):
+                setattr(self, attr, None)
+
     def _stack_groups(self, head, embed):
         n = len(self.stack.layers)
         return [head] + [self.stack.layer_params(i) for i in range(n - 1, -1, -1)] + [embed]

@@ -100,6 +100,11 @@ class Trainer:
                 for t in list(model.parameters()) + list(model.buffers()):
                     if id(t) not in own:
                         dist.broadcast(t.data, src=0)
+            # `.data` writes do not bump Parameter._version, which is all TransformerStack._key() watches: a forward that ran
+            # before this constructor (eval, fp8 calibration) would leave bf16 / fp8 weight images of the pre-broadcast values
+            for tw in _towers(model):
+                if hasattr(tw, "invalidate_weight_images"):
+                    tw.invalidate_weight_images()
         # let the towers accumulate parameter gradients straight into the optimizer's flat bucket
         sink = {id(p): p.grad for p in self.optimizer.param_groups[0]["params"]}
         for ti, tw in enumerate(_towers(model)):

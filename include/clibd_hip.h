@@ -29,6 +29,9 @@ extern "C" {
 
 const char* clibd_last_error(void);
 int clibd_abi_version(void);
+/* 16 hex digits identifying the kernel sources this library was built from (clibd_amd.build.csrc_hash()); "unknown" for a
+ * build outside clibd_amd/build.py.  The ctypes binding compares it with the sources beside it and refuses a stale library. */
+const char* clibd_build_hash(void);
 
 /* ------------------------------------------------------------------------------------------------
  * K2/K4/K5: bf16 MFMA GEMM  out = epilogue(A[M,K] · W[N,K]^T)   (nn.Linear layout)

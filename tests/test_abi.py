@@ -41,6 +41,17 @@ def test_python_binding_covers_every_declared_symbol(lib):
     assert _lib.load().clibd_abi_version() == 1
 
 
+def test_binding_refuses_a_library_built_from_other_sources(lib, monkeypatch):
+    """clibd_build_hash() (baked in by clibd_amd/build.py) must equal the hash of the sources beside the library."""
+    from clibd_amd import _lib, build
+
+    L = _lib.load()
+    assert L.clibd_build_hash().decode() == build.csrc_hash()
+    monkeypatch.setattr(build, "csrc_hash", lambda: "0123456789abcdef")
+    with pytest.raises(_lib.ClibdHipError, match="built from other kernel sources"):
+        _lib._check_build_hash(L)
+
+
 def test_epilogue_struct_layout_matches_header():
     from clibd_amd._lib import GemmEpilogue
 

@@ -183,3 +183,75 @@ def test_gradient_groups_cover_the_trainable_parameters_in_backward_order():
     assert {id(p) for p in ordered} == {id(p) for p in params} and len(ordered) == len(params)
     assert ordered[-1] is model.logit_scale and [len(c) for c in counts] == [5, 4, 4]
     assert sum(sum(c) for c in counts) == len(ordered) - 1
+
+
+def test_exported_checkpoint_carries_the_reference_position_id_buffers(tmp_path):
+    """a best.pth written here must load STRICTLY in the reference, whose pinned transformers 4.29.2 keeps
+    `embeddings.position_ids` as a persistent buffer of both BERT towers; and it must still load here."""
+    from clibd_amd.checkpoint import export_reference_state_dict, load_reference_checkpoint, save_reference_checkpoint
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, BertModel, CLIBDDNAEncoder, CLIBDLanguageEncoder, SimpleCLIP
+
+    tiny = dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128)
+    m = SimpleCLIP(None, CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, **tiny)), 4, 32),
+                   CLIBDLanguageEncoder(BertModel(BertConfigLite(vocab_size=100, **tiny)), 4, 32))
+    sd = export_reference_state_dict(m)
+    extra = sorted(set(sd) - set(m.state_dict()))
+    assert extra == ["dna_encoder.base_dna_encoder.bert.embeddings.position_ids",
+                     "language_encoder.base_language_encoder.embeddings.position_ids"]
+    for k in extra:
+        n = sd[k.replace("position_ids", "position_embeddings.weight")].shape[0]
+        assert sd[k].dtype == torch.int64 and torch.equal(sd[k], torch.arange(n)[None])
+    path = tmp_path / "best.pth"
+    save_reference_checkpoint(m, str(path))
+    res = load_reference_checkpoint(m, str(path))
+    assert not res.missing_keys and not res.unexpected_keys
+
+
+class _FakeFlatOptimizer:
+    """The attributes of optim.FusedAdamW that checkpoint.py touches (the real one needs a GPU)."""
+
+    def __init__(self, params):
+        self.param_groups = [dict(params=list(params), lr=1e-3)]
+        self._offsets, off = [], 0
+        for p in params:
+            self._offsets.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        self.exp_avg, self.exp_avg_sq, self.step_count = torch.zeros(off), torch.zeros(off), 0
+
+
+def test_training_state_records_and_remaps_the_optimizer_layout(tmp_path):
+    """the flat moment buffers are saved with (name, offset, numel) per parameter; a state saved under another
+    parameter order is re-mapped by name, one with other parameters (or no layout and another size) is refused loudly."""
+    from clibd_amd.checkpoint import load_training_state, save_training_state
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder, SimpleCLIP
+
+    tiny = dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128)
+    m = SimpleCLIP(None, CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, **tiny)), 4, 32), None)
+    train = [p for p in m.parameters() if p.requires_grad]
+    assert len(train) >= 4
+    a = _FakeFlatOptimizer(train)
+    for i, (p, off) in enumerate(zip(train, a._offsets)):
+        a.exp_avg[off:off + p.numel()] = i + 1.0
+        a.exp_avg_sq[off:off + p.numel()] = 10.0 * (i + 1)
+    a.step_count = 7
+    path = str(tmp_path / "state.pth")
+    save_training_state(path, m, a, epoch=2)
+    b = _FakeFlatOptimizer(train)                     # same layout: taken as is
+    assert load_training_state(path, m, b) == 2 and b.step_count == 7
+    assert torch.equal(b.exp_avg, a.exp_avg) and torch.equal(b.exp_avg_sq, a.exp_avg_sq)
+    c = _FakeFlatOptimizer(train[::-1])               # another order (e.g. other towers / fix_temperature): moved by name
+    load_training_state(path, m, c)
+    for i, p in enumerate(train):
+        j = len(train) - 1 - i
+        off = c._offsets[j]
+        assert float(c.exp_avg[off]) == i + 1.0 and float(c.exp_avg_sq[off + p.numel() - 1]) == 10.0 * (i + 1)
+    extra = torch.nn.Parameter(torch.zeros(5))
+    d = _FakeFlatOptimizer(train + [extra])           # a parameter the state has no moments for
+    with pytest.raises(ValueError, match="lacks optimizer moments"):
+        load_training_state(path, m, d)
+    st = torch.load(path, weights_only=False)
+    del st["optimizer"]["layout"]                      # a state from before the layout was recorded
+    torch.save(st, path)
+    load_training_state(path, m, _FakeFlatOptimizer(train))
+    with pytest.raises(ValueError, match="no optimizer layout"):
+        load_training_state(path, m, d)

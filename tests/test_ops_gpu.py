@@ -824,7 +824,10 @@ def test_gemm_splitk_workspace_exact(ops, dev, M, N, K):
 
 
 @pytest.mark.parametrize("M,Na,Nb,ld_extra", [(50432, 768, 768, 0), (34048, 3072, 768, 0), (256, 256, 256, 0), (4096 + 128, 768, 2304, 8),
-                                              (640, 512, 256, 0), (50432, 2304, 768, 0)])
+                                              (640, 512, 256, 0), (50432, 2304, 768, 0),
+                                              # M values whose first K-slice plan leaves a tail < 4 K-tiles: 6272 = ViT patch-embed
+                                              # rows at per-GPU batch 32, 3200 = text tower at batch 160, and the next few of that family
+                                              (6272, 768, 768, 0), (3200, 768, 768, 0), (1664, 768, 768, 0), (12928, 768, 768, 0), (4736, 512, 512, 8)])
 def test_gemm_tn_splitk_exact(ops, dev, M, Na, Nb, ld_extra):
     """Rows-contracting GEMM (weight gradient without transposes): out[Na,Nb] (+)= a[M,Na]^T b[M,Nb] — exact small-integer
     products (every k-slot of every fragment matters: position-dependent values), accumulate semantics, operands that are
