@@ -25,6 +25,14 @@ Pinning status:
 `precision("bf16")` switches every linear layer / attention product to bf16-rounded operands with fp32
 accumulation — the same rounding points as the HIP kernels (torch.autocast(bf16) in the reference,
 epoch/train_epoch.py:42-46); `precision("fp32")` is the reference's CPU path.
+
+`precision("fp8")` (BASELINE.json configs[4]; the reference has no such mode, so this one is pinned to the reference only
+through the bf16 mode it extends): the bf16 mode with the four forward GEMMs of every transformer layer (QKV, attention
+output, fc1, fc2) evaluated on OCP e4m3 operands exactly as the kernels quantise them — the activation as
+e4m3(clamp(value x scale, +-448)) taken from the producer's fp32 value, the frozen weight per output row as
+e4m3(w x 448 / max|w_row|), fp32 accumulation, de-quantisation by 1 / (row scale x activation scale) — while the backward
+stays the bf16 network's (dgrad through the bf16 weight, straight-through quantisers).  Scales per layer and site come from
+`set_fp8_scales` (the values the HIP towers use) or default to FP8_SCALES.
 """
 from __future__ import annotations
 
@@ -43,7 +51,7 @@ _PRECISION = "fp32"
 @contextlib.contextmanager
 def precision(mode: str):
     global _PRECISION
-    assert mode in ("fp32", "bf16")
+    assert mode in ("fp32", "bf16", "fp8")
     old, _PRECISION = _PRECISION, mode
     try:
         yield
@@ -123,11 +131,70 @@ def _hidden_drop(y, layer, site):
     return y * drop_factor(derive_seed(base, layer, site), idx, p_h).to(y.dtype)
 
 
-def olinear(x, weight, bias=None, round_out=True):
+# ---- fp8-forward mode (clibd_amd.engine.TransformerStack.enable_fp8) ------------------------------------
+FP8_SITES = ("qkv_in", "proj_in", "fc1_in", "fc2_in")          # activation sites, named by the GEMM that consumes them
+FP8_SCALES = dict(qkv_in=8.0, proj_in=32.0, fc1_in=8.0, fc2_in=4.0)
+_E4M3_MAX = 448.0
+
+
+def e4m3(x: torch.Tensor) -> torch.Tensor:
+    """values of OCP e4m3 (round to nearest even, saturating at +-448): what v_cvt_pk_fp8_f32 gives on clamped inputs"""
+    return x.clamp(-_E4M3_MAX, _E4M3_MAX).to(torch.float8_e4m3fn).to(x.dtype)
+
+
+def quantize_rows_e4m3(w: torch.Tensor):
+    """per output channel: (e4m3(w_n * s_n), s_n) with s_n = 448 / max_k |w_nk| (1 for an all-zero row) — clibd_quantize_rows_fp8"""
+    amax = w.abs().amax(dim=1, keepdim=True)
+    s = torch.where(amax > 0, _E4M3_MAX / amax, torch.ones_like(amax))
+    return e4m3(w * s), s
+
+
+class _Fp8Linear(torch.autograd.Function):
+    """forward: (e4m3(x * sa) @ e4m3(w * s_n)^T) / (s_n * sa) in fp32;  backward: the bf16 network's dgrad dy_bf16 @ w_bf16
+    (no weight gradient: the mode needs frozen base weights)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, sa):
+        w8, sn = quantize_rows_e4m3(weight.detach().float())
+        ctx.save_for_backward(weight)
+        return F.linear(e4m3(x.detach().float() * sa), w8) * (1.0 / (sn * sa)).view(-1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        return rb(dy) @ rb(weight.detach()), None, None
+
+
+def set_fp8_scales(layers, per_layer=None, last_block_qkv_only: bool = False):
+    """Attach the per-layer activation scales of the fp8 mode to a stack of oracle layers (ViT `blocks` or BERT
+    `encoder.layer`): per_layer = [{site: scale}] as in TransformerStack.fp8 (None: FP8_SCALES everywhere).
+    last_block_qkv_only: the ViT tower evaluates its last block on the class row only and keeps that remainder
+    (projection, MLP) in bf16 (clibd_amd/engine.py, cls_only_last)."""
+    n = len(layers)
+    for i, layer in enumerate(layers):
+        d = dict(FP8_SCALES if per_layer is None else per_layer[i])
+        if last_block_qkv_only and i == n - 1:
+            d = {"qkv_in": d["qkv_in"]}
+        for m in layer.modules():
+            m._fp8 = d
+
+
+def _fp8_scale(module, site):
+    if _PRECISION != "fp8":
+        return None
+    d = getattr(module, "_fp8", None)
+    if d is None:
+        d = FP8_SCALES
+    return d.get(site)
+
+
+def olinear(x, weight, bias=None, round_out=True, fp8_scale=None):
     """nn.Linear with the kernels' rounding points: bf16 operands, fp32 accumulate, fp32 bias, bf16 output.
     round_out=False: the GEMM epilogue keeps fp32 (residual add / fp32 head output fused before any rounding);
-    the gradient entering the GEMM is still bf16 (the dgrad GEMM's A operand)."""
-    y = F.linear(_r(x), _r(weight), None)
+    the gradient entering the GEMM is still bf16 (the dgrad GEMM's A operand).
+    fp8_scale (fp8 mode, one of the four layer GEMMs): e4m3 operands, x quantised from its fp32 value with that scale."""
+    y = _Fp8Linear.apply(x, weight, float(fp8_scale)) if fp8_scale is not None else F.linear(_r(x), _r(weight), None)
     if bias is not None:
         y = y + bias
     return _rg(_r(y) if round_out else y)
@@ -167,8 +234,9 @@ def _attn_drop(shape, layer):
     return drop_factor(derive_seed(base, layer, 0), ((bh * Sq + q) << 8) + key, p_a)
 
 
-def attention_core(q, k, v, mask_add=None, layer=None):
-    """q,k,v [B,h,S,dh]; scores and softmax in fp32, probabilities rounded to bf16 before P·V (bf16 mode)."""
+def attention_core(q, k, v, mask_add=None, layer=None, round_out=True):
+    """q,k,v [B,h,S,dh]; scores and softmax in fp32, probabilities rounded to bf16 before P·V (bf16 mode).
+    round_out=False (fp8 mode): the kernel converts its fp32 result straight to e4m3, with no bf16 rounding in between."""
     s = (_r(q) @ _r(k).transpose(-1, -2)) * (q.shape[-1] ** -0.5)
     if mask_add is not None:
         s = s + mask_add
@@ -180,7 +248,8 @@ def attention_core(q, k, v, mask_add=None, layer=None):
     # and the fp32 row sum divides the fp32 result (same function as softmax, same relative rounding error)
     e = torch.exp(s - s.max(dim=-1, keepdim=True).values.detach())
     em = e if fm is None else e * fm.to(e.dtype)
-    return _rg(_r((_r(em) @ _r(v)) / e.sum(dim=-1, keepdim=True)))
+    o = (_r(em) @ _r(v)) / e.sum(dim=-1, keepdim=True)
+    return _rg(_r(o) if round_out else o)
 
 
 class Attention(nn.Module):
@@ -193,10 +262,12 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x) if not isinstance(self.qkv, nn.Linear) else olinear(x, self.qkv.weight, self.qkv.bias)
+        qkv = self.qkv(x) if not isinstance(self.qkv, nn.Linear) else olinear(x, self.qkv.weight, self.qkv.bias,
+                                                                              fp8_scale=_fp8_scale(self, "qkv_in"))
         q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
-        o = attention_core(q, k, v).transpose(1, 2).reshape(B, N, C)
-        return olinear(o, self.proj.weight, self.proj.bias, round_out=False)
+        sp = _fp8_scale(self, "proj_in")
+        o = attention_core(q, k, v, round_out=sp is None).transpose(1, 2).reshape(B, N, C)
+        return olinear(o, self.proj.weight, self.proj.bias, round_out=False, fp8_scale=sp)
 
 
 class Mlp(nn.Module):
@@ -206,8 +277,10 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        h = olinear(x, self.fc1.weight, self.fc1.bias)
-        return olinear(_rg(_r(gelu_erf(h))), self.fc2.weight, self.fc2.bias, round_out=False)
+        h = olinear(x, self.fc1.weight, self.fc1.bias, fp8_scale=_fp8_scale(self, "fc1_in"))
+        s2 = _fp8_scale(self, "fc2_in")   # fp8: the fc1 epilogue converts gelu(bf16(h)) (fp32) straight to e4m3
+        a = gelu_erf(h)
+        return olinear(_rg(_r(a) if s2 is None else a), self.fc2.weight, self.fc2.bias, round_out=False, fp8_scale=s2)
 
 
 class Block(nn.Module):
@@ -263,7 +336,8 @@ class LoRAQKV(nn.Module):
 
     def forward(self, x):
         # the kernel adds bias after the rank update and rounds once; algebraically the same sum
-        base = F.linear(_r(x), _r(self.qkv.weight), None)
+        s8 = _fp8_scale(self, "qkv_in")   # fp8: only the base product runs on e4m3 operands; the adapters stay bf16
+        base = F.linear(_r(x), _r(self.qkv.weight), None) if s8 is None else _Fp8Linear.apply(x, self.qkv.weight, float(s8))
         tq = olinear(x, self.linear_a_q.weight)
         tv = olinear(x, self.linear_a_v.weight)
         dq = F.linear(_r(tq), _r(self.linear_b_q.weight))
@@ -316,7 +390,8 @@ class LoRALinear(nn.Module):
         self.in_features = w.in_features
 
     def forward(self, x):
-        base = F.linear(_r(x), _r(self.w.weight), None)
+        s8 = _fp8_scale(self, "qkv_in")
+        base = F.linear(_r(x), _r(self.w.weight), None) if s8 is None else _Fp8Linear.apply(x, self.w.weight, float(s8))
         t = olinear(x, self.w_a.weight)
         out = base + F.linear(_r(t), _r(self.w_b.weight)) + self.w.bias
         return _rg(_r(out))
@@ -324,7 +399,7 @@ class LoRALinear(nn.Module):
 
 def _lin(mod, x):
     if isinstance(mod, nn.Linear):
-        return olinear(x, mod.weight, mod.bias)
+        return olinear(x, mod.weight, mod.bias, fp8_scale=_fp8_scale(mod, "qkv_in"))
     return mod(x)
 
 
@@ -352,7 +427,8 @@ class _SelfAttn(nn.Module):
     def forward(self, x, mask_add, layer=None):
         B, S, Hd = x.shape
         sp = lambda t: t.view(B, S, self.heads, Hd // self.heads).transpose(1, 2)
-        o = attention_core(sp(_lin(self.query, x)), sp(_lin(self.key, x)), sp(_lin(self.value, x)), mask_add, layer)
+        o = attention_core(sp(_lin(self.query, x)), sp(_lin(self.key, x)), sp(_lin(self.value, x)), mask_add, layer,
+                           round_out=_fp8_scale(self, "proj_in") is None)
         return o.transpose(1, 2).reshape(B, S, Hd)
 
 
@@ -362,8 +438,8 @@ class _DenseLN(nn.Module):
         self.dense = nn.Linear(din, dout)
         self.LayerNorm = nn.LayerNorm(dout, eps=eps)
 
-    def forward(self, x, residual, layer=None, site=None):
-        y = olinear(x, self.dense.weight, self.dense.bias, round_out=False)
+    def forward(self, x, residual, layer=None, site=None, fp8_site=None):
+        y = olinear(x, self.dense.weight, self.dense.bias, round_out=False, fp8_scale=_fp8_scale(self, fp8_site) if fp8_site else None)
         if layer is not None:
             y = _hidden_drop(y, layer, site)
         return self.LayerNorm(y + residual)
@@ -390,9 +466,10 @@ class BertLayer(nn.Module):
         self.output = _DenseLN(ff, hidden, eps)
 
     def forward(self, x, mask_add=None, layer=None):
-        a = self.attention.output(self.attention.self(x, mask_add, layer), x, layer, 1)
-        h = olinear(a, self.intermediate.dense.weight, self.intermediate.dense.bias)
-        return self.output(_rg(_r(gelu_erf(h))), a, layer, 2)
+        a = self.attention.output(self.attention.self(x, mask_add, layer), x, layer, 1, "proj_in")
+        h = olinear(a, self.intermediate.dense.weight, self.intermediate.dense.bias, fp8_scale=_fp8_scale(self, "fc1_in"))
+        g = gelu_erf(h)
+        return self.output(_rg(_r(g) if _fp8_scale(self, "fc2_in") is None else g), a, layer, 2, "fc2_in")
 
 
 class _Encoder(nn.Module):

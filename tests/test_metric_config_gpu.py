@@ -108,6 +108,85 @@ def test_b2048_training_step_runs_and_learns(dev, big):
     assert torch.isfinite(tr.optimizer.flat_p).all()
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: BIOSCAN-5M-shaped run, per-GPU batch 1024 of a global batch 8192, fp8 MFMA GEMM path
+# (reference shape: config/model_config/for_bioscan_5m/final_experiments/image_dna_seed_42.yaml:1-2).  Same property style:
+# the oracle cannot run b=1024 in seconds, so the rows are tied to b=256 forwards (which ARE oracle-checked at small batch,
+# tests/test_fp8_gpu.py) bit for bit, the rank-local 1024 x 8192 loss block to a CPU statement, and a step must learn.
+B5, N5 = 1024, 8192
+
+
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
+def test_b1024_rows_equal_chunked_and_block_loss_matches_cpu(dev, big, fp8):
+    from clibd_amd import ops
+    from clibd_amd.data import synthetic_batch
+
+    model, batch = big
+    img, dna = batch["image"][:B5], batch["dna"][:B5]
+    if fp8:
+        model.enable_fp8_forward(calibration_inputs=(img, dna, None))   # per-layer scales from this batch; fixed for every call below
+    try:
+        with torch.no_grad():
+            i_full, d_full, _, scale, _ = model(img, dna, None)
+            chunks = [model(img[s : s + CH], dna[s : s + CH], None) for s in range(0, B5, CH)]
+            # the other seven ranks' rows of the global batch 8192 (their own synthetic batches)
+            others = []
+            for r in range(1, N5 // B5):
+                ob = synthetic_batch(B5, dev, seed=42, rank=r, with_text=False)
+                oi, od, _, _, _ = model(ob["image"], ob["dna"], None)
+                others.append((oi, od, ob["labels"]))
+        model.join_streams()
+        torch.cuda.synchronize()
+    finally:
+        if fp8:
+            model.enable_fp8_forward(enabled=False)
+    for full, k in ((i_full, 0), (d_full, 1)):
+        ch = torch.cat([c[k] for c in chunks])
+        assert torch.isfinite(full).all()
+        assert (full - ch).abs().max().item() <= 1e-6, (k, (full - ch).abs().max().item())     # 1024 = 4 x 256, same per-row arithmetic
+        assert torch.allclose(full.norm(dim=1), torch.ones(B5, device=dev), atol=1e-4)
+    # rank 0's row block of the directed terms image->dna and dna->image over the global batch (what ClipLoss evaluates per rank)
+    all_i = torch.cat([i_full] + [o[0] for o in others]).contiguous()
+    all_d = torch.cat([d_full] + [o[1] for o in others]).contiguous()
+    labels = torch.cat([batch["labels"][:B5]] + [o[2] for o in others]).contiguous()
+    assert labels.numel() == N5 and labels.unique().numel() == N5
+    labels[5] = labels[4]                      # one duplicate pair inside the block, one across ranks: multi-hot target rows
+    labels[B5 + 7] = labels[9]
+    scale_t = scale.detach().to(F32).reshape(1).contiguous()
+    loss_sum = torch.zeros((1,), dtype=F32, device=dev)
+    for x, y in ((i_full, all_d), (d_full, all_i)):
+        ws = ops.softce_workspace(B5, N5, 768, dev)
+        ops.softce_rows_fwd(x.contiguous(), y, labels, 0, scale_t, loss_sum, ws)
+    torch.cuda.synchronize()
+    got = float(loss_sum) / (2 * N5)
+    xi, xd, ai, ad, lab, sc = i_full.double().cpu(), d_full.double().cpu(), all_i.double().cpu(), all_d.double().cpu(), labels.cpu(), float(scale)
+    T = (lab[:B5, None] == lab[None, :]).double()
+    ref = 0.0
+    for x, y in ((xi, ad), (xd, ai)):
+        ref += float(-(T * torch.log_softmax(sc * x @ y.T, dim=1)).sum())
+    ref /= 2 * N5
+    assert abs(got - ref) < 1e-3 * max(1.0, abs(ref)), (got, ref)          # this rank's share of the N = 8192 loss
+    assert 0.0 < got * (N5 // B5) < math.log(N5) + 1.0, got                 # a share of a loss that starts at ln 8192
+
+
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
+def test_b1024_training_step_runs_and_learns(dev, big, fp8):
+    from clibd_amd.train import Trainer
+
+    model, batch = big
+    img, dna, labels = batch["image"][:B5], batch["dna"][:B5], batch["labels"][:B5]
+    tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True, fp8_recalibrate_every=2 if fp8 else 0)
+    try:
+        losses = [float(tr.step(img, dna, None, labels)) for _ in range(3)]
+    finally:
+        model.enable_fp8_forward(enabled=False)
+        for enc in (model.image_encoder, model.dna_encoder):
+            enc.tower().grad_sink = None
+    assert all(math.isfinite(l) for l in losses)
+    assert abs(losses[0] - math.log(B5)) < 0.6 and losses[-1] < losses[0], losses
+    assert torch.isfinite(tr.optimizer.flat_p).all()
+
+
 def test_gemm_operand_beyond_4gib_takes_the_64bit_kernel(dev):
     """A [M,K] bf16 operand of 4.3 GB: the 256x256 kernel addresses operands with 32-bit byte offsets and must decline
     (csrc/gemm256.hip gemm256_try_launch); the 128x128 kernel takes it.  Exact on integer data."""
