@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
     ap.add_argument("--fp8-forward", action="store_true", help="BASELINE configs[4]: forward GEMMs on the fp8 MFMA (not the headline config)")
     ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
+    ap.add_argument("--eval", action="store_true", help="eval path (SURVEY §8f-2, not the headline metric): no-grad embedding forward + K10 top-k search")
+    ap.add_argument("--eval-queries", type=int, default=1024, help="--eval: queries per top-k launch")
+    ap.add_argument("--eval-keys", type=int, default=409600, help="--eval: size of the key bank (BIOSCAN-5M-sized by default; 21000 = BIOSCAN-1M)")
     return ap.parse_args()
 
 
@@ -197,6 +200,101 @@ def cpu_baseline(batch: int, steps: int):
                       f"then median of {len(times)} steps at {threads} threads ({', '.join(f'{t:.1f}' for t in times)} s), loss {loss:.4f}"}
 
 
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X fp32-input MFMA = the fp32 vector rate (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBPS = 8000.0
+
+
+def eval_bench(args, model, batch, b, world, rank, dev, dist, timer):
+    """`--eval`: the inference side of the path (reference epoch/inference_epoch.py:43-111 + util/util.py:521-528).
+    value = paired samples/s of the no-grad embedding forward (both towers, L2-normalise), whole job; `roofline` = the forward
+    GEMMs against the bf16 MFMA peak; `k10` = the streaming top-k search of `--eval-queries` image embeddings against a key
+    bank of `--eval-keys` unit vectors (exact fp32 scores on the fp32 MFMA: bound by that pipe, 2 Q Nk D FLOP at 157 TFLOP/s;
+    its bytes — the bank is streamed once per 64-query block out of L2 / Infinity Cache — are quoted against HBM peak too)."""
+    from clibd_amd import ops
+
+    model.eval()
+
+    def fwd():
+        with torch.no_grad():
+            out = model(batch["image"], batch["dna"], batch["text"])
+        model.join_streams()
+        return out
+
+    for _ in range(args.warmup):
+        out = fwd()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = fwd()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    gemm = None
+    if not args.no_gemm_timing:
+        model.overlap_towers = False            # per-launch durations of the kernel itself (towers serialized), as in the training line
+        fwd()
+        torch.cuda.synchronize()
+        timer.enabled = True
+        for _ in range(min(args.steps, 5)):
+            fwd()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        model.overlap_towers = True
+        gemm = timer.result()
+        gemm["steps"] = min(args.steps, 5)
+    k10 = None
+    if rank == 0:
+        Q, Nk, D, k = min(args.eval_queries, b), args.eval_keys, out[0].shape[1], 5
+        g = torch.Generator(device=dev).manual_seed(7)
+        keys = torch.nn.functional.normalize(torch.randn((Nk, D), generator=g, device=dev), dim=1)
+        q = out[0][:Q].detach().float().contiguous()
+        ops.topk_ip(q, keys, k)                  # warm-up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 2
+        e0.record()
+        for _ in range(reps):
+            sim, idx = ops.topk_ip(q, keys, k)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flops = 2.0 * Q * Nk * D
+        algo_bytes = 4.0 * D * (Q + Nk) + 12.0 * Q * k
+        k10 = {"kernel": "topk_ip_stream_kernel (fused exact-fp32 scores + running top-8, no Q x Nk matrix)", "queries": Q, "keys": Nk, "dim": D,
+               "k": k, "ms_per_launch": ms, "bound": "mfma-fp32", "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+               "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+               "queries_per_s": Q / (ms * 1e-3), "algorithmic_GBps": algo_bytes / (ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS,
+               "hbm_frac": algo_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+               "note": "exact fp32 inner products (faiss.IndexFlatIP semantics, indices bit-exact) run on the fp32-input MFMA at 1/16 of the "
+                       "bf16 rate: the search is bound by that pipe, not by HBM (the key bank is 4 D Nk bytes, read once per 64-query block "
+                       "from L2 / Infinity Cache)"}
+    if rank == 0:
+        GF_PER_PAIR_FWD = 58.78   # BASELINE.md §3: ViT-B/16 35.18 + BarcodeBERT 23.60 GFLOP per pair, forward
+        pairs_per_s = b * world * args.steps / elapsed
+        roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "kernel": "gemm256_bf16_nt_kernel (forward kinds)", "step_frac": pairs_per_s * GF_PER_PAIR_FWD * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12),
+                "traffic_note": "no PMC pass for the eval path"}
+        if gemm:
+            roof.update(achieved=gemm["tflops"], frac=gemm["frac"], launches=gemm["launches"], gemm_ms_per_step=gemm["total_ms"] / gemm["steps"],
+                        avg_launch_us=gemm["total_ms"] / gemm["launches"] * 1e3, algorithmic_bytes_per_launch=gemm["bytes_per_launch"])
+        out_line = {"metric": f"eval: paired samples/sec, no-grad embedding forward (I+D), batch {b * world}", "value": pairs_per_s,
+                    "unit": "paired samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                    "higher_is_better": True, "scaling": "strong" if args.per_gpu_batch is None else "weak", "vs_baseline": None, "dtype": "bf16",
+                    "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights, random unit key bank)",
+                    "config": {"workload": f"eval path (secondary, SURVEY 8f-2): get_feature_and_label-style no-grad forward of ViT-B/16 + BarcodeBERT at "
+                                           f"{world} GPU x {b}, then top-5 inner-product search", "per_gpu_batch": b, "global_batch": b * world,
+                               "parallelism": f"dp{world}"},
+                    "roofline": roof, "k10": k10}
+        print(json.dumps(out_line), flush=True)
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher (the reference starts its own ranks too: scripts/train_cl.py:365 mp.spawn):
     start `torch.distributed.run` with N fresh rank processes as a CHILD of this process — which has not touched the GPU
@@ -274,6 +372,11 @@ def main():
     timer = GemmTimer()
     if not args.no_gemm_timing:
         timer.install()
+    if args.eval:
+        eval_bench(args, model, batch, b, world, rank, dev, dist, timer)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     def one_step():
         return trainer.step(batch["image"], batch["dna"], batch["text"], batch["labels"])

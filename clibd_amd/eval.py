@@ -1,6 +1,6 @@
-"""Eval-side counterparts on the device ("next" rows SURVEY §8f-1/2): k-mer tokenisation of raw barcodes and the top-k
-retrieval of `make_prediction` (reference bioscanclip/util/util.py:521-553: sklearn L2-normalise -> faiss.IndexFlatIP ->
-search(query, max_k) -> label lookup)."""
+"""Eval-side counterparts on the device ("next" rows SURVEY §8f-1/2): k-mer tokenisation of raw barcodes, the embedding loop
+`get_feature_and_label` (reference bioscanclip/epoch/inference_epoch.py:43-111) and the top-k retrieval of `make_prediction`
+(reference bioscanclip/util/util.py:521-553: sklearn L2-normalise -> faiss.IndexFlatIP -> search(query, max_k) -> label lookup)."""
 from __future__ import annotations
 
 from typing import List, Sequence
@@ -18,6 +18,63 @@ def tokenize_barcodes(sequences: Sequence[str], device, max_len: int = 660, k: i
     buf = b"".join(s[:max_len].ljust(max_len, "N").encode("ascii", "replace") for s in sequences)
     seq = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8).reshape(len(sequences), max_len).copy()).to(device)
     return ops.kmer_tokenize(seq, k)
+
+
+def convert_label_dict_to_list_of_dict(label_batch: dict) -> List[dict]:
+    """inference_epoch.py:8-20: {level: [labels of the batch]} -> [{level: label} per sample]"""
+    return [{"order": o, "family": f, "genus": g, "species": s_}
+            for o, f, g, s_ in zip(label_batch["order"], label_batch["family"], label_batch["genus"], label_batch["species"])]
+
+
+def get_feature_and_label(dataloader, model, device, for_open_clip=False, multi_gpu=False, as_numpy=True):
+    """The reference's embedding loop (inference_epoch.py:43-111) without its per-batch `.cpu().tolist()` round trips:
+    every batch runs the towers under no_grad, the second `F.normalize` of the reference (:87-92) is the L2-norm kernel, and
+    the embeddings stay on the device until ONE copy at the end.
+
+    Batches are the reference's 7-tuples (processid, image, dna, input_ids, token_type_ids, attention_mask, label dict);
+    `dna` may be a tensor of token ids or a list of raw barcode strings (tokenised by the 5-mer kernel; the remote
+    BarcodeBERT tokenizer of the newer checkpoints is out of scope, SURVEY §8a-a5').
+    Returns (file_name_list, image_features, dna_features, text_features, label_list) like the reference — features as
+    float32 numpy arrays [N, D] (as_numpy=True; the reference builds float64 arrays of the same fp32 values) or as device
+    tensors (as_numpy=False, e.g. to feed `make_prediction` without leaving the GPU); None for an absent tower."""
+    if for_open_clip:
+        raise NotImplementedError("open_clip towers are out of scope (DESIGN §8)")
+    dev = torch.device(device)
+    feats = ([], [], [])
+    label_list, file_name_list = [], []
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            for batch in dataloader:
+                processid_batch, image_input_batch, dna_input_batch, input_ids, token_type_ids, attention_mask, label_batch = batch
+                language_input = None
+                if getattr(model, "language_encoder", None) is not None:
+                    language_input = {"input_ids": input_ids.to(dev), "token_type_ids": token_type_ids.to(dev),
+                                      "attention_mask": attention_mask.to(dev)}
+                if torch.is_tensor(dna_input_batch):
+                    dna_input_batch = dna_input_batch.to(dev)
+                elif getattr(model, "dna_encoder", None) is not None:
+                    dna_input_batch = tokenize_barcodes(list(dna_input_batch), dev)
+                image_in = image_input_batch.to(dev) if getattr(model, "image_encoder", None) is not None else None
+                outs = model(image_in, dna_input_batch, language_input)[:3]
+                for store, out in zip(feats, outs):
+                    if out is not None:
+                        store.append(ops.l2norm_fwd(out.detach().to(torch.float32).contiguous())[0])
+                label_list.extend(convert_label_dict_to_list_of_dict(label_batch))
+                file_name_list.extend(list(processid_batch))
+        if hasattr(model, "join_streams"):
+            model.join_streams()
+    finally:
+        model.train(was_training)
+    out = []
+    for store in feats:
+        if not store:
+            out.append(None)
+        else:
+            t = torch.cat(store, dim=0)
+            out.append(t.cpu().numpy() if as_numpy else t)
+    return file_name_list, out[0], out[1], out[2], label_list
 
 
 def topk_search(query_feature: torch.Tensor, keys_feature: torch.Tensor, max_k: int = 5):

@@ -568,8 +568,9 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
                                        float(eps), float(weight_decay), int(step), float(grad_scale), _stream()), "adamw_step")
 
 
-def topk_ip(q: torch.Tensor, keys: torch.Tensor, k: int = 5, chunk: int = 8192):
-    """Exact fp32 inner-product top-k (faiss.IndexFlatIP.search): returns (similarities fp32 [Q,k], indices int64 [Q,k])."""
+def topk_ip(q: torch.Tensor, keys: torch.Tensor, k: int = 5):
+    """Exact fp32 inner-product top-k (faiss.IndexFlatIP.search): returns (similarities fp32 [Q,k], indices int64 [Q,k]).
+    Streaming: scores never leave the MFMA accumulators' running top-8 lists (no [Q,Nk] matrix)."""
     _chk(q, F32, "q")
     _chk(keys, F32, "keys")
     Q, D = q.shape
@@ -579,11 +580,9 @@ def topk_ip(q: torch.Tensor, keys: torch.Tensor, k: int = 5, chunk: int = 8192):
     idx = torch.empty((Q, k), dtype=I64, device=q.device)
     sim = torch.empty((Q, k), dtype=F32, device=q.device)
     lib = _lib.load()
-    ws = torch.empty((lib.clibd_topk_ip_workspace_bytes(min(Q, chunk), Nk),), dtype=torch.uint8, device=q.device)
-    for s0 in range(0, Q, chunk):
-        n = min(chunk, Q - s0)
-        check(lib.clibd_topk_ip(q[s0:].data_ptr(), keys.data_ptr(), n, Nk, D, k, idx[s0:].data_ptr(), sim[s0:].data_ptr(), ws.data_ptr(),
-                                ws.numel(), _stream()), "topk_ip")
+    ws = torch.empty((max(int(lib.clibd_topk_ip_workspace_bytes(Q, Nk)), 16),), dtype=torch.uint8, device=q.device)
+    check(lib.clibd_topk_ip(q.data_ptr(), keys.data_ptr(), Q, Nk, D, k, idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "topk_ip")
     return sim, idx
 
 

@@ -271,7 +271,8 @@ int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D, int row0,
  * K10 ("next" row §8f-2): exact fp32 inner-product top-k — faiss.IndexFlatIP.search(query, k) in the reference's eval
  * path (util/util.py:521-528, make_prediction; callers L2-normalise first, clibd_l2norm_fwd).  q [Q,D], keys [Nk,D]
  * fp32; out_idx int64 [Q,k] (ties -> lower key index), out_sim fp32 [Q,k]; 1 <= k <= 8; D % 4 == 0.  Scores use the
- * fp32-input MFMA (exact fp32 products, fmaf chain).  workspace: clibd_topk_ip_workspace_bytes(Q, Nk) (the [Q,Nk] scores).
+ * fp32-input MFMA (exact fp32 products, fmaf chain) and go from the accumulators into running top-8 lists in registers: the
+ * [Q,Nk] score matrix is never written.  workspace: clibd_topk_ip_workspace_bytes(Q, Nk) (per-key-split lists, <= 16 KiB per query).
  * ------------------------------------------------------------------------------------------------ */
 size_t clibd_topk_ip_workspace_bytes(int Q, int Nk);
 int clibd_topk_ip(const float* q, const float* keys, int Q, int Nk, int D, int k, int64_t* out_idx, float* out_sim,

@@ -838,3 +838,53 @@ def test_training_trajectory_matches_oracle(dev):
     du_h = torch.cat([(hp[n] - start[n]).flatten() for n in sorted(start)])
     du_o = torch.cat([(dict(om.named_parameters())[n].detach() - start[n]).flatten() for n in sorted(start)])
     assert cos(du_h, du_o) > 0.98 and rel(du_h, du_o) < 0.2, (cos(du_h, du_o), rel(du_h, du_o))
+
+
+def test_get_feature_and_label_matches_the_reference_loop(dev):
+    """clibd_amd.eval.get_feature_and_label against the oracle running the reference's loop body
+    (epoch/inference_epoch.py:56-96: eval mode, no_grad, model(...), F.normalize, extend the label / file-name lists) on the
+    reference's 7-tuple batches — including a batch whose barcodes arrive as raw strings, a ragged last batch, and the
+    device-tensor return feeding make_prediction without a host round trip."""
+    import random
+
+    from clibd_amd.eval import LEVELS, get_feature_and_label, make_prediction
+    from clibd_amd.model import SimpleCLIP
+    from oracle import clibd_oracle as O
+    from tests.test_oracle import build_dna, build_image, build_text
+
+    gd, gt, gi = load("dna_tiny_golden.pt"), load("text_tiny_golden.pt"), load("image_tiny_golden.pt")
+    model = SimpleCLIP(hip_image(gi, dev), hip_dna(gd, dev), hip_text(gt, dev)).to(dev)
+    om = O.SimpleCLIP(build_image(gi), build_dna(gd), build_text(gt))
+    rnd = random.Random(4)
+    g = torch.Generator().manual_seed(8)
+    batches, sizes = [], (5, 5, 3)
+    for bi, n in enumerate(sizes):
+        seqs = ["".join(rnd.choice("ACGT") for _ in range(rnd.choice((400, 660, 700)))) for _ in range(n)]
+        dna = seqs if bi == 1 else torch.tensor([O.kmer_tokenize(s) for s in seqs])
+        ids = torch.randint(0, gt["vocab"], (n, 20), generator=g)
+        lens = torch.randint(6, 21, (n,), generator=g)
+        labels = {lv: [f"{lv}_{bi}_{i}" for i in range(n)] for lv in LEVELS}
+        batches.append(([f"P{bi}_{i}" for i in range(n)], torch.rand(n, 3, 224, 224, generator=g), dna, ids, torch.zeros_like(ids),
+                        (torch.arange(20)[None] < lens[:, None]).long(), labels, seqs))
+    loader = [b[:7] for b in batches]
+    model.train()     # the loop must switch to eval (dropout off) and restore the mode afterwards
+    names, fi, fd, ft, lab = get_feature_and_label(loader, model, dev)
+    assert model.training
+    assert names == [f"P{bi}_{i}" for bi, n in enumerate(sizes) for i in range(n)]
+    assert lab[6] == {lv: f"{lv}_1_1" for lv in LEVELS} and len(lab) == sum(sizes)
+    ref = ([], [], [])
+    with torch.no_grad(), O.precision("bf16"):
+        for b in batches:
+            ids = torch.tensor([O.kmer_tokenize(s) for s in b[7]])
+            outs = om(b[1], ids, {"input_ids": b[3], "token_type_ids": b[4], "attention_mask": b[5]})[:3]
+            for store, o in zip(ref, outs):
+                store.append(torch.nn.functional.normalize(o, dim=-1))
+    for got, want in zip((fi, fd, ft), ref):
+        want = torch.cat(want)
+        assert got.dtype.name == "float32" and got.shape == tuple(want.shape)
+        assert (torch.from_numpy(got) - want).abs().max().item() < 2e-3
+    _, ti, td, _, _ = get_feature_and_label(loader, model, dev, as_numpy=False)
+    assert ti.is_cuda and torch.equal(ti.cpu(), torch.from_numpy(fi))
+    pred, idx = make_prediction(ti, td, lab, with_indices=True, max_k=3)      # image queries against the DNA keys, on the device
+    _, oidx = O.topk_inner_product(torch.from_numpy(fi), torch.from_numpy(fd), k=3)
+    assert torch.equal(torch.from_numpy(idx), oidx) and pred[0]["genus"][0] == lab[int(oidx[0, 0])]["genus"]

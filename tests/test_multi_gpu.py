@@ -193,3 +193,114 @@ def test_full_finetune_bucketed_allreduce_on_the_gpu():
     # AdamW normalises each gradient element: where a gradient is within bf16 rounding of zero, the two batch splits can step in
     # opposite directions (3 steps x lr 1e-4 on parameters of magnitude ~0.05): measured 1.6e-4 relative over all parameters
     assert res[0]["same_keys"] and res[0]["param_rel"] < 1e-3, res[0]["param_rel"]
+
+
+def _ddp_worker(rank, world, port, out, ndev):
+    """The reference's own loop around the HIP model: DDP(model, find_unused_parameters=True) (train_cl.py:204),
+    optim.AdamW(model.parameters(), lr) (:221), GradScaler (:195), torch.autocast + scaler.scale(loss).backward() +
+    scaler.step + scaler.update (epoch/train_epoch.py:42-60) — no clibd_amd.train.Trainer, no join_streams()."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    torch.cuda.set_device(rank % ndev)
+    dev = torch.device("cuda", rank % ndev)
+    if ndev >= world:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clibd_amd.model import ClipLoss, SimpleCLIP
+        from clibd_amd.train import Trainer
+        from tests.test_model_gpu import hip_dna, hip_image, hip_text
+
+        gs, gd, gt, gi = _load("step_tiny_golden.pt"), _load("dna_tiny_golden.pt"), _load("text_tiny_golden.pt"), _load("image_tiny_golden.pt")
+
+        def build():
+            m = SimpleCLIP(hip_image(gi, dev), hip_dna(gd, dev), hip_text(gt, dev)).to(dev)
+            with torch.no_grad():
+                m.logit_scale.copy_(gs["logit_scale"])
+            return m
+
+        model = build()
+        with torch.no_grad():
+            if rank > 0:    # DDP broadcasts rank 0's parameters at construction
+                for p in model.parameters():
+                    if p.requires_grad:
+                        p.add_(0.01 * (rank + 1))
+        ddp = DDP(model, device_ids=[dev.index], find_unused_parameters=True)
+        optimizer = torch.optim.AdamW(ddp.parameters(), lr=1e-3)
+        scaler = torch.amp.GradScaler("cuda", enabled=True)
+        criterion = ClipLoss(local_loss=False, gather_with_grad=True, rank=rank, world_size=world, criterion=torch.nn.CrossEntropyLoss())
+        ddp.eval()   # dropout off so that the split batch can be compared with one process on the full batch (masks are per element index)
+        B = gs["labels"].numel()
+        b = B // world
+        sl = slice(rank * b, (rank + 1) * b)
+        img_all, dna_all, lab_all = (gs["image_u8"].float() / 255.0).to(dev), gs["dna"].to(dev), gs["labels"].to(dev)
+        text_all = {k: v.to(dev) for k, v in gs["text"].items()}
+        losses = []
+        for _ in range(3):
+            language_input = {k: v[sl] for k, v in text_all.items()}
+            optimizer.zero_grad()
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                image_output, dna_output, language_output, logit_scale, logit_bias = ddp(img_all[sl], dna_all[sl], language_input)
+            loss = criterion(image_features=image_output, dna_features=dna_output, text_features=language_output, labels=lab_all[sl],
+                             logit_scale=logit_scale)
+            scaler.scale(loss).backward()
+            scaler.step(optimizer)
+            scaler.update()
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        train = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        res = {"losses": losses, "scale": float(scaler.get_scale()),
+               "checksum": float(sum(p.detach().double().sum() for _, p in train)), "absmax": float(max(p.detach().abs().max() for _, p in train)),
+               "with_grad": sorted(n for n, p in train if p.grad is not None)}
+        # train() mode (HF BERT dropout p = 0.1 active, as the reference runs): the loop must work and keep the replicas identical
+        ddp.train()
+        optimizer.zero_grad()
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            io, do, lo_, ls, _ = ddp(img_all[sl], dna_all[sl], {k: v[sl] for k, v in text_all.items()})
+        lt = criterion(image_features=io, dna_features=do, text_features=lo_, labels=lab_all[sl], logit_scale=ls)
+        scaler.scale(lt).backward()
+        scaler.step(optimizer)
+        scaler.update()
+        torch.cuda.synchronize()
+        res.update(train_loss=lt.item(), checksum_train=float(sum(p.detach().double().sum() for _, p in train)))
+        if rank == 0:   # the same three eval-mode steps by ONE process on the full batch through Trainer.step
+            ref = build()
+            tr1 = Trainer(ref, lr=1e-3, world_size=1, rank=0, all_gather=True)
+            ref.eval()
+            ref_losses = [float(tr1.step(img_all, dna_all, text_all, lab_all)) for _ in range(3)]
+            torch.cuda.synchronize()
+            res["ref_losses"] = ref_losses
+            res["reachable"] = sorted(n for n, p in ref.named_parameters() if any(p is q for q in tr1.optimizer.param_groups[0]["params"]))
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_training_loop_ddp_gradscaler_autocast():
+    """INTEGRATION.md §1's claim, executed: the reference's caller contract (DDP + AdamW + GradScaler + autocast, two ranks)
+    around the HIP `SimpleCLIP` follows the same loss trajectory as `Trainer.step` on the full batch; the towers' backward
+    runs on their side streams while DDP's reducer hooks fire on the autograd thread; replicas stay identical."""
+    n = torch.cuda.device_count()
+    if n < 1:
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(2, 29653, out, n), nprocs=2, join=True)
+    res = dict(out)
+    assert sorted(res) == [0, 1]
+    ref = res[0]["ref_losses"]
+    for r in (0, 1):
+        assert res[r]["checksum"] == res[0]["checksum"] and res[r]["absmax"] == res[0]["absmax"]     # DDP kept the replicas identical
+        assert res[r]["checksum_train"] == res[0]["checksum_train"]
+        assert res[r]["scale"] == 65536.0                                                           # no step was skipped for inf / nan
+        assert res[r]["with_grad"] == res[0]["reachable"]          # exactly the parameters Trainer's bucket holds received a gradient
+        for a, e in zip(res[r]["losses"], ref):
+            assert abs(a - e) < 2e-3 * max(1.0, abs(e)), (r, res[r]["losses"], ref)     # every rank reports the full-batch loss
+        assert res[r]["losses"][-1] < res[r]["losses"][0] and res[r]["train_loss"] == res[r]["train_loss"]

@@ -696,9 +696,12 @@ def test_attention_query_prefix(ops, dev, B, S, nh, nq):
 
 
 # ----------------------------------------------------------------------------------------------- eval-side "next" rows
-@pytest.mark.parametrize("Q,Nk,D,k", [(37, 500, 768, 5), (130, 2048, 128, 5), (5, 9, 64, 3), (64, 21000, 768, 5)])
+@pytest.mark.parametrize("Q,Nk,D,k", [(37, 500, 768, 5), (130, 2048, 128, 5), (5, 9, 64, 3), (64, 21000, 768, 5), (2500, 21000, 768, 5),
+                                      (200, 409600, 768, 5), (70, 100, 36, 8), (1, 64, 768, 1)])
 def test_topk_inner_product_indices_bit_exact(ops, dev, Q, Nk, D, k):
-    """Integer top-k indices must equal the fp32 reference's (north-star: bit-exact); ties -> lower index."""
+    """Integer top-k indices must equal the fp32 reference's (north-star: bit-exact); ties -> lower index.  Sizes cover one
+    key split and many (few queries: the keys are split over workgroups and merged), a ragged last key tile, the reference's
+    BIOSCAN-1M key bank (~21 k) and a BIOSCAN-5M-sized one (409 600 keys), whose [Q, Nk] score matrix is never written."""
     from oracle import clibd_oracle as O
 
     g = torch.Generator().manual_seed(Q + Nk)
@@ -707,10 +710,21 @@ def test_topk_inner_product_indices_bit_exact(ops, dev, Q, Nk, D, k):
     q[0] = keys[Nk // 2]              # an exact match
     sim, idx = ops.topk_ip(q.to(dev), keys.to(dev), k)
     torch.cuda.synchronize()
-    s64 = q.double() @ keys.double().T
-    ref_idx = torch.argsort(-s64, dim=1, stable=True)[:, :k]
+    q64 = q.double()
+    if Nk <= 32768:
+        s64 = q64 @ keys.double().T
+        ref_idx = torch.argsort(-s64, dim=1, stable=True)[:, :k]
+        ref_sim = torch.gather(s64, 1, ref_idx)
+    else:   # key chunks: top-k of every chunk (fp64 scores of random data have no ties), merged
+        vs, ids = [], []
+        for c0 in range(0, Nk, 65536):
+            v, i = torch.topk(q64 @ keys[c0 : c0 + 65536].double().T, k, dim=1)
+            vs.append(v)
+            ids.append(i + c0)
+        v, sel = torch.topk(torch.cat(vs, 1), k, dim=1)
+        ref_idx, ref_sim = torch.gather(torch.cat(ids, 1), 1, sel), v
     assert torch.equal(idx.cpu(), ref_idx)
-    assert torch.allclose(sim.cpu().double(), torch.gather(s64, 1, ref_idx), atol=2e-6)
+    assert torch.allclose(sim.cpu().double(), ref_sim, atol=2e-6)
     if Nk <= 2048:
         osim, oidx = O.topk_inner_product(q, keys, k)
         assert torch.equal(idx.cpu(), oidx)
@@ -724,6 +738,16 @@ def test_topk_ties_prefer_lower_index(ops, dev):
     _, idx = ops.topk_ip(q.to(dev), keys.to(dev), 4)
     torch.cuda.synchronize()
     assert idx.cpu().tolist() == [[0, 1, 2, 3]] * 3
+    # the same across key tiles, key splits and the four per-query lists of a workgroup: 3000 identical keys, two better ones
+    keys = torch.zeros(3000, 64)
+    keys[:, 0] = 0.5
+    keys[1777, 0] = keys[65, 0] = 1.0
+    q = torch.zeros(70, 64)
+    q[:, 0] = 1.0
+    sim, idx = ops.topk_ip(q.to(dev), keys.to(dev), 8)
+    torch.cuda.synchronize()
+    assert idx.cpu().tolist() == [[65, 1777, 0, 1, 2, 3, 4, 5]] * 70
+    assert sim.cpu().tolist() == [[1.0, 1.0] + [0.5] * 6] * 70
 
 
 def test_kmer_tokenizer_matches_oracle(dev):

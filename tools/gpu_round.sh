@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, the bench line on the metric's configuration, secondary configs, rocprofv3 summaries.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [steps to run, default "test bench b256 tri prof"; also: fp8 pmc]
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [steps to run, default "test bench b256 tri prof"; also: fp8 pmc dram eval]
 set -u
 TAG=${1:-run}
 WHAT=${2:-"test bench b256 tri prof"}
@@ -50,5 +50,20 @@ if has pmc; then
   find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
   find "$OUT" -name "*.db" -delete
   tail -30 "$OUT/pmc_traffic.txt"; tail -30 "$OUT/pmc_mfma.txt"
+fi
+if has dram; then   # DRAM share of the L2's memory-side requests per kernel (tools/pmc_dram.py)
+  B=${PMC_BATCH:-2048}
+  timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d "$OUT/pmc_dram_rd" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d > "$OUT/pmc_dram_rd.log" 2>&1
+  echo "dram rd exit $?"
+  timeout 900 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d "$OUT/pmc_dram_wr" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d > "$OUT/pmc_dram_wr.log" 2>&1
+  echo "dram wr exit $?"
+  python tools/pmc_dram.py "$OUT/pmc_dram_rd" "$OUT/pmc_dram_wr" "$OUT/pmc_dram_b$B.json" $B > "$OUT/pmc_dram.txt" 2>&1
+  find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
+  find "$OUT" -name "*.db" -delete
+  tail -32 "$OUT/pmc_dram.txt"
+fi
+if has eval; then
+  timeout 900 python bench.py --eval --steps 5 --warmup 2 > "$OUT/bench_eval.json" 2> "$OUT/bench_eval.err"
+  echo "eval exit $?"; tail -c 1800 "$OUT/bench_eval.json"
 fi
 du -sh "$OUT"
