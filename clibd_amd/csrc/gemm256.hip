@@ -342,7 +342,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         // first use of the bias — is a vmcnt(0) that also waits for the previous row's store: one store in flight per
         // wave, 16 (fc1: 32) serial write round trips per tile.  The bias is therefore an inline-asm load (invisible to the
         // waitcnt pass), and the first row group of the two-pass kinds is loaded up here as well.
-        constexpr bool TWO_PASS = (KIND == EPI_MUL_AUX || KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP);
+        constexpr bool TWO_PASS = (epi_aux_kind(KIND) || KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP);
         constexpr bool PRELOAD_ROWS = TWO_PASS && !LORA && !FP8;  // (the LoRA / fp8 instantiations have no room for a row group)
         f32x4 bias_q[2];
         uint4 in_aux[8];
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int mc = min(mb + 16 * n + r, p.M - 1);
-                    if constexpr (KIND == EPI_MUL_AUX) {
+                    if constexpr (epi_aux_kind(KIND)) {
                         in_aux[4 * n + r] = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
                     } else {
                         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)mc * ep.ld_res + nb);
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         // ONE tied wait statement on every path (two of them, one per branch, make hipcc merge their results through copies it
         // places BEFORE the wait: stale bias).  Without a next tile there is no LDS-DMA behind the operands: an untied wait for
         // the operands themselves comes first and the tied one is then a no-op that only carries the data dependence.
-        if constexpr (PRELOAD_ROWS && KIND == EPI_MUL_AUX) {
+        if constexpr (PRELOAD_ROWS && epi_aux_kind(KIND)) {
             if (!has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             EPI_TIED_WAIT(24);
         } else if constexpr (PRELOAD_ROWS) {
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                         float v[8];
                         _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
                             _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r];
-                        if (KIND == EPI_MUL_AUX) {
+                        if (epi_aux_kind(KIND)) {
                             *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
                         } else {
                             f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
@@ -576,6 +576,7 @@ static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
         case EPI_BF16: return K256(EPI_BF16);
         case EPI_GELU_SAVE: return K256(EPI_GELU_SAVE);
         case EPI_MUL_AUX: return K256(EPI_MUL_AUX);
+        case EPI_ADD_AUX: return K256(EPI_ADD_AUX);
         case EPI_RES_F32: return K256(EPI_RES_F32);
         case EPI_RES_F32_DROP: return K256(EPI_RES_F32_DROP);
         case EPI_SPLITK_F32: return (const void*)gemm256_bf16_nt_kernel<EPI_SPLITK_F32, false, false, false, false>;

@@ -109,14 +109,15 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
             v[2 * e + 1] *= gelu_grad_f(bf2f((unsigned short)(xs[e] >> 16)));
         }
     }
-    if (ep.act == CLIBD_ACT_MUL_AUX) {
+    if (ep.act == CLIBD_ACT_MUL_AUX || ep.act == CLIBD_ACT_ADD_AUX) {
         const uint4* ax = (const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
         const uint4 x0 = ax[0], x1 = ax[1];
         const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            v[2 * e] *= bf2f((unsigned short)(xs[e] & 0xffffu));
-            v[2 * e + 1] *= bf2f((unsigned short)(xs[e] >> 16));
+            const float a0 = bf2f((unsigned short)(xs[e] & 0xffffu)), a1 = bf2f((unsigned short)(xs[e] >> 16));
+            if (ep.act == CLIBD_ACT_MUL_AUX) { v[2 * e] *= a0; v[2 * e + 1] *= a1; }
+            else { v[2 * e] += a0; v[2 * e + 1] += a1; }
         }
     }
     if (ep.residual_f32 != nullptr) {
@@ -168,8 +169,10 @@ enum : int {
     EPI_RES_F32 = 4,    // [bias] + residual_f32 -> out_f32                     (proj / fc2 forward)
     EPI_RES_F32_DROP = 5,  // [bias] -> dropout -> + residual_f32 -> out_f32    (BERT proj / fc2 forward, train mode)
     EPI_SPLITK_F32 = 6,    // plain fp32 store of this split's partial tile (split-K workspace mode)
-    EPI_NUM_KINDS = 7,
+    EPI_ADD_AUX = 7,       // + aux_bf16 -> out_bf16                            (dgrad joining a bf16 residual-gradient stream)
+    EPI_NUM_KINDS = 8,
 };
+constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX; }
 
 __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.split_k > 1) return EPI_GENERIC;
@@ -177,6 +180,7 @@ __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.act == CLIBD_ACT_NONE && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_BF16;
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE;
     if (ep.act == CLIBD_ACT_MUL_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX;
+    if (ep.act == CLIBD_ACT_ADD_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_ADD_AUX;
     if (ep.act == CLIBD_ACT_NONE && !ep.out_pre_bf16 && ep.residual_f32 && ep.out_f32 && !ep.out_bf16) return drop ? EPI_RES_F32_DROP : EPI_RES_F32;
     return EPI_GENERIC;
 }
@@ -196,13 +200,14 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
         *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
         return;
     }
-    if (KIND == EPI_MUL_AUX) {
+    if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
         const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
         const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[2 * e] *= bf2f((unsigned short)(xs[e] & 0xffffu));
-            v[2 * e + 1] *= bf2f((unsigned short)(xs[e] >> 16));
+            const float a0 = bf2f((unsigned short)(xs[e] & 0xffffu)), a1 = bf2f((unsigned short)(xs[e] >> 16));
+            if (KIND == EPI_MUL_AUX) { v[2 * e] *= a0; v[2 * e + 1] *= a1; }
+            else { v[2 * e] += a0; v[2 * e + 1] += a1; }
         }
         *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
         return;
@@ -232,7 +237,7 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
         if (ep.act == CLIBD_ACT_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-        } else if (ep.act == CLIBD_ACT_GELU_GRAD || ep.act == CLIBD_ACT_MUL_AUX) {
+        } else if (ep.act == CLIBD_ACT_GELU_GRAD || ep.act == CLIBD_ACT_MUL_AUX || ep.act == CLIBD_ACT_ADD_AUX) {
             const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
             const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
 #pragma unroll
@@ -241,9 +246,12 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
                 if (ep.act == CLIBD_ACT_GELU_GRAD) {
                     v[2 * e] *= gelu_grad_f(a0);
                     v[2 * e + 1] *= gelu_grad_f(a1);
-                } else {
+                } else if (ep.act == CLIBD_ACT_MUL_AUX) {
                     v[2 * e] *= a0;
                     v[2 * e + 1] *= a1;
+                } else {
+                    v[2 * e] += a0;
+                    v[2 * e + 1] += a1;
                 }
             }
         }
@@ -275,12 +283,13 @@ __device__ __forceinline__ void store_row8_gelu_fp8(const clibd_gemm_epilogue& e
 template <int KIND>
 __device__ __forceinline__ void fold_row8_in(const clibd_gemm_epilogue& ep, int m, int nb, float v[8], const uint4& ax, const f32x4& r0,
                                              const f32x4& r1) {
-    if (KIND == EPI_MUL_AUX) {
+    if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
         const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[2 * e] *= bf2f((unsigned short)(xs[e] & 0xffffu));
-            v[2 * e + 1] *= bf2f((unsigned short)(xs[e] >> 16));
+            const float a0 = bf2f((unsigned short)(xs[e] & 0xffffu)), a1 = bf2f((unsigned short)(xs[e] >> 16));
+            if (KIND == EPI_MUL_AUX) { v[2 * e] *= a0; v[2 * e + 1] *= a1; }
+            else { v[2 * e] += a0; v[2 * e + 1] += a1; }
         }
     } else {  // EPI_RES_F32 / EPI_RES_F32_DROP
         if (KIND == EPI_RES_F32_DROP) {
@@ -303,7 +312,7 @@ template <int KIND>
 __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
     uint4 ax = make_uint4(0u, 0u, 0u, 0u);
     f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;
-    if (KIND == EPI_MUL_AUX) {
+    if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
         ax = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
     } else {
         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);

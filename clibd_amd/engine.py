@@ -15,6 +15,7 @@ Reference arithmetic being replaced (all third-party model code the reference de
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -27,6 +28,15 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 class NotSupportedYet(NotImplementedError):
     pass
+
+
+# Frozen-base (LoRA) backward: the gradient of the residual stream travels between blocks as bf16 instead of fp32 — the
+# LayerNorm backward then moves 10 instead of 16 bytes per element and the BERT dgrad GEMMs join the stream with a bf16 add
+# (CLIBD_ACT_ADD_AUX) instead of an fp32 read + write.  The reference's autograd keeps this stream in fp32 (also under
+# autocast); the extra rounding (one bf16 rounding per block-half: ~0.1 % rms each, independent) is budgeted in DESIGN.md §4.
+# CLIBD_RESIDUAL_GRAD=fp32 restores the fp32 stream.  Full fine-tune mode always keeps fp32.
+def residual_grad_bf16() -> bool:
+    return os.environ.get("CLIBD_RESIDUAL_GRAD", "bf16").lower() != "fp32"
 
 
 @dataclass
@@ -392,6 +402,7 @@ class TransformerStack:
         first_lora = min((i for i, L in enumerate(self.layers) if L.lora is not None), default=len(self.layers))
         if full:
             first_lora = -1  # every layer has trainable parameters and the input gradient is needed
+        r16 = residual_grad_bf16() and not full   # bf16 residual-gradient stream (see residual_grad_bf16)
         # full fine-tune: the LayerNorm backward accumulates d(gamma), d(beta) in the same pass (it holds dy and xhat anyway)
         pg = lambda w, b: (dict(dgamma=grads[id(w)].view(-1), dbeta=grads[id(b)].view(-1)) if full and id(w) in grads else {})
         wg = lambda dy, x, ws, bs: linear_wgrad(dy, x, ws, bs, grads) if full else None
@@ -418,17 +429,27 @@ class TransformerStack:
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
-                    _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)            # residual path: class rows only
-                    ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
-                    ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
-                    dx_f32, dx_bf16 = ndx_f32, ndx_bf16
+                    if r16:
+                        dres16, _ = ops.scatter_rows(dx1_f32, S, bf16=True, f32=False)           # residual path: class rows only
+                        ndx_bf16 = new(H, BF16)
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16)
+                        dx_f32, dx_bf16 = None, ndx_bf16
+                    else:
+                        _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)        # residual path: class rows only
+                        ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
+                        dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif self.pre_ln:
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)          # d(fc1 out)
                 wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                 ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
-                dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
-                ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
+                if r16:
+                    dx1_f32, dx1_bf16 = None, new(H, BF16)
+                    ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres_bf16=dx_bf16, dx_bf16=dx1_bf16)
+                else:
+                    dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
+                    ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
                 wg(dx1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtmp)                                             # d(attn out)
                 ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv)
@@ -437,9 +458,40 @@ class TransformerStack:
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
-                    ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
-                    ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
+                    if r16:
+                        ndx_f32, ndx_bf16 = None, new(H, BF16)
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16)
+                    else:
+                        ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
                     dx_f32, dx_bf16 = ndx_f32, ndx_bf16
+            elif r16:
+                # post-LN, bf16 stream: `dx_f32` holds the incoming gradient of the layer output (fp32 from the head at the top layer,
+                # bf16 below).  Each LayerNorm backward writes the un-dropped residual copy (*_res) and, under dropout, the masked
+                # copy the dense branch's dgrad consumes; the two dgrads that re-join the stream add the residual copy in their epilogue.
+                def ln_back(dy, xs, st, gam, drop_site):
+                    res = new(H, BF16)
+                    if drop_site is not None and drop_site.thr16 > 0:
+                        masked = new(H, BF16)
+                        ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, dx_bf16=masked, drop=drop_site)
+                        return res, masked
+                    ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res)
+                    return res, res
+
+                ds2_res, ds2_b = ln_back(dx_f32, rec["s2"], rec["st2"], c.g2, rec["d_h2"])
+                ops.gemm_nt(ds2_b, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)
+                dx1 = new(H, BF16)
+                ops.gemm_nt(dh, c.w1_t, act=ops.ACT_ADD_AUX, aux=ds2_res, out_bf16=dx1)
+                ds1_res, ds1_b = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"])
+                ops.gemm_nt(ds1_b, c.wo_t, out_bf16=dtmp)
+                ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv, drop=rec["d_att"])
+                if has_lora:
+                    self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads)
+                if i > first_lora:
+                    ndx = new(H, BF16)
+                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
+                                act=ops.ACT_ADD_AUX, aux=ds1_res, out_bf16=ndx)
+                    dx_f32 = ndx
             else:
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"], **pg(L.ln2_w, L.ln2_b))

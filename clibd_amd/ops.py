@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import GemmEpilogue, check
 
-ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX, ACT_ADD_AUX = 0, 1, 2, 3, 4, 5
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
 FP8 = torch.float8_e4m3fn  # OCP e4m3 (gfx950's fp8 MFMA operand format); max finite 448
 
@@ -270,10 +270,31 @@ def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, l
                                           _p(stats), _p(lora_a), _p(t_out), _stream()), "layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, drop=None, dgamma=None, dbeta=None) -> None:
-    """dgamma / dbeta (fp32 [H], accumulate): the LayerNorm parameter gradients in the same pass (full fine-tune mode)."""
+def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, drop=None, dgamma=None, dbeta=None,
+                  dres_bf16=None, dx_res_bf16=None) -> None:
+    """dgamma / dbeta (fp32 [H], accumulate): the LayerNorm parameter gradients in the same pass (full fine-tune mode).
+    dres_bf16 / dx_res_bf16: the residual gradient travels as bf16 (clibd_layernorm_bwd_res16): dx = LN'(dy) + dres_bf16,
+    dx_res_bf16 = bf16(dx) without the dropout mask that dx_bf16 carries; no fp32 input / output stream then."""
     _chk(x, F32, "x")
     M, H = x.shape
+    if dres_bf16 is not None or dx_res_bf16 is not None:
+        if dres is not None or dx_f32 is not None or dgamma is not None:
+            raise ValueError("layernorm_bwd: the bf16 residual-gradient form has no fp32 streams and no parameter gradients")
+        for nm, t in (("dres_bf16", dres_bf16), ("dx_res_bf16", dx_res_bf16), ("dx_bf16", dx_bf16)):
+            if t is not None:
+                _chk(t, BF16, nm)
+                if tuple(t.shape) != (M, H):
+                    raise ValueError(f"layernorm_bwd: {nm} shape")
+        _chk(dy, dy.dtype if dy.dtype in (BF16, F32) else BF16, "dy")
+        if tuple(dy.shape) != (M, H):
+            raise ValueError("layernorm_bwd: dy shape")
+        _chk(stats, F32, "stats")
+        _chk(gamma, F32, "gamma")
+        d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
+        check(_lib.load().clibd_layernorm_bwd_res16(dy.data_ptr() if dy.dtype == BF16 else None, dy.data_ptr() if dy.dtype == F32 else None,
+                                                    x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres_bf16), _p(dx_res_bf16),
+                                                    _p(dx_bf16), d.seed, d.thr16, d.scale, _stream()), "layernorm_bwd_res16")
+        return
     if dy.dtype == BF16:
         _chk(dy, BF16, "dy")
         dyb, dyf = dy.data_ptr(), None

@@ -51,12 +51,14 @@ const char* clibd_build_hash(void);
  *   if act == CLIBD_ACT_GELU_SAVE_GRAD (needs out_pre_bf16): x = float(bf16(v)); out_pre_bf16[m,n] = bf16(gelu'(x));
  *                                   v = gelu_erf(x)    (training forward: the backward then needs no transcendental)
  *   if act == CLIBD_ACT_MUL_AUX:    v = v * aux_bf16[m,n]                       (dgrad through GELU with saved gelu')
+ *   if act == CLIBD_ACT_ADD_AUX:    v = v + aux_bf16[m,n]                       (dgrad joining a bf16 residual-gradient stream)
  *   if residual_f32:  v += residual_f32[m,n]
  *   out_bf16[m,n] = bf16(v) ; out_f32[m,n] = v   (either or both)
  *   split_k > 1: only out_f32 allowed; partial sums are atomically added into a caller-zeroed out_f32.
  * Constraints: K % 64 == 0, lda/ldw % 8 == 0, N % 16 == 0, all ld_* % 8 == 0, 16-byte aligned pointers.
  * ------------------------------------------------------------------------------------------------ */
-enum { CLIBD_ACT_NONE = 0, CLIBD_ACT_GELU = 1, CLIBD_ACT_GELU_GRAD = 2, CLIBD_ACT_GELU_SAVE_GRAD = 3, CLIBD_ACT_MUL_AUX = 4 };
+enum { CLIBD_ACT_NONE = 0, CLIBD_ACT_GELU = 1, CLIBD_ACT_GELU_GRAD = 2, CLIBD_ACT_GELU_SAVE_GRAD = 3, CLIBD_ACT_MUL_AUX = 4,
+       CLIBD_ACT_ADD_AUX = 5 };
 
 typedef struct clibd_gemm_epilogue {
     const float* bias;          /* [N] fp32 */
@@ -146,6 +148,13 @@ int clibd_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x
 int clibd_layernorm_bwd_drop(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
                              const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
                              void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
+/* The same backward with the RESIDUAL GRADIENT carried in bf16 (frozen-base / LoRA mode): dx = LN'(dy) [+ dres_bf16];
+ * dx_res_bf16 (optional) = bf16(dx), the gradient of the residual sum handed to the next block; dx_bf16 (optional) = bf16(dx x the
+ * dense branch's dropout mask) when drop_thr16 > 0, else the same values.  10 instead of 16 bytes per element of a pre-LN block
+ * (the reference's autograd keeps this stream in fp32: the rounding it adds is budgeted in DESIGN.md §4). */
+int clibd_layernorm_bwd_res16(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
+                              int M, int H, const void* dres_bf16, void* dx_res_bf16, void* dx_bf16, uint32_t drop_seed,
+                              int drop_thr16, float drop_scale, void* stream);
 /* full fine-tune mode: the same backward that also accumulates the parameter gradients it has the operands for
  *   dgamma[c] += sum_m dy[m,c] * xhat[m,c],  dbeta[c] += sum_m dy[m,c]     (fp32 [H], caller zeroes once per step). */
 int clibd_layernorm_bwd_pg(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,

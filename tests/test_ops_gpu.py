@@ -610,7 +610,8 @@ def test_gemm_gelu_save_grad_and_mul_aux(ops, dev):
 @pytest.mark.parametrize("K", [256, 768])
 @pytest.mark.parametrize("kind,bias,lora", [("bf16", False, False), ("bf16", True, True), ("bf16", False, True), ("gelu_save", True, False),
                                             ("gelu_save", False, False), ("mul_aux", False, False), ("res_f32", True, False),
-                                            ("res_f32", False, True), ("res_f32_drop", True, False), ("generic_two_outputs", True, False)])
+                                            ("res_f32", False, True), ("res_f32_drop", True, False), ("generic_two_outputs", True, False),
+                                            ("add_aux", False, False), ("add_aux", False, True), ("add_aux", True, False)])
 def test_gemm256_epilogue_kinds(ops, dev, kind, bias, lora, K):
     """Every specialised epilogue instantiation of the 256x256 kernel (kind x bias x rank-8 update) on a ragged M (last
     m-tile has 5 live rows), against a torch fp32 reference with the kernel's rounding points; rows past M stay untouched."""
@@ -649,6 +650,15 @@ def test_gemm256_epilogue_kinds(ops, dev, kind, bias, lora, K):
         full, out = buf(BF16)
         ops.gemm_nt(a, w, act=ops.ACT_MUL_AUX, aux=aux, out_bf16=out, **kw)
         checks.append((full, ref * aux.float(), 4e-3))
+    elif kind == "add_aux":   # dgrad joining a bf16 residual-gradient stream (CLIBD_ACT_ADD_AUX)
+        aux = torch.randn(M, N, generator=g).to(dev, BF16)
+        full, out = buf(BF16)
+        ops.gemm_nt(a, w, act=ops.ACT_ADD_AUX, aux=aux, out_bf16=out, **kw)
+        checks.append((full, ref + aux.float(), 4e-3))
+        small = torch.empty((300, 256), dtype=BF16, device=dev)    # the same epilogue through the 128x128 kernel (M < 1024)
+        ops.gemm_nt(a[:300], w[:256], act=ops.ACT_ADD_AUX, aux=aux[:300, :256], out_bf16=small, bias=b[:256] if bias else None,
+                    rank_u=u[:300] if lora else None, rank_v=v[:256] if lora else None)
+        assert rel_err(small.float().cpu(), (ref[:300, :256] + aux[:300, :256].float()).cpu()) < 4e-3
     elif kind in ("res_f32", "res_f32_drop"):
         res = torch.randn(M, N, generator=g).to(dev)
         full, out = buf(F32)
@@ -922,3 +932,40 @@ def test_layernorm_bwd_with_fused_param_grads(ops, dev, M, H, f32dy, drop, res):
     xhat = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6)
     assert rel_err(outs[1][2] - 0.25, (dyr.double() * xhat).sum(0)) < 2e-4
     assert rel_err(outs[1][3] + 0.5, dyr.double().sum(0)) < 2e-4
+
+
+# ----------------------------------------------------------------------------------------------- round 3: bf16 residual-gradient stream
+@pytest.mark.parametrize("M,H,f32dy,drop", [(1000, 768, False, False), (333, 768, True, True), (70, 512, False, True), (64, 1024, True, False)])
+def test_layernorm_bwd_bf16_residual_stream(ops, dev, M, H, f32dy, drop):
+    """clibd_layernorm_bwd_res16 = clibd_layernorm_bwd with the residual gradient read and written as bf16: fed the bf16
+    image of the fp32 call's residual it must reproduce that call's dx bit for bit (same arithmetic, fp32 inside), as an
+    un-dropped residual copy and — under dropout — a masked copy for the dense branch."""
+    g = torch.Generator().manual_seed(M + H)
+    x = torch.randn(M, H, generator=g) * 2 + 0.3
+    gam, bet = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    dy = torch.randn(M, H, generator=g)
+    dyd = dy.to(dev) if f32dy else dy.to(dev, BF16)
+    st = torch.empty((M, 2), device=dev)
+    y = torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_fwd(x.to(dev), gam.to(dev), bet.to(dev), 1e-6, y_bf16=y, stats=st)
+    d = ops.Drop(0.1, 4242) if drop else None
+    dres16 = torch.randn(M, H, generator=g).to(dev, BF16)
+    dxf, dxb = torch.empty((M, H), device=dev), torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_bwd(dyd, x.to(dev), st, gam.to(dev), dres=dres16.float(), dx_f32=dxf, dx_bf16=dxb, drop=d)
+    res, masked = torch.empty((M, H), dtype=BF16, device=dev), torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_bwd(dyd, x.to(dev), st, gam.to(dev), dres_bf16=dres16, dx_res_bf16=res, dx_bf16=masked, drop=d)
+    torch.cuda.synchronize()
+    assert torch.equal(res.cpu().float(), bfr(dxf.cpu()))            # the un-dropped gradient of the residual sum
+    assert torch.equal(masked.cpu(), dxb.cpu())                      # the dense branch's copy carries the dropout mask
+    if drop:
+        assert not torch.equal(res.cpu(), masked.cpu())
+    only = torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_bwd(dyd, x.to(dev), st, gam.to(dev), dres_bf16=dres16, dx_res_bf16=only)      # one output, no incoming mask
+    nores = torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_bwd(dyd, x.to(dev), st, gam.to(dev), dx_bf16=nores, dx_res_bf16=only if False else None, dres_bf16=dres16)
+    torch.cuda.synchronize()
+    assert torch.equal(only.cpu(), res.cpu())
+    if not drop:
+        assert torch.equal(nores.cpu(), res.cpu())
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(dyd, x.to(dev), st, gam.to(dev), dres=dres16.float(), dres_bf16=dres16, dx_bf16=nores)
