@@ -319,14 +319,18 @@ def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated):
 
 def test_fp8_gradients_on_spread_embeddings(dev):
     """VERDICT r2 asked whether the fp8-forward gradient is better aligned with the bf16 path's once the embeddings are spread
-    (at random init the rows of a tower's output are nearly parallel, cosine(fp8, bf16) = 0.81).  It is not — measured on
-    MI355X in round 3: adapters and heads trained for 40 bf16 steps on a fixed batch of 32 pairs (loss 3.47 -> 0.035, mean mutual
-    cosine of the image embeddings 0.997 -> 0.20), then cosine(fp8 gradient, bf16 gradient) = 0.33 on the training batch and 0.56
-    on a fresh batch.  The fp8 forward perturbs unit-norm embeddings by ~5e-3; the temperature (x14.3) turns that into ~7 %
-    noise on the softmax probabilities, and the gradient p - t of a batch the model already fits is smaller than that noise.
-    The mode is therefore embedding-grade (eval / retrieval, forward parity gated above), and as a training mode it is a
-    noisy-gradient accelerator (+11 % step rate, the loss still falls: test_fp8_training_steps_reduce_loss), never the headline.
-    This test records the numbers and holds the floor they set (direction still positive, embeddings close)."""
+    (at random init the rows of a tower's output are nearly parallel, cosine(fp8, bf16) = 0.81).  It is not.  Measured on
+    MI355X in round 3 — adapters and heads trained in bf16 on a fixed batch of 32 pairs, fp8 scales calibrated on the batch
+    under test, gradients of all trainable tensors:
+        after  8 steps (loss 3.47 -> 3.20, mean mutual cosine of the image embeddings 0.90): cosine(fp8, bf16) 0.92 on the
+                       training batch, 0.70 on a fresh batch; max |embedding difference| 0.08;
+        after 40 steps (loss 0.03, mutual cosine 0.18): 0.45 / 0.61; max |embedding difference| 0.10 - 0.13.
+    The fp8 forward perturbs the unit-norm embeddings of trained towers by ~0.1 (5e-3 at random init: trained adapters raise
+    the dynamic range of the residual stream); the temperature (x14.3) turns that into O(1) noise on the logits, and the
+    gradient p - t of a batch the model already fits is smaller than that noise.  The mode is therefore embedding-grade at
+    initialisation only, and as a training mode a noisy-gradient accelerator (+11 % step rate; the loss still falls:
+    test_fp8_training_steps_reduce_loss), never the headline.  This test records the numbers and holds the
+    floor they set: direction still positive, embeddings within 0.3."""
     from clibd_amd.data import synthetic_batch
     from clibd_amd.model import ClipLoss
     from clibd_amd.train import Trainer
@@ -374,4 +378,4 @@ def test_fp8_gradients_on_spread_embeddings(dev):
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
     assert out[("40 steps", "train")][1] < 0.9                      # the embeddings did spread
     for k, (c, _, de) in out.items():
-        assert c > 0.15 and de < 3e-2, (k, c, de)                    # the floor the measurement sets: direction positive, embeddings close
+        assert c > 0.15 and de < 0.3, (k, c, de)                     # the floor the measurement sets
