@@ -147,3 +147,39 @@ def test_results_do_not_depend_on_a_concurrent_stream(dev, env, noise_kind):
                     bad.append((name, k, float((a.float() - b.float()).abs().max())))
                     break
     assert not bad, bad
+
+
+def test_full_size_two_tower_step_is_bit_reproducible(dev):
+    """Tripwire for DESIGN.md §4's "one unreproduced mismatch" (two of sixteen image embeddings 1 % off in one full-suite run of
+    round 2): the full-size forward + backward with the towers on two streams, 24 passes — every third one behind an
+    fp8-forward pass, as in the test that saw it — must return bit-identical embeddings every time
+    (tools/stress_model_determinism.py runs the same loop for longer)."""
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import ClipLoss
+    from tests.test_fp8_gpu import _full_size_pair
+
+    model = _full_size_pair(dev)
+    batch = synthetic_batch(16, dev, seed=5, rank=0, with_text=False)
+    labels = (torch.arange(16) % 11).to(dev)
+    crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+    ps = [p for p in model.parameters() if p.requires_grad]
+
+    def step():
+        hi, hd, _, scale, _ = model(batch["image"], batch["dna"], None)
+        gs = torch.autograd.grad(crit(hi, hd, None, labels, scale), ps, allow_unused=True)
+        model.join_streams()
+        torch.cuda.synchronize()
+        return hi.detach().float().cpu(), hd.detach().float().cpu(), [None if g_ is None else g_.detach().float().cpu() for g_ in gs]
+
+    ri, rd, rg = step()
+    for k in range(24):
+        if k % 3 == 2:
+            model.enable_fp8_forward()
+            step()
+            model.enable_fp8_forward(enabled=False)
+        i, d, g_ = step()
+        assert torch.equal(i, ri), (k, (i != ri).any(dim=1).nonzero().flatten().tolist(), float((i - ri).abs().max()))
+        assert torch.equal(d, rd), (k, (d != rd).any(dim=1).nonzero().flatten().tolist(), float((d - rd).abs().max()))
+        for a, b_ in zip(g_, rg):   # gradients: float-atomic sums in the loss and the adapter gradients -> 1e-5 of the largest element
+            if a is not None:
+                assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max()) + 1e-12, k
