@@ -87,6 +87,29 @@ __device__ __forceinline__ void store_rows16(unsigned short* row, const f32x4 (&
     }
 }
 
+// the (dt, dt + 1) = (2 pr, 2 pr + 1) half of store_rows16, for a wave that holds only those two column tiles
+__device__ __forceinline__ void store_rows16_pair(unsigned short* row, const f32x4& va, const f32x4& vb, float mul, bool on, int g, int pr) {
+    unsigned a0 = pack2bf(va[0] * mul, va[1] * mul), a1 = pack2bf(va[2] * mul, va[3] * mul);
+    unsigned b0 = pack2bf(vb[0] * mul, vb[1] * mul), b1 = pack2bf(vb[2] * mul, vb[3] * mul);
+    permlane16_swap_u32(a0, b0);
+    permlane16_swap_u32(a1, b1);
+    if (on) *(uint4*)(row + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1)) = make_uint4(a0, a1, b0, b1);
+}
+// Training forward (single-pass backward, attention_bwd_sp_kernel): beside out = bf16(o * mul) also the bf16 residual of that
+// rounding, o_lo = bf16(o * mul - float(bf16(o * mul))), so that the backward can take delta = dO . (o_hi + o_lo) with fp32-class
+// accuracy (delta from the bf16 output alone costs the q-adapter gradients 4-7 %: DESIGN.md §3.2).
+__device__ __forceinline__ void store_rows16_lo(unsigned short* row_lo, const f32x4 (&v)[4], float mul, bool on, int g) {
+    f32x4 lo[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = v[dt][r] * mul;
+            lo[dt][r] = x - bfround(x);
+        }
+    store_rows16(row_lo, lo, 1.0f, on, g);
+}
+
 constexpr float NEG_BIG = -1.0e30f;
 
 #ifdef CLIBD_GEMM_DIAG
@@ -110,8 +133,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ out, float scale,
                                                                     int nq, int out_seq, unsigned drop_seed,
-                                                                    int drop_thr16, float drop_scale, float out_fp8_scale) {
+                                                                    int drop_thr16, float drop_scale, float out_fp8_scale,
+                                                                    float* __restrict__ lse, unsigned short* __restrict__ o_lo) {
     // out_fp8_scale > 0 (fp8-forward mode): `out` holds OCP e4m3 bytes, fp8(o * out_fp8_scale) — the projection GEMM's operand
+    // lse / o_lo (optional, training forward): per (head, query) log2-domain log-sum-exp c2 * max + log2(sum) of the UN-dropped
+    // scores, [B * nheads, S] fp32, and the bf16 residual of the output rounding (store_rows16_lo), laid out like `out`
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
     char* kt_lds = smem;
@@ -200,6 +226,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                 }
                 sum = group4_sum(sum);
                 inv[t] = 1.0f / sum;
+                if (lse != nullptr && g == 0) {
+                    const int qq = (2 * p + t) * 16 + i;
+                    if (qq < nq) lse[(size_t)blockIdx.x * S + qq] = mc + __builtin_amdgcn_logf(sum);
+                }
             }
             f32x4 o[2][4];
 #pragma unroll
@@ -245,6 +275,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                     }
                 } else {
                     store_rows16(out + oidx, o[t], inv[t], q < nq, g);
+                    if (o_lo != nullptr) store_rows16_lo(o_lo + oidx, o[t], inv[t], q < nq, g);
                 }
             }
         }
@@ -297,6 +328,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
         }
         sum = group4_sum(sum);
         const float inv = 1.0f / sum;
+        if (lse != nullptr && g == 0 && q < nq) lse[(size_t)blockIdx.x * S + q] = mc + __builtin_amdgcn_logf(sum);
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
@@ -329,6 +361,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                 }
             } else {
                 store_rows16(out + oidx, o, inv, q < nq, g);
+                if (o_lo != nullptr) store_rows16_lo(o_lo + oidx, o, inv, q < nq, g);
             }
         }
     }
@@ -351,7 +384,8 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
                                                                                int total_heads, const int* __restrict__ key_mask,
                                                                                unsigned short* __restrict__ out, float scale, int nq,
                                                                                int out_seq, unsigned drop_seed, int drop_thr16,
-                                                                               float drop_scale, float out_fp8_scale) {
+                                                                               float drop_scale, float out_fp8_scale,
+                                                                               float* __restrict__ lse, unsigned short* __restrict__ o_lo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
     constexpr int BUF = 2 * S_pad * 128;   // K then V of one head
@@ -397,7 +431,7 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
         const bool mine = qt < nqt;
         const int q = qt * 16 + i;
         // this head's image: issued one head ago (or just above); the wave's own pieces are awaited, the barrier publishes the rest
-        if (stored) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (stored && lse == nullptr) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (the training forward stores more per head: full wait)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int next = head + (int)gridDim.x;
@@ -447,6 +481,7 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
             }
             sum = group4_sum(sum);
             const float inv = 1.0f / sum;
+            if (lse != nullptr && g == 0 && q < nq) lse[(size_t)head * S + q] = mc + __builtin_amdgcn_logf(sum);
             f32x4 o[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
@@ -479,6 +514,7 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
                     }
                 } else {
                     store_rows16(out + oidx, o, inv, q < nq, g);
+                    if (o_lo != nullptr) store_rows16_lo(o_lo + oidx, o, inv, q < nq, g);
                 }
             }
         }
@@ -854,6 +890,211 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
     }
 }
 
+// ============================================ backward, single pass ===============================================
+// The two-phase kernel above evaluates every score, every exponential and every dP twice (once per query tile for dQ and the
+// softmax statistics, once per key tile for dK / dV) because it derives the row statistics itself.  Given the forward's
+// log-sum-exp and delta = dO . O (from the saved output and its rounding residual, store_rows16_lo), one sweep over the
+// (key tile, query tile) pairs is enough:
+//     P = exp2(c2 s - lse),  dS = P o (dP - delta),  dV += P^T dO,  dK += dS^T Q,  dQ += dS K.
+// One workgroup of 8 waves per head, all four operand images (K, V, Q, dO: [32 NP][64] bf16 each) resident in LDS.  Key tiles
+// are OWNED by waves (tile w and w + 8): dK and dV of a tile stay in that wave's accumulators for the whole head.  dQ is a sum
+// over every wave's keys; instead of atomics the waves exchange dS: per block of 64 queries each wave writes the bf16 dS of its
+// key tiles into a fifth LDS image laid out [key][query] — the layout of the other images, so the hardware-transposing read
+// (ds_read_b64_tr_b16) hands it back as the "query on the lane, keys in the k-slots" MFMA operand — and after a barrier the
+// eight waves compute that block's dQ = dS K, one (query tile, half of the head dim) each, contracting over ALL keys.
+// Deterministic, no float atomics; 2 barriers per 64 queries.  MFMAs per head at S = 197: 1 790 against 2 660, exponentials and
+// score arithmetic once instead of twice.  Needs nq = S, no key mask, S <= 224 (LDS: 5 images of 32 NP rows + statistics).
+constexpr int ATTB_WAVES = 8;
+
+template <bool DROP>
+__global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const unsigned short* __restrict__ qkv,
+                                                                          const unsigned short* __restrict__ dout,
+                                                                          const unsigned short* __restrict__ o_hi,
+                                                                          const unsigned short* __restrict__ o_lo,
+                                                                          const float* __restrict__ lse, int S, int nheads,
+                                                                          unsigned short* __restrict__ dqkv, float scale, unsigned drop_seed,
+                                                                          int drop_thr16, float drop_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NT = (S + 15) >> 4;          // 16-row tiles of the sequence
+    const int NP = (NT + 1) >> 1;          // 32-row k-slots
+    const int R = 32 * NP;                 // rows of every image
+    char* kimg = smem;
+    char* vimg = kimg + R * 128;
+    char* qimg = vimg + R * 128;
+    char* doimg = qimg + R * 128;
+    char* dsimg = doimg + R * 128;         // [key][64 queries of the current block] bf16
+    float* st_m = (float*)(dsimg + R * 128);
+    float* st_d = st_m + R;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / nheads, h = blockIdx.x % nheads;
+    const int H = nheads * DH;
+    const size_t ld = (size_t)3 * H;
+    const unsigned short* qbase = qkv + (size_t)b * S * ld + h * DH;
+    const size_t obase = (size_t)b * S * H + h * DH;
+    const unsigned short* dobase = dout + obase;
+    unsigned short* dqbase = dqkv + (size_t)b * S * ld + h * DH;
+    const int g = lane >> 4, i = lane & 15;
+    const float c2 = scale * 1.4426950408889634f;
+
+    stage_head_tile(kimg, qbase + H, ld, S, R, wave, lane, ATTB_WAVES);
+    stage_head_tile(vimg, qbase + 2 * H, ld, S, R, wave, lane, ATTB_WAVES);
+    stage_head_tile(qimg, qbase, ld, S, R, wave, lane, ATTB_WAVES);
+    stage_head_tile(doimg, dobase, (size_t)H, S, R, wave, lane, ATTB_WAVES);
+    // delta[q] = dO[q] . (o_hi[q] + o_lo[q]) and the row statistic; query rows >= S get lse = +BIG, i.e. P = 0 exactly
+    for (int r0 = 0; r0 < R; r0 += 8 * ATTB_WAVES) {
+        const int row = r0 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+        float part = 0.f;
+        if (row < S) {
+            const size_t off = (size_t)row * H + 8 * sub;
+            const bf16x8 d8 = *(const bf16x8*)(dobase + off);
+            const bf16x8 h8 = *(const bf16x8*)(o_hi + obase + off);
+            const bf16x8 l8 = *(const bf16x8*)(o_lo + obase + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                part += bf2f((unsigned short)d8[e]) * (bf2f((unsigned short)h8[e]) + bf2f((unsigned short)l8[e]));
+        }
+        part += dpp_mov<DPP_QUAD_XOR1>(part);
+        part += dpp_mov<DPP_QUAD_XOR2>(part);
+        part += dpp_mov<DPP_ROW_HALF_MIRROR>(part);   // the 8 lanes of a row
+        if (sub == 0 && row < R) {
+            st_d[row] = part;
+            st_m[row] = row < S ? lse[(size_t)blockIdx.x * S + row] : -NEG_BIG;
+        }
+    }
+    // the key rows of the exchange image that no wave owns (the padding tile of an odd tile count) must read as zeros
+    for (int e = threadIdx.x; e < (R - 16 * NT) * 8; e += 64 * ATTB_WAVES) *(uint4*)(dsimg + 16 * NT * 128 + e * 16) = make_uint4(0u, 0u, 0u, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- this wave's key tiles (0, 1 or 2 of them) as MFMA row fragments, for the whole head
+    const int nown = (wave < NT ? 1 : 0) + (wave + ATTB_WAVES < NT ? 1 : 0);
+    bf16x8 kf[2][2], vf[2][2];
+    int keyv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kt = min(wave + ATTB_WAVES * j, 2 * NP - 1);
+        keyv[j] = (wave + ATTB_WAVES * j) * 16 + i;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[j][ks] = lds_row_frag(kimg, kt * 16 + i, ks, g);
+            vf[j][ks] = lds_row_frag(vimg, kt * 16 + i, ks, g);
+        }
+    }
+    f32x4 dv[2][4], dk[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dv[j][dt] = (f32x4){0, 0, 0, 0}; dk[j][dt] = (f32x4){0, 0, 0, 0}; }
+
+    const int nqb = (NT + 3) >> 2;   // blocks of 64 queries
+#pragma unroll 1
+    for (int it = 0; it < nqb; ++it) {
+        // ------------ sweep: this wave's key tiles x the block's two query pairs
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int s = 2 * it + p;          // query pair = k-slot of the Q / dO images
+            if (s < NP) {
+                const bool q1 = 2 * s + 1 < NT;
+                bf16x8 qr[2][2], dor[2][2];
+                float mr[2][4], dlr[2][4];
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        qr[hq][ks] = lds_row_frag(qimg, (2 * s + hq) * 16 + i, ks, g);
+                        dor[hq][ks] = lds_row_frag(doimg, (2 * s + hq) * 16 + i, ks, g);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qq = (2 * s + hq) * 16 + 4 * g + r;
+                        mr[hq][r] = st_m[qq];
+                        dlr[hq][r] = st_d[qq];
+                    }
+                }
+                bf16x8 pf[2], dsf[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    pf[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    dsf[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (j >= nown) continue;
+                    const bool key_live = keyv[j] < S;   // padding keys of the last live tile: no probability, no dS (dQ sums over keys)
+                    f32x4 pp[2], dd[2];
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) {
+                        pp[hq] = (f32x4){0, 0, 0, 0};
+                        dd[hq] = (f32x4){0, 0, 0, 0};
+                        if (hq == 1 && !q1) continue;
+                        f32x4 sv = (f32x4){0, 0, 0, 0}, dpv = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[hq][ks], kf[j][ks], sv, 0, 0, 0);
+                            dpv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dor[hq][ks], vf[j][ks], dpv, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float pr = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -mr[hq][r]));   // normalised; 0 for query rows >= S
+                            if (!key_live) pr = 0.f;
+                            float fm = 1.0f;
+                            if (DROP) {
+                                const int qq = (2 * s + hq) * 16 + 4 * g + r;
+                                fm = drop_one(drop_seed, (((unsigned)blockIdx.x * (unsigned)S + (unsigned)qq) << 8) + (unsigned)keyv[j], (unsigned)drop_thr16, drop_scale);
+                            }
+                            pp[hq][r] = pr * fm;                           // dV = (P o M/(1-p))^T dO
+                            dd[hq][r] = pr * (dpv[r] * fm - dlr[hq][r]);   // dS / scale
+                        }
+                    }
+                    pf[j] = pack_frag(pp[0], pp[1]);
+                    dsf[j] = pack_frag(dd[0], dd[1]);
+                    // exchange image: row = key, columns 32 p + 16 hq + 4 g .. + 3 of the block (8 bytes per query tile)
+                    const uint4 w4 = __builtin_bit_cast(uint4, dsf[j]);
+                    const int krow = (wave + ATTB_WAVES * j) * 16 + i;
+                    *(uint2*)(dsimg + tile_off(krow, 4 * p + (g >> 1)) + 8 * (g & 1)) = make_uint2(w4.x, w4.y);
+                    *(uint2*)(dsimg + tile_off(krow, 4 * p + 2 + (g >> 1)) + 8 * (g & 1)) = make_uint2(w4.z, w4.w);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 trdo = lds_tr_frag(doimg, s, dt, lane);
+                    const bf16x8 trq = lds_tr_frag(qimg, s, dt, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (j >= nown) continue;
+                        dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trdo, pf[j], dv[j][dt], 0, 0, 0);
+                        dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trq, dsf[j], dk[j][dt], 0, 0, 0);
+                    }
+                }
+            } else {
+                // a query pair past the end (the block's second pair when NP is odd): its columns of the exchange image are read by no one
+            }
+        }
+        __syncthreads();   // the block's dS is complete
+        // ------------ dQ of the block: wave -> (query tile 4 it + (wave >> 1), head-dim half wave & 1), all keys
+        {
+            const int qtl = wave >> 1, pr2 = wave & 1;
+            const int qt = 4 * it + qtl;
+            if (qt < NT) {
+                f32x4 dq0 = (f32x4){0, 0, 0, 0}, dq1 = (f32x4){0, 0, 0, 0};
+#pragma unroll 1
+                for (int sp = 0; sp < NP; ++sp) {
+                    const bf16x8 dsb = lds_tr_frag(dsimg, sp, qtl, lane);
+                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(kimg, sp, 2 * pr2, lane), dsb, dq0, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(kimg, sp, 2 * pr2 + 1, lane), dsb, dq1, 0, 0, 0);
+                }
+                const int q = qt * 16 + i;
+                store_rows16_pair(dqbase + (size_t)min(q, S - 1) * ld, dq0, dq1, scale, q < S, g, pr2);
+            }
+        }
+        __syncthreads();   // before the next block's dS overwrites the exchange image
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j >= nown) continue;
+        const size_t roff = (size_t)min(keyv[j], S - 1) * ld;
+        store_rows16(dqbase + H + roff, dk[j], scale, keyv[j] < S, g);
+        store_rows16(dqbase + 2 * H + roff, dv[j], 1.0f, keyv[j] < S, g);
+    }
+}
+
 static int att_check(const void* qkv, int B, int S, int nheads, const char* who) {
     if (!qkv) return set_error(CLIBD_EINVAL, "attention: null pointer");
     if (B <= 0 || S <= 0 || nheads <= 0) return set_error(CLIBD_EINVAL, "attention: non-positive shape");
@@ -881,7 +1122,8 @@ using namespace clibd;
     }
 
 static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,
-                              int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, float out_fp8_scale, void* stream) {
+                              int nq, int out_seq, uint32_t drop_seed, int drop_thr16, float drop_scale, float out_fp8_scale, void* stream,
+                              float* lse = nullptr, void* o_lo = nullptr) {
     if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "attention_fwd: bad dropout threshold");
     if (drop_thr16 > 0 && (unsigned long long)B * nheads * S * 256ull >= (1ull << 32)) return set_error(CLIBD_EINVAL, "attention_fwd: dropout index overflow");
     if (int e = att_check(qkv, B, S, nheads, "fwd")) return e;
@@ -907,12 +1149,12 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
             hipFuncSetAttribute((const void*)attention_fwd_persistent_kernel<NP, MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
             hipLaunchKernelGGL((attention_fwd_persistent_kernel<NP, MSK, DRP>), dim3(num_cus), dim3(64 * ATTP_WAVES), ldsp, st, \
                                (const unsigned short*)qkv, S, nheads, total, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
-                               drop_seed, drop_thr16, drop_scale, out_fp8_scale);                                 \
+                               drop_seed, drop_thr16, drop_scale, out_fp8_scale, lse, (unsigned short*)o_lo);      \
         } else {                                                                                                  \
         hipFuncSetAttribute((const void*)attention_fwd_kernel<N, (N >= 10), MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((attention_fwd_kernel<N, (N >= 10), MSK, DRP>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,       \
                            (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
-                           drop_seed, drop_thr16, drop_scale, out_fp8_scale);                                     \
+                           drop_seed, drop_thr16, drop_scale, out_fp8_scale, lse, (unsigned short*)o_lo);         \
         }                                                                                                         \
     } while (0)
 #define LAUNCH(N)                                                        \
@@ -926,6 +1168,41 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
 #undef LAUNCH
 #undef LAUNCH_M
     return check_launch("attention_fwd");
+}
+
+// Training forward for the single-pass backward: the same kernels, which also write lse [B * nheads, S] (fp32, log2 domain) and
+// o_lo (bf16 [B * S, H]: the rounding residual of `out`).  nq = S only (the backward that consumes them needs every query row).
+extern "C" int clibd_attention_fwd_save(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out, uint32_t drop_seed,
+                                        int drop_thr16, float drop_scale, float* lse, void* o_lo, void* stream) {
+    if (!lse || !o_lo) return set_error(CLIBD_EINVAL, "attention_fwd_save: null lse / o_lo");
+    if (!aligned16(o_lo) || ((uintptr_t)lse & 3)) return set_error(CLIBD_EINVAL, "attention_fwd_save: alignment");
+    return attention_fwd_impl(qkv, B, S, nheads, key_mask, out, S, S, drop_seed, drop_thr16, drop_scale, 0.f, stream, lse, o_lo);
+}
+
+extern "C" int clibd_attention_bwd_sp(const void* qkv, const void* dout, const void* out, const void* o_lo, const float* lse, int B, int S,
+                                      int nheads, void* dqkv, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
+    if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "attention_bwd_sp: bad dropout threshold");
+    if (drop_thr16 > 0 && (unsigned long long)B * nheads * S * 256ull >= (1ull << 32)) return set_error(CLIBD_EINVAL, "attention_bwd_sp: dropout index overflow");
+    if (int e = att_check(qkv, B, S, nheads, "bwd_sp")) return e;
+    if (!dout || !dqkv || !out || !o_lo || !lse) return set_error(CLIBD_EINVAL, "attention_bwd_sp: null pointer");
+    if (S > 224) return set_error(CLIBD_EINVAL, "attention_bwd_sp: S must be <= 224 (five LDS images); use clibd_attention_bwd");
+    if (!aligned16(dout) || !aligned16(dqkv) || !aligned16(out) || !aligned16(o_lo)) return set_error(CLIBD_EINVAL, "attention_bwd_sp: alignment");
+    const int np = ((S + 15) / 16 + 1) / 2;
+    const size_t lds = (size_t)5 * 32 * np * 128 + (size_t)2 * 32 * np * sizeof(float);
+    const float scale = 0.125f;
+    hipStream_t st = (hipStream_t)stream;
+    if (drop_thr16 > 0) {
+        hipFuncSetAttribute((const void*)attention_bwd_sp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attention_bwd_sp_kernel<true>), dim3(B * nheads), dim3(64 * ATTB_WAVES), lds, st, (const unsigned short*)qkv,
+                           (const unsigned short*)dout, (const unsigned short*)out, (const unsigned short*)o_lo, lse, S, nheads,
+                           (unsigned short*)dqkv, scale, drop_seed, drop_thr16, drop_scale);
+    } else {
+        hipFuncSetAttribute((const void*)attention_bwd_sp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attention_bwd_sp_kernel<false>), dim3(B * nheads), dim3(64 * ATTB_WAVES), lds, st, (const unsigned short*)qkv,
+                           (const unsigned short*)dout, (const unsigned short*)out, (const unsigned short*)o_lo, lse, S, nheads,
+                           (unsigned short*)dqkv, scale, drop_seed, drop_thr16, drop_scale);
+    }
+    return check_launch("attention_bwd_sp");
 }
 
 extern "C" int clibd_attention_fwd_drop(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out,

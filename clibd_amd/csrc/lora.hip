@@ -403,6 +403,34 @@ __global__ __launch_bounds__(256) void lora_dt_db_kernel(const unsigned short* _
     }
 }
 
+// Standalone down-projection t[m, 0:8] = bf16(x[m, :] . a_cat[0:8, :]^T) (bf16 operands, fp32 accumulation) — the arithmetic the
+// LayerNorm kernel fuses for the first rank-(4+4) slot.  Used for the SECOND slot of adapters with 4 < r <= 8 (the reference
+// accepts any r > 0, image_encoder.py:50-53): a rare configuration, one wave per row, not tuned.
+__global__ __launch_bounds__(256) void lora_down_proj_kernel(const unsigned short* __restrict__ x, int ld, const unsigned short* __restrict__ a_cat,
+                                                             int M, int H, unsigned short* __restrict__ t) {
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * 4;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += nwaves) {
+        float tp[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tp[r] = 0.f;
+        for (int c = 8 * lane; c < H; c += 512) {
+            const bf16x8 xv = *(const bf16x8*)(x + (size_t)row * ld + c);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bf16x8 av = *(const bf16x8*)(a_cat + (size_t)r * H + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tp[r] += bf2f((unsigned short)xv[e]) * bf2f((unsigned short)av[e]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float sum = wave_sum(tp[r]);
+            if (lane == r) t[(size_t)row * 8 + r] = f2bf(sum);
+        }
+    }
+}
+
 }  // namespace clibd
 
 using namespace clibd;
@@ -527,4 +555,15 @@ extern "C" int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_
 #undef LWM_LAUNCH2
     }
     return check_launch("lora_backward (dA)");
+}
+
+extern "C" int clibd_lora_down_proj(const void* x_bf16, int ld_x, const void* a_cat_bf16, int M, int H, void* t_bf16, void* stream) {
+    if (!x_bf16 || !a_cat_bf16 || !t_bf16) return set_error(CLIBD_EINVAL, "lora_down_proj: null pointer");
+    if (M <= 0 || H <= 0 || H % 8 != 0 || ld_x < H || ld_x % 8 != 0) return set_error(CLIBD_EINVAL, "lora_down_proj: bad shape");
+    if (!aligned16(x_bf16) || !aligned16(a_cat_bf16) || !aligned16(t_bf16)) return set_error(CLIBD_EINVAL, "lora_down_proj: alignment");
+    int blocks = (M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(lora_down_proj_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16, ld_x,
+                       (const unsigned short*)a_cat_bf16, M, H, (unsigned short*)t_bf16);
+    return check_launch("lora_down_proj");
 }

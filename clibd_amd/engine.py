@@ -39,6 +39,15 @@ def residual_grad_bf16() -> bool:
     return os.environ.get("CLIBD_RESIDUAL_GRAD", "bf16").lower() != "fp32"
 
 
+# Attention backward: "sp" = single pass (ops.attention_bwd_sp; the training forward then also saves its per-layer output, the
+# rounding residual of that output and the log-sum-exp: 4 more bytes per element of activation memory per layer), "2phase" = the
+# kernel that derives the softmax statistics itself and evaluates every score twice.  The single-pass form needs full
+# sequences without a key mask, S <= 224 and the bf16 forward; everything else (text tower, the class-row-only last ViT block,
+# fp8-forward mode) keeps the two-phase kernel.
+def attention_backward_single_pass() -> bool:
+    return os.environ.get("CLIBD_ATTN_BWD", "sp").lower() != "2phase"
+
+
 @dataclass
 class LoraParams:
     """The four adapter matrices of one layer (nn.Parameters, fp32): a_* [4,H], b_* [H,4]."""
@@ -77,7 +86,7 @@ class _LayerCache:
     """bf16 device images of one layer's frozen weights: W [N,K] for forward, W^T [K,N] for dgrad.
     fp8-forward mode adds the e4m3 forward images and their per-channel dequantisation factors (w*8, cs_*)."""
     __slots__ = ("wqkv", "wqkv_t", "bqkv", "wo", "wo_t", "bo", "w1", "w1_t", "b1", "w2", "w2_t", "b2", "g1", "be1", "g2", "be2",
-                 "v_fwd", "v_bwd", "a_cat", "w_dt", "wqkv8", "cs_qkv", "wo8", "cs_o", "w18", "cs_1", "w28", "cs_2")
+                 "v_fwd", "v_bwd", "a_cat", "w_dt", "slot2", "wqkv8", "cs_qkv", "wo8", "cs_o", "w18", "cs_1", "w28", "cs_2")
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -85,17 +94,25 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t if (t.dtype == F32 and t.is_contiguous()) else t.to(F32).contiguous()
 
 
-def _pad_rank4(lp: "LoraParams"):
-    """The kernels carry the adapters as rank 4 + 4 (one MFMA k-slot of 8).  Ranks 1-3 (the reference accepts any r > 0,
-    image_encoder.py:53; every shipped config uses 4) run zero-padded: A gets zero rows, B zero columns — the same product."""
+def _rank_slots(lp: "LoraParams"):
+    """The kernels carry the adapters as rank 4 + 4 (q and v in one MFMA k-slot of 8).  The reference accepts any r > 0
+    (image_encoder.py:53; every shipped config uses 4): ranks 1-3 run zero-padded — A gets zero rows, B zero columns, the same
+    product — and ranks 5-8 as TWO such slots, rows / columns 0-3 and 4-7 of every adapter matrix (B A x = B1 A1 x + B2 A2 x):
+    the second slot's down-projection, rank update and gradients take a pass of their own (TransformerStack._slot2_*).
+    Returns [(a_q, a_v, b_q, b_v)] per slot, each [4,H] / [H,4] fp32."""
     a_q, a_v, b_q, b_v = _f32c(lp.a_q), _f32c(lp.a_v), _f32c(lp.b_q), _f32c(lp.b_v)
-    r = a_q.shape[0]
-    if r == 4:
-        return a_q, a_v, b_q, b_v
-    H = a_q.shape[1]
-    pa = lambda a: torch.cat([a, a.new_zeros((4 - r, H))], dim=0)
-    pb = lambda b: torch.cat([b, b.new_zeros((H, 4 - r))], dim=1).contiguous()
-    return pa(a_q), pa(a_v), pb(b_q), pb(b_v)
+    r, H = a_q.shape
+    if r > 8:
+        raise NotSupportedYet("LoRA rank > 8 (two rank-4 slots per adapter)")
+
+    def slot(lo):
+        hi = min(lo + 4, r)
+        k = hi - lo
+        pa = lambda a: a[lo:hi].contiguous() if k == 4 else torch.cat([a[lo:hi], a.new_zeros((4 - k, H))], dim=0)
+        pb = lambda b: (b[:, lo:hi] if k == 4 else torch.cat([b[:, lo:hi], b.new_zeros((H, 4 - k))], dim=1)).contiguous()
+        return pa(a_q), pa(a_v), pb(b_q), pb(b_v)
+
+    return [slot(0)] + ([slot(4)] if r > 4 else [])
 
 
 class TransformerStack:
@@ -195,7 +212,7 @@ class TransformerStack:
                     c.wo8, c.cs_o = ops.quantize_rows_fp8(_f32c(L.proj_w), f8["proj_in"])
                     c.w18, c.cs_1 = ops.quantize_rows_fp8(_f32c(L.fc1_w), f8["fc1_in"])
                     c.w28, c.cs_2 = ops.quantize_rows_fp8(_f32c(L.fc2_w), f8["fc2_in"])
-                c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = None
+                c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = c.slot2 = None
                 self._cache.append(c)
         self._cache_key = key
 
@@ -205,14 +222,44 @@ class TransformerStack:
         for L, c in zip(self.layers, self._cache):
             if L.lora is None:
                 continue
+            dev = L.proj_w.device
+            images = lambda: dict(v_fwd=torch.empty((3 * H, 8), dtype=BF16, device=dev), v_bwd=torch.empty((H, 8), dtype=BF16, device=dev),
+                                  a_cat=torch.empty((8, H), dtype=BF16, device=dev), w_dt=torch.empty((16, 3 * H), dtype=BF16, device=dev))
             if c.v_fwd is None:
-                dev = L.proj_w.device
-                c.v_fwd = torch.empty((3 * H, 8), dtype=BF16, device=dev)
-                c.v_bwd = torch.empty((H, 8), dtype=BF16, device=dev)
-                c.a_cat = torch.empty((8, H), dtype=BF16, device=dev)
-                c.w_dt = torch.empty((16, 3 * H), dtype=BF16, device=dev)
-            lp = L.lora
-            ops.lora_pack(*_pad_rank4(lp), c.v_fwd, c.v_bwd, c.a_cat, c.w_dt)
+                im = images()
+                c.v_fwd, c.v_bwd, c.a_cat, c.w_dt = im["v_fwd"], im["v_bwd"], im["a_cat"], im["w_dt"]
+            slots = _rank_slots(L.lora)
+            ops.lora_pack(*slots[0], c.v_fwd, c.v_bwd, c.a_cat, c.w_dt)
+            if len(slots) > 1:      # ranks 5-8: the second rank-(4+4) slot
+                if self.fp8 is not None:
+                    raise NotSupportedYet("fp8 forward with LoRA rank > 4")
+                if c.slot2 is None:
+                    c.slot2 = images()
+                ops.lora_pack(*slots[1], c.slot2["v_fwd"], c.slot2["v_bwd"], c.slot2["a_cat"], c.slot2["w_dt"])
+            else:
+                c.slot2 = None
+
+    # ---- second rank slot (4 < r <= 8): passes built from the existing kernels — a zero-operand GEMM whose rank-8 MFMA step
+    # carries t2 . V2^T and whose epilogue adds the first slot's result
+    def _slot2_fwd(self, c, x_bf16, qkv):
+        """qkv + (x A2^T) B2^T for q and v: returns (new qkv, t2)."""
+        M = qkv.shape[0]
+        t2 = ops.lora_down_proj(x_bf16, c.slot2["a_cat"])
+        out = torch.empty_like(qkv)
+        ops.gemm_nt(torch.zeros((M, 64), dtype=BF16, device=qkv.device), torch.zeros((qkv.shape[1], 64), dtype=BF16, device=qkv.device),
+                    rank_u=t2, rank_v=c.slot2["v_fwd"], act=ops.ACT_ADD_AUX, aux=qkv, out_bf16=out)
+        return out, t2
+
+    def _slot2_dgrad(self, c, dt2, dx):
+        """dx + dt2 . A_cat2 (the second slot's share of the QKV input gradient); dx bf16 or fp32, a new tensor is returned."""
+        M, Hd = dx.shape
+        zA, zW = torch.zeros((M, 64), dtype=BF16, device=dx.device), torch.zeros((Hd, 64), dtype=BF16, device=dx.device)
+        out = torch.empty_like(dx)
+        if dx.dtype == BF16:
+            ops.gemm_nt(zA, zW, rank_u=dt2, rank_v=c.slot2["v_bwd"], act=ops.ACT_ADD_AUX, aux=dx, out_bf16=out)
+        else:
+            ops.gemm_nt(zA, zW, rank_u=dt2, rank_v=c.slot2["v_bwd"], residual=dx, out_f32=out)
+        return out
 
     def lora_a(self, i: int):
         if i >= len(self.layers) or self.layers[i].lora is None:
@@ -249,9 +296,12 @@ class TransformerStack:
         xn8 = new(H, ops.FP8) if f8s is not None else None   # fp8 image of the first LayerNorm's output (temporary)
         h_tmp = new(FF, BF16) if (f8s is not None and not save) else None       # the fp8 fc1 form always writes gelu'
         t = t0
+        sp_ok = save and key_mask is None and f8s is None and S <= 224 and attention_backward_single_pass()
         for i, (L, c) in enumerate(zip(self.layers, self._cache)):
             has_lora = L.lora is not None
             rec = {}
+            att_sv = None
+            t2 = None   # second rank slot's down-projection (LoRA ranks 5-8)
             f8 = f8s[i] if f8s is not None else None
             crec = {} if cal is not None else None
             if keep:
@@ -269,6 +319,8 @@ class TransformerStack:
                 else:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
                     ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
+                    if c.slot2 is not None:
+                        qkv, t2 = self._slot2_fwd(c, xn, qkv)
                     if crec is not None:
                         crec["qkv_in"] = amax(xn)
                 newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
@@ -286,7 +338,7 @@ class TransformerStack:
                 x2 = newB(H, F32)
                 ops.gemm_nt(ac, c.w2, bias=c.b2, residual=x1, out_f32=x2)
                 if save:
-                    rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h, cls_only=True)
+                    rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, t2=t2, qkv=qkv, x1=x1, st2=st2, h=h, cls_only=True)
                     if keep:
                         rec.update(o=o_cls, xn2=xn2c, a=ac)
                 x_f32 = x2
@@ -312,7 +364,14 @@ class TransformerStack:
                 else:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
                     ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
-                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
+                    if c.slot2 is not None:
+                        qkv, t2 = self._slot2_fwd(c, xn, qkv)
+                    if sp_ok:   # training forward of the single-pass attention backward: this layer's o, its rounding residual, the lse
+                        o = o if keep else new(H, BF16)
+                        att_sv = dict(o_att=o, o_lo=new(H, BF16), lse=torch.empty((B * self.heads * S,), dtype=F32, device=dev))
+                        ops.attention_fwd(qkv, B, S, self.heads, None, o, lse=att_sv["lse"], o_lo=att_sv["o_lo"])
+                    else:
+                        ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
                     ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
                     ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
                     ops.gemm_nt(xn2, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
@@ -320,9 +379,11 @@ class TransformerStack:
                     if crec is not None:
                         crec.update(qkv_in=amax(xn), proj_in=amax(o), fc1_in=amax(xn2), fc2_in=amax(a))
                 if save:
-                    rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, qkv=qkv, x1=x1, st2=st2, h=h)
+                    rec = dict(x_in=x_f32, st1=st1, xn=xn, t=t, t2=t2, qkv=qkv, x1=x1, st2=st2, h=h)
                     if keep:
                         rec.update(o=o, xn2=xn2, a=a)
+                    if att_sv is not None:
+                        rec.update(att_sv)
                 x_f32 = x2
             else:
                 d_att = d_h1 = d_h2 = None
@@ -360,7 +421,14 @@ class TransformerStack:
                 else:
                     x1_bf16 = new(H, BF16)
                     ops.gemm_nt(x_bf16, c.wqkv, bias=c.bqkv, rank_u=ru, rank_v=rv, out_bf16=qkv)
-                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att)
+                    if c.slot2 is not None:
+                        qkv, t2 = self._slot2_fwd(c, x_bf16, qkv)
+                    if sp_ok:
+                        o = o if keep else new(H, BF16)
+                        att_sv = dict(o_att=o, o_lo=new(H, BF16), lse=torch.empty((B * self.heads * S,), dtype=F32, device=dev))
+                        ops.attention_fwd(qkv, B, S, self.heads, None, o, drop=d_att, lse=att_sv["lse"], o_lo=att_sv["o_lo"])
+                    else:
+                        ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att)
                     ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=s1, drop=d_h1)
                     ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_bf16=x1_bf16, y_f32=x1_f32, stats=st1)
                     ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
@@ -369,10 +437,12 @@ class TransformerStack:
                     if crec is not None:
                         crec.update(qkv_in=amax(x_bf16), proj_in=amax(o), fc1_in=amax(x1_bf16), fc2_in=amax(a))
                 if save:
-                    rec = dict(x_bf16=x_bf16, t=t if has_lora else None, qkv=qkv, s1=s1, st1=st1, h=h, s2=s2, st2=st2,
+                    rec = dict(x_bf16=x_bf16, t=t if has_lora else None, t2=t2, qkv=qkv, s1=s1, st1=st1, h=h, s2=s2, st2=st2,
                                d_att=d_att, d_h1=d_h1, d_h2=d_h2)
                     if keep:
                         rec.update(o=o, x1_bf16=x1_bf16, a=a)
+                    if att_sv is not None:
+                        rec.update(att_sv)
                 x_f32, x_bf16, t = x2_f32, x2_bf16, t_next
             saved.append(rec)
             if cal is not None:
@@ -409,6 +479,7 @@ class TransformerStack:
         for i in range(len(self.layers) - 1, -1, -1):
             L, c, rec = self.layers[i], self._cache[i], saved[i]
             has_lora = L.lora is not None
+            dt2 = None   # second rank slot's dt (LoRA ranks 5-8), set by _lora_grads
             if i < first_lora:
                 break  # nothing trainable at or below this layer
             if self.pre_ln and rec.get("cls_only"):
@@ -425,19 +496,20 @@ class TransformerStack:
                 ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtc)                                              # d(attn out), class rows
                 ops.attention_bwd(rec["qkv"], dtc, B, S, self.heads, key_mask, dqkv, nq=1)
                 if has_lora:
-                    self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads)
+                    dt2 = self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads, rec.get("t2"))
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
+                    dq_in = dtmp if dt2 is None else self._slot2_dgrad(c, dt2, dtmp)
                     if r16:
                         dres16, _ = ops.scatter_rows(dx1_f32, S, bf16=True, f32=False)           # residual path: class rows only
                         ndx_bf16 = new(H, BF16)
-                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16)
+                        ops.layernorm_bwd(dq_in, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16)
                         dx_f32, dx_bf16 = None, ndx_bf16
                     else:
                         _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)        # residual path: class rows only
                         ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
-                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
+                        ops.layernorm_bwd(dq_in, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
                         dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif self.pre_ln:
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
@@ -452,18 +524,19 @@ class TransformerStack:
                     ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
                 wg(dx1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtmp)                                             # d(attn out)
-                ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv)
+                self._attention_bwd(rec, dtmp, B, S, key_mask, dqkv)
                 if has_lora:
-                    self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads)
+                    dt2 = self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads, rec.get("t2"))
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
+                    dq_in = dtmp if dt2 is None else self._slot2_dgrad(c, dt2, dtmp)
                     if r16:
                         ndx_f32, ndx_bf16 = None, new(H, BF16)
-                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16)
+                        ops.layernorm_bwd(dq_in, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16)
                     else:
                         ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
-                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
+                        ops.layernorm_bwd(dq_in, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
                     dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif r16:
                 # post-LN, bf16 stream: `dx_f32` holds the incoming gradient of the layer output (fp32 from the head at the top layer,
@@ -484,14 +557,14 @@ class TransformerStack:
                 ops.gemm_nt(dh, c.w1_t, act=ops.ACT_ADD_AUX, aux=ds2_res, out_bf16=dx1)
                 ds1_res, ds1_b = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"])
                 ops.gemm_nt(ds1_b, c.wo_t, out_bf16=dtmp)
-                ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv, drop=rec["d_att"])
+                self._attention_bwd(rec, dtmp, B, S, key_mask, dqkv, drop=rec["d_att"])
                 if has_lora:
-                    self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads)
+                    dt2 = self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads, rec.get("t2"))
                 if i > first_lora:
                     ndx = new(H, BF16)
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
                                 act=ops.ACT_ADD_AUX, aux=ds1_res, out_bf16=ndx)
-                    dx_f32 = ndx
+                    dx_f32 = ndx if dt2 is None else self._slot2_dgrad(c, dt2, ndx)
             else:
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"], **pg(L.ln2_w, L.ln2_b))
@@ -504,34 +577,51 @@ class TransformerStack:
                 ops.layernorm_bwd(dx1, rec["s1"], rec["st1"], c.g1, dx_f32=ds1_f32, dx_bf16=ds1_bf16, drop=rec["d_h1"], **pg(L.ln1_w, L.ln1_b))
                 wg(ds1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(ds1_bf16, c.wo_t, out_bf16=dtmp)
-                ops.attention_bwd(rec["qkv"], dtmp, B, S, self.heads, key_mask, dqkv, drop=rec["d_att"])
+                self._attention_bwd(rec, dtmp, B, S, key_mask, dqkv, drop=rec["d_att"])
                 if has_lora:
-                    self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads)
+                    dt2 = self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads, rec.get("t2"))
                 wg(dqkv, rec["x_bf16"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ndx = new(H, F32)
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
                                 residual=ds1_f32, out_f32=ndx)
-                    dx_f32 = ndx
+                    dx_f32 = ndx if dt2 is None else self._slot2_dgrad(c, dt2, ndx)
             if on_layer_done is not None:
                 on_layer_done(i)
         return dx_f32 if full else None
 
-    def _lora_grads(self, L, c, dqkv, x_bf16, t, dt, grads):
+    def _attention_bwd(self, rec, dout, B, S, key_mask, dqkv, drop=None):
+        if "lse" in rec:   # the forward saved what the single-pass kernel needs
+            ops.attention_bwd_sp(rec["qkv"], dout, rec["o_att"], rec["o_lo"], rec["lse"], B, S, self.heads, dqkv, drop=drop)
+        else:
+            ops.attention_bwd(rec["qkv"], dout, B, S, self.heads, key_mask, dqkv, drop=drop)
+
+    def _lora_grads(self, L, c, dqkv, x_bf16, t, dt, grads, t2=None):
+        """dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v (the rank-8 operand of the QKV dgrad that follows) and the four adapter gradients
+        in one call: dq and dv are streamed once for dt and dB together (clibd_lora_backward); the k segment of dqkv is never read.
+        Ranks other than 4 run on rank-4 slots (_rank_slots): scratch gradients, sliced back; ranks 5-8 take a second call with the
+        second slot's images and down-projection t2, whose dt (returned) joins the QKV dgrad through _slot2_dgrad."""
         H = self.H
-        # dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v (the rank-8 operand of the QKV dgrad that follows) and the four adapter gradients in
-        # one call: dq and dv are streamed once for dt and dB together (clibd_lora_backward); the k segment of dqkv is never read
         lp = L.lora
         r = lp.a_q.shape[0]
         if r == 4:
             ops.lora_backward(dqkv, x_bf16, t, c.w_dt, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
-        else:   # ranks 1-3: rank-4 scratch gradients (the padded rows / columns receive exact zeros' worth of signal), sliced back
-            dev = dqkv.device
+            return None
+        dev = dqkv.device
+        dt2 = None
+        for k, (tk, w_dt, dtk) in enumerate(((t, c.w_dt, dt), (t2, None if c.slot2 is None else c.slot2["w_dt"], None))):
+            lo = 4 * k
+            if lo >= r:
+                break
+            if k == 1:
+                dtk = dt2 = torch.empty_like(dt)
             ga_q, ga_v = torch.zeros((4, H), dtype=F32, device=dev), torch.zeros((4, H), dtype=F32, device=dev)
             gb_q, gb_v = torch.zeros((H, 4), dtype=F32, device=dev), torch.zeros((H, 4), dtype=F32, device=dev)
-            ops.lora_backward(dqkv, x_bf16, t, c.w_dt, dt, ga_q, ga_v, gb_q, gb_v)
-            grads[id(lp.a_q)].add_(ga_q[:r]); grads[id(lp.a_v)].add_(ga_v[:r])
-            grads[id(lp.b_q)].add_(gb_q[:, :r]); grads[id(lp.b_v)].add_(gb_v[:, :r])
+            ops.lora_backward(dqkv, x_bf16, tk, w_dt, dtk, ga_q, ga_v, gb_q, gb_v)
+            n = min(4, r - lo)   # the padded rows / columns receive exact zeros' worth of signal
+            grads[id(lp.a_q)][lo:lo + n].add_(ga_q[:n]); grads[id(lp.a_v)][lo:lo + n].add_(ga_v[:n])
+            grads[id(lp.b_q)][:, lo:lo + n].add_(gb_q[:, :n]); grads[id(lp.b_v)][:, lo:lo + n].add_(gb_v[:, :n])
+        return dt2
 
 
 def linear_wgrad(dy_bf16: torch.Tensor, x_bf16: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], grads: dict):

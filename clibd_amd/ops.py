@@ -328,10 +328,24 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, 
 
 
 def attention_fwd(qkv: torch.Tensor, B: int, S: int, nheads: int, key_mask: Optional[torch.Tensor], out: torch.Tensor,
-                  nq: Optional[int] = None, drop=None, out_fp8_scale: float = 0.0) -> None:
+                  nq: Optional[int] = None, drop=None, out_fp8_scale: float = 0.0, lse: Optional[torch.Tensor] = None,
+                  o_lo: Optional[torch.Tensor] = None) -> None:
     """nq: evaluate only the first nq query rows of every sequence; `out` is then [B*nq, H].
-    out_fp8_scale > 0 (fp8-forward mode): `out` is float8_e4m3fn and receives e4m3(o * out_fp8_scale)."""
+    out_fp8_scale > 0 (fp8-forward mode): `out` is float8_e4m3fn and receives e4m3(o * out_fp8_scale).
+    lse (fp32 [B*nheads*S]) + o_lo (bf16 [B*S, H]): training forward for attention_bwd_sp (clibd_attention_fwd_save)."""
     _chk(qkv, BF16, "qkv")
+    if lse is not None or o_lo is not None:
+        _chk(out, BF16, "out"); _chk(lse, F32, "lse"); _chk(o_lo, BF16, "o_lo")
+        H_ = nheads * 64
+        if (nq is not None and nq != S) or out_fp8_scale > 0 or tuple(qkv.shape) != (B * S, 3 * H_) or tuple(out.shape) != (B * S, H_) \
+                or tuple(o_lo.shape) != (B * S, H_) or lse.numel() != B * nheads * S:
+            raise ValueError("attention_fwd: the saving form needs nq = S, bf16 out [B*S,H], o_lo [B*S,H], lse [B*nheads*S]")
+        if key_mask is not None:
+            _chk(key_mask, I32, "key_mask")
+        d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
+        check(_lib.load().clibd_attention_fwd_save(qkv.data_ptr(), B, S, nheads, _p(key_mask), out.data_ptr(), d.seed, d.thr16, d.scale,
+                                                   lse.data_ptr(), o_lo.data_ptr(), _stream()), "attention_fwd_save")
+        return
     _chk(out, FP8 if out_fp8_scale > 0 else BF16, "out")
     H = nheads * 64
     nq = S if nq is None else nq
@@ -372,6 +386,23 @@ def attention_bwd(qkv, dout, B, S, nheads, key_mask, dqkv, nq: Optional[int] = N
           "attention_bwd")
 
 
+def attention_bwd_sp(qkv, dout, out, o_lo, lse, B, S, nheads, dqkv, drop=None) -> None:
+    """Single-pass backward from the forward's saved output, rounding residual and log-sum-exp (clibd_attention_bwd_sp):
+    full sequences, no key mask, S <= 224."""
+    H = nheads * 64
+    for nm, t, shape in (("qkv", qkv, (B * S, 3 * H)), ("dout", dout, (B * S, H)), ("out", out, (B * S, H)), ("o_lo", o_lo, (B * S, H)),
+                         ("dqkv", dqkv, (B * S, 3 * H))):
+        _chk(t, BF16, nm)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"attention_bwd_sp: {nm} must be {shape}")
+    _chk(lse, F32, "lse")
+    if lse.numel() != B * nheads * S:
+        raise ValueError("attention_bwd_sp: lse must have B*nheads*S elements")
+    d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
+    check(_lib.load().clibd_attention_bwd_sp(qkv.data_ptr(), dout.data_ptr(), out.data_ptr(), o_lo.data_ptr(), lse.data_ptr(), B, S, nheads,
+                                             dqkv.data_ptr(), d.seed, d.thr16, d.scale, _stream()), "attention_bwd_sp")
+
+
 def lora_pack(a_q, a_v, b_q, b_v, v_fwd, v_bwd, a_cat, w_dt) -> None:
     H = a_q.shape[1]
     for nm, t, shape in (("a_q", a_q, (4, H)), ("a_v", a_v, (4, H)), ("b_q", b_q, (H, 4)), ("b_v", b_v, (H, 4))):
@@ -384,6 +415,18 @@ def lora_pack(a_q, a_v, b_q, b_v, v_fwd, v_bwd, a_cat, w_dt) -> None:
             raise ValueError(f"lora_pack: {nm} must be {shape}")
     check(_lib.load().clibd_lora_pack(a_q.data_ptr(), a_v.data_ptr(), b_q.data_ptr(), b_v.data_ptr(), H, v_fwd.data_ptr(),
                                       v_bwd.data_ptr(), a_cat.data_ptr(), w_dt.data_ptr(), _stream()), "lora_pack")
+
+
+def lora_down_proj(x: torch.Tensor, a_cat: torch.Tensor) -> torch.Tensor:
+    """t [M,8] = bf16(x [M,H] . a_cat [8,H]^T): the adapters' down-projection as its own kernel (second rank slot, 4 < r <= 8)."""
+    _chk(x, BF16, "x", contiguous=False)
+    _chk(a_cat, BF16, "a_cat")
+    M, H = x.shape
+    if tuple(a_cat.shape) != (8, H):
+        raise ValueError("lora_down_proj: a_cat must be [8,H]")
+    t = torch.empty((M, 8), dtype=BF16, device=x.device)
+    check(_lib.load().clibd_lora_down_proj(x.data_ptr(), _rowmajor(x, "x"), a_cat.data_ptr(), M, H, t.data_ptr(), _stream()), "lora_down_proj")
+    return t
 
 
 def lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v) -> None:

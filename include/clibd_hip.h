@@ -176,6 +176,18 @@ int clibd_attention_fwd(const void* qkv, int B, int S, int nheads, const int32_t
                         int nq, int out_seq, void* stream);
 int clibd_attention_bwd(const void* qkv, const void* dout, int B, int S, int nheads, const int32_t* key_mask,
                         void* dqkv, int nq, int dout_seq, void* stream);
+
+/* Single-pass backward (frozen-base training, full sequences): the forward also saves, per (head, query), the log2-domain
+ * log-sum-exp of the un-dropped scores — lse fp32 [B * nheads, S] — and the bf16 residual of its output rounding — o_lo bf16
+ * [B * S, H], out + o_lo = the fp32 output to 2^-17 — so that the backward evaluates every score, exponential and dP ONCE:
+ *   P = exp2(c2 s - lse), delta = dO . (out + o_lo), dS = P o (dP - delta), dV += P^T dO, dK += dS^T Q, dQ += dS K
+ * (one 8-wave workgroup per head, K / V / Q / dO resident in LDS, dK / dV in the key-owning wave's accumulators, dQ from a dS
+ * exchange through LDS: no atomics, deterministic).  Same results as clibd_attention_bwd up to rounding points.
+ * clibd_attention_fwd_save: nq = S; key_mask allowed in the forward.  clibd_attention_bwd_sp: no key mask, S <= 224. */
+int clibd_attention_fwd_save(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out, uint32_t drop_seed,
+                             int drop_thr16, float drop_scale, float* lse, void* o_lo, void* stream);
+int clibd_attention_bwd_sp(const void* qkv, const void* dout, const void* out, const void* o_lo, const float* lse, int B, int S,
+                           int nheads, void* dqkv, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream);
 /* fp8-forward mode: the attention output leaves as e4m3(o * out_fp8_scale) bytes [B*out_seq, H] (operand of the projection
  * clibd_gemm_fp8_nt; the backward recomputes what it needs from qkv, so no bf16 copy is kept). */
 int clibd_attention_fwd_fp8(const void* qkv, int B, int S, int nheads, const int32_t* key_mask, void* out_fp8,
@@ -205,6 +217,10 @@ int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B, int S, in
  * ------------------------------------------------------------------------------------------------ */
 int clibd_lora_pack(const float* a_q, const float* a_v, const float* b_q, const float* b_v, int H,
                     void* v_fwd_bf16, void* v_bwd_bf16, void* a_cat_bf16, void* w_dt_bf16, void* stream);
+/* t[M,8] = bf16(x[M,H] . a_cat[8,H]^T): the adapters' down-projection on its own (the LayerNorm kernels fuse it for the first
+ * rank-(4+4) slot; adapters with 4 < r <= 8 — the reference accepts any r > 0, image_encoder.py:50-53, dna_encoder.py:80-88 —
+ * carry ranks 5..8 in a second slot whose t comes from here).  x bf16 row stride ld_x (% 8), H % 8 == 0. */
+int clibd_lora_down_proj(const void* x_bf16, int ld_x, const void* a_cat_bf16, int M, int H, void* t_bf16, void* stream);
 int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* dt_bf16,
                      int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v, void* stream);
 /* The adapters' whole backward in one call: dt[M, 0:16] = dqkv . w_dt^T (bf16; columns 8..15 zero: the rank-8 operand of the QKV

@@ -230,6 +230,65 @@ def test_attention_fwd_bwd(ops, dev, B, S, nh, masked):
         assert rel_err(got[:, sl], gref[:, sl]) < 1.5e-2, name
 
 
+@pytest.mark.parametrize("B,S,nh,p_drop", [(2, 197, 2, 0.0), (3, 133, 3, 0.1), (2, 224, 1, 0.0), (5, 20, 2, 0.0), (1, 7, 1, 0.1), (2, 100, 12, 0.0),
+                                            (40, 197, 12, 0.0)])
+def test_attention_single_pass_backward(ops, dev, B, S, nh, p_drop):
+    """clibd_attention_fwd_save + clibd_attention_bwd_sp: the training forward also writes the log-sum-exp and the rounding
+    residual of its output (out unchanged, bit for bit), and the single-pass backward built on them must give the gradients of
+    the fp64 statement (same gate as the two-phase kernel) and agree with the two-phase kernel — under dropout too, where both
+    evaluate the same counter-based masks.  B x heads >= 2 x CUs at S = 197 takes the persistent forward."""
+    g = torch.Generator().manual_seed(S * 5 + nh)
+    H = nh * 64
+    qkv = bfr(torch.randn(B * S, 3 * H, generator=g))
+    do = bfr(torch.randn(B * S, H, generator=g))
+    qkv_d, do_d = qkv.to(dev, BF16), do.to(dev, BF16)
+    drop = ops.Drop(p_drop, 777) if p_drop > 0 else None
+    out = torch.empty((B * S, H), dtype=BF16, device=dev)
+    ops.attention_fwd(qkv_d, B, S, nh, None, out, drop=drop)
+    out2 = torch.full((B * S, H), float("nan"), dtype=BF16, device=dev)
+    o_lo = torch.full((B * S, H), float("nan"), dtype=BF16, device=dev)
+    lse = torch.full((B * nh * S,), float("nan"), dtype=F32, device=dev)
+    ops.attention_fwd(qkv_d, B, S, nh, None, out2, drop=drop, lse=lse, o_lo=o_lo)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out) and torch.isfinite(o_lo.float()).all() and torch.isfinite(lse).all()
+    nb = min(B, 3)                                       # the reference on the first sequences only (the big case is 40 x 12 heads)
+    q, k, _ = qkv[: nb * S].double().view(nb, S, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    sc = (q @ k.transpose(-1, -2)) * 0.125
+    lse_ref = torch.logsumexp(sc, dim=-1) * 1.4426950408889634        # log2 domain, [nb, nh, S]
+    assert (lse.cpu().view(B, nh, S)[:nb].double() - lse_ref).abs().max().item() < 2e-3
+    if p_drop == 0.0:
+        oref = _attn_ref(qkv[: nb * S].double(), nb, S, nh, None)
+        e_hi = (out[: nb * S].cpu().double() - oref).abs().max().item()
+        e_sum = (out[: nb * S].cpu().double() + o_lo[: nb * S].cpu().double() - oref).abs().max().item()
+        assert e_sum < 1.05 * e_hi + 1e-5, (e_hi, e_sum)       # hi + lo is the kernel's fp32 output: no further from the statement than hi alone
+        oh, ol = out.cpu().float(), o_lo.cpu().float()
+        assert bool((ol.abs() <= oh.abs() * 2.0 ** -8 + 1e-30).all())           # the residual of a round-to-nearest: at most half an ulp of hi
+    dq_sp = torch.full((B * S, 3 * H), float("nan"), dtype=BF16, device=dev)
+    ops.attention_bwd_sp(qkv_d, do_d, out, o_lo, lse, B, S, nh, dq_sp, drop=drop)
+    dq_2p = torch.full((B * S, 3 * H), float("nan"), dtype=BF16, device=dev)
+    ops.attention_bwd(qkv_d, do_d, B, S, nh, None, dq_2p, drop=drop)
+    torch.cuda.synchronize()
+    got, old = dq_sp.cpu().float(), dq_2p.cpu().float()
+    assert torch.isfinite(got).all()
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert rel_err(got[:, sl], old[:, sl]) < 1.2e-2, name          # two roundings of the same gradient
+    if p_drop == 0.0:
+        qd = qkv[: nb * S].double().requires_grad_(True)
+        (gref,) = torch.autograd.grad(_attn_ref(qd, nb, S, nh, None), qd, do[: nb * S].double())
+        for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+            e_new, e_old = rel_err(got[: nb * S, sl], gref[:, sl]), rel_err(old[: nb * S, sl], gref[:, sl])
+            assert e_new < 1.5e-2 and e_new < 1.5 * e_old + 1e-3, (name, e_new, e_old)
+    again = torch.empty_like(dq_sp)
+    ops.attention_bwd_sp(qkv_d, do_d, out, o_lo, lse, B, S, nh, again, drop=drop)
+    torch.cuda.synchronize()
+    assert torch.equal(again, dq_sp)                                        # no atomics: bit-reproducible
+    if S > 224 - 32:
+        with pytest.raises(RuntimeError, match="224"):
+            big = torch.zeros((256, 3 * 64), dtype=BF16, device=dev)
+            ops.attention_bwd_sp(big, big[:, :64].contiguous(), big[:, :64].contiguous(), big[:, :64].contiguous(),
+                                 torch.zeros(256, device=dev), 1, 256, 1, torch.empty_like(big))
+
+
 @pytest.mark.parametrize("S,masked,p_drop", [(197, False, 0.0), (133, False, 0.1), (224, True, 0.0), (170, True, 0.1), (256, False, 0.0)])
 def test_attention_persistent_kernels_match_per_head_kernels(ops, dev, S, masked, p_drop):
     """A forward launch with many heads (B * heads >= 2 x CUs) and S > 160 takes the persistent kernel (one workgroup of 16 waves per
