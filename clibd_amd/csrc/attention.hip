@@ -119,8 +119,15 @@ __device__ long long* g_att_stamps = nullptr;   // [workgroup][8]
     do {                                                                                                  \
         if (g_att_stamps != nullptr && threadIdx.x == 0) g_att_stamps[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+// per-wave stamps of the single-pass backward: [workgroup][wave][16]
+#define SP_STAMP(k)                                                                                       \
+    do {                                                                                                  \
+        if (g_att_stamps != nullptr && (threadIdx.x & 63) == 0)                                           \
+            g_att_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
 #else
 #define ATT_STAMP(k) do { } while (0)
+#define SP_STAMP(k) do { } while (0)
 #endif
 
 // ============================================ forward ==========================================================
@@ -937,6 +944,7 @@ __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const
     const int g = lane >> 4, i = lane & 15;
     const float c2 = scale * 1.4426950408889634f;
 
+    SP_STAMP(0);
     stage_head_tile(kimg, qbase + H, ld, S, R, wave, lane, ATTB_WAVES);
     stage_head_tile(vimg, qbase + 2 * H, ld, S, R, wave, lane, ATTB_WAVES);
     stage_head_tile(qimg, qbase, ld, S, R, wave, lane, ATTB_WAVES);
@@ -967,6 +975,7 @@ __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    SP_STAMP(1);
     // ---- this wave's key tiles (0, 1 or 2 of them) as MFMA row fragments, for the whole head
     const int nown = (wave < NT ? 1 : 0) + (wave + ATTB_WAVES < NT ? 1 : 0);
     bf16x8 kf[2][2], vf[2][2];
@@ -1067,7 +1076,9 @@ __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const
                 // a query pair past the end (the block's second pair when NP is odd): its columns of the exchange image are read by no one
             }
         }
+        if (it < 4) SP_STAMP(2 + 3 * it);
         __syncthreads();   // the block's dS is complete
+        if (it < 4) SP_STAMP(3 + 3 * it);
         // ------------ dQ of the block: wave -> (query tile 4 it + (wave >> 1), head-dim half wave & 1), all keys
         {
             const int qtl = wave >> 1, pr2 = wave & 1;
@@ -1084,8 +1095,10 @@ __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const
                 store_rows16_pair(dqbase + (size_t)min(q, S - 1) * ld, dq0, dq1, scale, q < S, g, pr2);
             }
         }
+        if (it < 4) SP_STAMP(4 + 3 * it);
         __syncthreads();   // before the next block's dS overwrites the exchange image
     }
+    SP_STAMP(14);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (j >= nown) continue;
@@ -1093,6 +1106,7 @@ __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const
         store_rows16(dqbase + H + roff, dk[j], scale, keyv[j] < S, g);
         store_rows16(dqbase + 2 * H + roff, dv[j], 1.0f, keyv[j] < S, g);
     }
+    SP_STAMP(15);
 }
 
 static int att_check(const void* qkv, int B, int S, int nheads, const char* who) {

@@ -39,13 +39,15 @@ def residual_grad_bf16() -> bool:
     return os.environ.get("CLIBD_RESIDUAL_GRAD", "bf16").lower() != "fp32"
 
 
-# Attention backward: "sp" = single pass (ops.attention_bwd_sp; the training forward then also saves its per-layer output, the
-# rounding residual of that output and the log-sum-exp: 4 more bytes per element of activation memory per layer), "2phase" = the
-# kernel that derives the softmax statistics itself and evaluates every score twice.  The single-pass form needs full
+# Attention backward: "2phase" (default) = the kernel that derives the softmax statistics itself and evaluates every score twice;
+# "sp" = single pass (ops.attention_bwd_sp; the training forward then also saves its per-layer output, the rounding residual of
+# that output and the log-sum-exp: 4 more bytes per element of activation memory per layer).  The single-pass form needs full
 # sequences without a key mask, S <= 224 and the bf16 forward; everything else (text tower, the class-row-only last ViT block,
-# fp8-forward mode) keeps the two-phase kernel.
+# fp8-forward mode) keeps the two-phase kernel.  Round 3 measurement: parity-green, 1.7 x fewer MFMAs and half the
+# exponentials per head, but as built 1.46 x SLOWER (one 8-wave workgroup per CU runs its phases in lockstep and exposes the
+# staging of four operand images: 41 % of its lifetime) — it stays opt-in until its pipeline is rebuilt.
 def attention_backward_single_pass() -> bool:
-    return os.environ.get("CLIBD_ATTN_BWD", "sp").lower() != "2phase"
+    return os.environ.get("CLIBD_ATTN_BWD", "2phase").lower() == "sp"
 
 
 @dataclass

@@ -893,3 +893,31 @@ def test_get_feature_and_label_matches_the_reference_loop(dev):
     pred, idx = make_prediction(ti, td, lab, with_indices=True, max_k=3)      # image queries against the DNA keys, on the device
     _, oidx = O.topk_inner_product(torch.from_numpy(fi), torch.from_numpy(fd), k=3)
     assert torch.equal(torch.from_numpy(idx), oidx) and pred[0]["genus"][0] == lab[int(oidx[0, 0])]["genus"]
+
+
+def test_single_pass_attention_backward_in_the_towers(dev, monkeypatch):
+    """CLIBD_ATTN_BWD=sp (opt-in): the towers' training forward saves lse / output residual and the backward takes the single-pass
+    attention kernel (the class-row-only last ViT block and masked sequences keep the two-phase one).  Same embeddings bit for
+    bit, gradients equal to the default path's up to the kernels' rounding points, and still within the oracle gates."""
+    from oracle import clibd_oracle as O
+
+    gd, gi = load("dna_tiny_golden.pt"), load("image_tiny_golden.pt")
+    from tests.test_oracle import build_dna, build_image
+
+    for hm, om, x in ((hip_image(gi, dev), build_image(gi), gi["image_u8"].float() / 255.0), (hip_dna(gd, dev), build_dna(gd), gd["ids"])):
+        g = torch.Generator().manual_seed(3)
+        res = {}
+        for mode in ("2phase", "sp"):
+            monkeypatch.setenv("CLIBD_ATTN_BWD", mode)
+            y = hm(x.to(dev))
+            if mode == "2phase":
+                cot = torch.randn(y.shape, generator=g)
+            res[mode] = (y.detach().cpu(), grads_named(hm, (y * cot.to(dev)).sum()))
+        monkeypatch.delenv("CLIBD_ATTN_BWD")
+        assert torch.equal(res["sp"][0], res["2phase"][0])
+        assert_grads(res["sp"][1], res["2phase"][1], rel_tol=2e-2, cos_tol=0.9995, what="sp vs two-phase")
+        with O.precision("bf16"):
+            yo = om(x)
+            ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+            go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
+        assert_grads(res["sp"][1], go, rel_tol=2e-2, cos_tol=0.999, what="sp vs oracle")
