@@ -241,27 +241,20 @@ class TransformerStack:
             else:
                 c.slot2 = None
 
-    # ---- second rank slot (4 < r <= 8): passes built from the existing kernels — a zero-operand GEMM whose rank-8 MFMA step
-    # carries t2 . V2^T and whose epilogue adds the first slot's result
-    def _slot2_fwd(self, c, x_bf16, qkv):
-        """qkv + (x A2^T) B2^T for q and v: returns (new qkv, t2)."""
-        M = qkv.shape[0]
-        t2 = ops.lora_down_proj(x_bf16, c.slot2["a_cat"])
-        out = torch.empty_like(qkv)
-        ops.gemm_nt(torch.zeros((M, 64), dtype=BF16, device=qkv.device), torch.zeros((qkv.shape[1], 64), dtype=BF16, device=qkv.device),
-                    rank_u=t2, rank_v=c.slot2["v_fwd"], act=ops.ACT_ADD_AUX, aux=qkv, out_bf16=out)
-        return out, t2
-
-    def _slot2_dgrad(self, c, dt2, dx):
-        """dx + dt2 . A_cat2 (the second slot's share of the QKV input gradient); dx bf16 or fp32, a new tensor is returned."""
-        M, Hd = dx.shape
-        zA, zW = torch.zeros((M, 64), dtype=BF16, device=dx.device), torch.zeros((Hd, 64), dtype=BF16, device=dx.device)
-        out = torch.empty_like(dx)
-        if dx.dtype == BF16:
-            ops.gemm_nt(zA, zW, rank_u=dt2, rank_v=c.slot2["v_bwd"], act=ops.ACT_ADD_AUX, aux=dx, out_bf16=out)
-        else:
-            ops.gemm_nt(zA, zW, rank_u=dt2, rank_v=c.slot2["v_bwd"], residual=dx, out_f32=out)
+    # ---- second rank slot (4 < r <= 8): a pass built from the existing kernels — a zero-operand GEMM whose rank-8 MFMA step
+    # carries u . V^T into an fp32 addend, which the layer's real GEMM then takes as its fp32 residual: ONE rounding of the sum,
+    # as in the reference's B(A x) over all r columns
+    def _slot2_addend(self, u, v, N, residual=None):
+        M = u.shape[0]
+        out = torch.empty((M, N), dtype=F32, device=u.device)
+        ops.gemm_nt(torch.zeros((M, 64), dtype=BF16, device=u.device), torch.zeros((N, 64), dtype=BF16, device=u.device), rank_u=u, rank_v=v,
+                    residual=residual, out_f32=out)
         return out
+
+    def _slot2_fwd(self, c, x_bf16):
+        """(fp32 [M,3H] addend (x A2^T) B2^T on the q and v columns, t2) of the second rank slot."""
+        t2 = ops.lora_down_proj(x_bf16, c.slot2["a_cat"])
+        return self._slot2_addend(t2, c.slot2["v_fwd"], 3 * self.H), t2
 
     def lora_a(self, i: int):
         if i >= len(self.layers) or self.layers[i].lora is None:
@@ -320,9 +313,8 @@ class TransformerStack:
                     ops.gemm_fp8_nt(xn8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
                 else:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
-                    ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
-                    if c.slot2 is not None:
-                        qkv, t2 = self._slot2_fwd(c, xn, qkv)
+                    add32, t2 = self._slot2_fwd(c, xn) if c.slot2 is not None else (None, None)
+                    ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, residual=add32, out_bf16=qkv)
                     if crec is not None:
                         crec["qkv_in"] = amax(xn)
                 newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
@@ -365,9 +357,8 @@ class TransformerStack:
                     ops.gemm_fp8_nt(a, c.w28, c.cs_2, bias=c.b2, residual=x1, out_f32=x2)
                 else:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
-                    ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
-                    if c.slot2 is not None:
-                        qkv, t2 = self._slot2_fwd(c, xn, qkv)
+                    add32, t2 = self._slot2_fwd(c, xn) if c.slot2 is not None else (None, None)
+                    ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, residual=add32, out_bf16=qkv)
                     if sp_ok:   # training forward of the single-pass attention backward: this layer's o, its rounding residual, the lse
                         o = o if keep else new(H, BF16)
                         att_sv = dict(o_att=o, o_lo=new(H, BF16), lse=torch.empty((B * self.heads * S,), dtype=F32, device=dev))
@@ -422,9 +413,8 @@ class TransformerStack:
                     x_fp8 = x8_next
                 else:
                     x1_bf16 = new(H, BF16)
-                    ops.gemm_nt(x_bf16, c.wqkv, bias=c.bqkv, rank_u=ru, rank_v=rv, out_bf16=qkv)
-                    if c.slot2 is not None:
-                        qkv, t2 = self._slot2_fwd(c, x_bf16, qkv)
+                    add32, t2 = self._slot2_fwd(c, x_bf16) if c.slot2 is not None else (None, None)
+                    ops.gemm_nt(x_bf16, c.wqkv, bias=c.bqkv, rank_u=ru, rank_v=rv, residual=add32, out_bf16=qkv)
                     if sp_ok:
                         o = o if keep else new(H, BF16)
                         att_sv = dict(o_att=o, o_lo=new(H, BF16), lse=torch.empty((B * self.heads * S,), dtype=F32, device=dev))
@@ -501,17 +491,17 @@ class TransformerStack:
                     dt2 = self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads, rec.get("t2"))
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
-                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
-                    dq_in = dtmp if dt2 is None else self._slot2_dgrad(c, dt2, dtmp)
+                    add32 = None if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H)      # second rank slot: dt2 . A_cat2, fp32
+                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, residual=add32, out_bf16=dtmp)
                     if r16:
                         dres16, _ = ops.scatter_rows(dx1_f32, S, bf16=True, f32=False)           # residual path: class rows only
                         ndx_bf16 = new(H, BF16)
-                        ops.layernorm_bwd(dq_in, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16)
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16)
                         dx_f32, dx_bf16 = None, ndx_bf16
                     else:
                         _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)        # residual path: class rows only
                         ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
-                        ops.layernorm_bwd(dq_in, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dres_full, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
                         dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif self.pre_ln:
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
@@ -531,14 +521,14 @@ class TransformerStack:
                     dt2 = self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads, rec.get("t2"))
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
-                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, out_bf16=dtmp)
-                    dq_in = dtmp if dt2 is None else self._slot2_dgrad(c, dt2, dtmp)
+                    add32 = None if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H)      # second rank slot: dt2 . A_cat2, fp32
+                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, residual=add32, out_bf16=dtmp)
                     if r16:
                         ndx_f32, ndx_bf16 = None, new(H, BF16)
-                        ops.layernorm_bwd(dq_in, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16)
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16)
                     else:
                         ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
-                        ops.layernorm_bwd(dq_in, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
                     dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif r16:
                 # post-LN, bf16 stream: `dx_f32` holds the incoming gradient of the layer output (fp32 from the head at the top layer,
@@ -564,9 +554,10 @@ class TransformerStack:
                     dt2 = self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads, rec.get("t2"))
                 if i > first_lora:
                     ndx = new(H, BF16)
+                    add32 = None if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H)
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
-                                act=ops.ACT_ADD_AUX, aux=ds1_res, out_bf16=ndx)
-                    dx_f32 = ndx if dt2 is None else self._slot2_dgrad(c, dt2, ndx)
+                                act=ops.ACT_ADD_AUX, aux=ds1_res, residual=add32, out_bf16=ndx)
+                    dx_f32 = ndx
             else:
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"], **pg(L.ln2_w, L.ln2_b))
@@ -585,9 +576,10 @@ class TransformerStack:
                 wg(dqkv, rec["x_bf16"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ndx = new(H, F32)
+                    res32 = ds1_f32 if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H, residual=ds1_f32)
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
-                                residual=ds1_f32, out_f32=ndx)
-                    dx_f32 = ndx if dt2 is None else self._slot2_dgrad(c, dt2, ndx)
+                                residual=res32, out_f32=ndx)
+                    dx_f32 = ndx
             if on_layer_done is not None:
                 on_layer_done(i)
         return dx_f32 if full else None
@@ -602,7 +594,7 @@ class TransformerStack:
         """dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v (the rank-8 operand of the QKV dgrad that follows) and the four adapter gradients
         in one call: dq and dv are streamed once for dt and dB together (clibd_lora_backward); the k segment of dqkv is never read.
         Ranks other than 4 run on rank-4 slots (_rank_slots): scratch gradients, sliced back; ranks 5-8 take a second call with the
-        second slot's images and down-projection t2, whose dt (returned) joins the QKV dgrad through _slot2_dgrad."""
+        second slot's images and down-projection t2, whose dt (returned) joins the QKV dgrad as an fp32 addend (_slot2_addend)."""
         H = self.H
         lp = L.lora
         r = lp.a_q.shape[0]
