@@ -913,7 +913,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
 // score arithmetic once instead of twice.  Needs nq = S, no key mask, S <= 224 (LDS: 5 images of 32 NP rows + statistics).
 constexpr int ATTB_WAVES = 8;
 
-template <bool DROP>
+template <bool DROP, int NPT>   // NPT: number of 32-row k-slots (7 at S = 197, 5 at S = 133) when known at compile time, 0 = run-time
 __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const unsigned short* __restrict__ qkv,
                                                                           const unsigned short* __restrict__ dout,
                                                                           const unsigned short* __restrict__ o_hi,
@@ -922,9 +922,9 @@ __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const
                                                                           unsigned short* __restrict__ dqkv, float scale, unsigned drop_seed,
                                                                           int drop_thr16, float drop_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int NT = (S + 15) >> 4;          // 16-row tiles of the sequence
-    const int NP = (NT + 1) >> 1;          // 32-row k-slots
-    const int R = 32 * NP;                 // rows of every image
+    const int NT = (S + 15) >> 4;                        // 16-row tiles of the sequence
+    const int NP = NPT > 0 ? NPT : ((NT + 1) >> 1);      // 32-row k-slots
+    const int R = 32 * NP;                               // rows of every image
     char* kimg = smem;
     char* vimg = kimg + R * 128;
     char* qimg = vimg + R * 128;
@@ -945,29 +945,43 @@ __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const
     const float c2 = scale * 1.4426950408889634f;
 
     SP_STAMP(0);
+    // delta[q] = dO[q] . (o_hi[q] + o_lo[q]) and the row statistic; query rows >= S get lse = +BIG, i.e. P = 0 exactly.
+    // Eight lanes per row, 64 rows per pass.  ALL passes' rows are requested before the operand images: the in-order vmcnt queue
+    // then lets the arithmetic below start as soon as these loads are back, with the LDS-DMA of the images still in flight
+    // (the first version issued each pass's loads after the previous pass's reduction: four global round trips behind the
+    // DMA queue = 41 % of the workgroup's lifetime, tools/att_sp_stamps.py; now 28 %).
+    constexpr int DPASS = 4;                 // 4 x 64 = 256 rows >= R
+    bf16x8 d8[DPASS], h8[DPASS], l8[DPASS];
+    float lse_r[DPASS];
+    {
+        const int sub = threadIdx.x & 7;
+#pragma unroll
+        for (int ps = 0; ps < DPASS; ++ps) {
+            const int row = min(64 * ps + (int)(threadIdx.x >> 3), S - 1);
+            const size_t off = (size_t)row * H + 8 * sub;
+            d8[ps] = *(const bf16x8*)(dobase + off);
+            h8[ps] = *(const bf16x8*)(o_hi + obase + off);
+            l8[ps] = *(const bf16x8*)(o_lo + obase + off);
+            lse_r[ps] = lse[(size_t)blockIdx.x * S + row];
+        }
+    }
     stage_head_tile(kimg, qbase + H, ld, S, R, wave, lane, ATTB_WAVES);
     stage_head_tile(vimg, qbase + 2 * H, ld, S, R, wave, lane, ATTB_WAVES);
     stage_head_tile(qimg, qbase, ld, S, R, wave, lane, ATTB_WAVES);
     stage_head_tile(doimg, dobase, (size_t)H, S, R, wave, lane, ATTB_WAVES);
-    // delta[q] = dO[q] . (o_hi[q] + o_lo[q]) and the row statistic; query rows >= S get lse = +BIG, i.e. P = 0 exactly
-    for (int r0 = 0; r0 < R; r0 += 8 * ATTB_WAVES) {
-        const int row = r0 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
-        float part = 0.f;
-        if (row < S) {
-            const size_t off = (size_t)row * H + 8 * sub;
-            const bf16x8 d8 = *(const bf16x8*)(dobase + off);
-            const bf16x8 h8 = *(const bf16x8*)(o_hi + obase + off);
-            const bf16x8 l8 = *(const bf16x8*)(o_lo + obase + off);
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                part += bf2f((unsigned short)d8[e]) * (bf2f((unsigned short)h8[e]) + bf2f((unsigned short)l8[e]));
-        }
+    for (int ps = 0; ps < DPASS; ++ps) {
+        const int row = 64 * ps + (int)(threadIdx.x >> 3), sub = threadIdx.x & 7;
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            part += bf2f((unsigned short)d8[ps][e]) * (bf2f((unsigned short)h8[ps][e]) + bf2f((unsigned short)l8[ps][e]));
         part += dpp_mov<DPP_QUAD_XOR1>(part);
         part += dpp_mov<DPP_QUAD_XOR2>(part);
         part += dpp_mov<DPP_ROW_HALF_MIRROR>(part);   // the 8 lanes of a row
         if (sub == 0 && row < R) {
-            st_d[row] = part;
-            st_m[row] = row < S ? lse[(size_t)blockIdx.x * S + row] : -NEG_BIG;
+            st_d[row] = row < S ? part : 0.f;
+            st_m[row] = row < S ? lse_r[ps] : -NEG_BIG;
         }
     }
     // the key rows of the exchange image that no wave owns (the padding tile of an odd tile count) must read as zeros
@@ -1085,11 +1099,22 @@ __global__ __launch_bounds__(64 * ATTB_WAVES) void attention_bwd_sp_kernel(const
             const int qt = 4 * it + qtl;
             if (qt < NT) {
                 f32x4 dq0 = (f32x4){0, 0, 0, 0}, dq1 = (f32x4){0, 0, 0, 0};
+                if constexpr (NPT > 0) {
+                    // every transposing read of the block's dS column and of the two K^T fragments is independent of the MFMAs:
+                    // fully unrolled, the reads of the later k-slots fly under the earlier products
+#pragma unroll
+                    for (int sp = 0; sp < NPT; ++sp) {
+                        const bf16x8 dsb = lds_tr_frag(dsimg, sp, qtl, lane);
+                        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(kimg, sp, 2 * pr2, lane), dsb, dq0, 0, 0, 0);
+                        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(kimg, sp, 2 * pr2 + 1, lane), dsb, dq1, 0, 0, 0);
+                    }
+                } else {
 #pragma unroll 1
-                for (int sp = 0; sp < NP; ++sp) {
-                    const bf16x8 dsb = lds_tr_frag(dsimg, sp, qtl, lane);
-                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(kimg, sp, 2 * pr2, lane), dsb, dq0, 0, 0, 0);
-                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(kimg, sp, 2 * pr2 + 1, lane), dsb, dq1, 0, 0, 0);
+                    for (int sp = 0; sp < NP; ++sp) {
+                        const bf16x8 dsb = lds_tr_frag(dsimg, sp, qtl, lane);
+                        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(kimg, sp, 2 * pr2, lane), dsb, dq0, 0, 0, 0);
+                        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(kimg, sp, 2 * pr2 + 1, lane), dsb, dq1, 0, 0, 0);
+                    }
                 }
                 const int q = qt * 16 + i;
                 store_rows16_pair(dqbase + (size_t)min(q, S - 1) * ld, dq0, dq1, scale, q < S, g, pr2);
@@ -1205,17 +1230,24 @@ extern "C" int clibd_attention_bwd_sp(const void* qkv, const void* dout, const v
     const size_t lds = (size_t)5 * 32 * np * 128 + (size_t)2 * 32 * np * sizeof(float);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_SP(DRP, NPT_)                                                                                                   \
+    do {                                                                                                                      \
+        hipFuncSetAttribute((const void*)attention_bwd_sp_kernel<DRP, NPT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attention_bwd_sp_kernel<DRP, NPT_>), dim3(B * nheads), dim3(64 * ATTB_WAVES), lds, st, (const unsigned short*)qkv, \
+                           (const unsigned short*)dout, (const unsigned short*)out, (const unsigned short*)o_lo, lse, S, nheads, \
+                           (unsigned short*)dqkv, scale, drop_seed, drop_thr16, drop_scale);                                  \
+    } while (0)
+    // the two sequence lengths of the training step get their k-slot count at compile time (unrolled dQ stage); the rest share a run-time form
     if (drop_thr16 > 0) {
-        hipFuncSetAttribute((const void*)attention_bwd_sp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((attention_bwd_sp_kernel<true>), dim3(B * nheads), dim3(64 * ATTB_WAVES), lds, st, (const unsigned short*)qkv,
-                           (const unsigned short*)dout, (const unsigned short*)out, (const unsigned short*)o_lo, lse, S, nheads,
-                           (unsigned short*)dqkv, scale, drop_seed, drop_thr16, drop_scale);
+        if (np == 5) LAUNCH_SP(true, 5);
+        else if (np == 7) LAUNCH_SP(true, 7);
+        else LAUNCH_SP(true, 0);
     } else {
-        hipFuncSetAttribute((const void*)attention_bwd_sp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((attention_bwd_sp_kernel<false>), dim3(B * nheads), dim3(64 * ATTB_WAVES), lds, st, (const unsigned short*)qkv,
-                           (const unsigned short*)dout, (const unsigned short*)out, (const unsigned short*)o_lo, lse, S, nheads,
-                           (unsigned short*)dqkv, scale, drop_seed, drop_thr16, drop_scale);
+        if (np == 5) LAUNCH_SP(false, 5);
+        else if (np == 7) LAUNCH_SP(false, 7);
+        else LAUNCH_SP(false, 0);
     }
+#undef LAUNCH_SP
     return check_launch("attention_bwd_sp");
 }
 
