@@ -44,8 +44,8 @@ def residual_grad_bf16() -> bool:
 # that output and the log-sum-exp: 4 more bytes per element of activation memory per layer).  The single-pass form needs full
 # sequences without a key mask, S <= 224 and the bf16 forward; everything else (text tower, the class-row-only last ViT block,
 # fp8-forward mode) keeps the two-phase kernel.  Round 3 measurement: parity-green, 1.7 x fewer MFMAs and half the
-# exponentials per head, but as built 1.46 x SLOWER (one 8-wave workgroup per CU runs its phases in lockstep and exposes the
-# staging of four operand images: 41 % of its lifetime) — it stays opt-in until its pipeline is rebuilt.
+# exponentials per head, but as built 1.17 - 1.24 x SLOWER (one 8-wave workgroup per CU runs its phases in lockstep and cannot put
+# the staging of its 192 KB per head under compute) — it stays opt-in until its pipeline is rebuilt.
 def attention_backward_single_pass() -> bool:
     return os.environ.get("CLIBD_ATTN_BWD", "2phase").lower() == "sp"
 
