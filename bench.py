@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: CLIBD Image+DNA contrastive TRAINING step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: the script starts torch.distributed.run itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = forward of the ViT-B/16 + BarcodeBERT(BERT-base) towers with rank-4 LoRA adapters, L2-normalise,
@@ -311,7 +311,13 @@ def self_launch(n: int) -> int:
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries the JSON line only: anything else a rank or a backend writes there (gloo's connection banner in the
+    # shared-GPU debug mode) is passed on to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
