@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void topk_ip_stream_kernel(const float* __rest
                                                              int D, int tiles_per_split, int nsplit, int k,
                                                              long long* __restrict__ out_idx, float* __restrict__ out_sim,
                                                              float* __restrict__ part_v, int* __restrict__ part_i) {
-    __shared__ float qa[64 * TK_LD];
-    __shared__ float kb[64 * TK_LD];
+    __shared__ float qa[2][64 * TK_LD];   // two stages: the next 32-deep chunk is fetched and written while the current one is multiplied
+    __shared__ float kb[2][64 * TK_LD];
     __shared__ float cand_v[64][4 * TK_KMAX + 1];
     __shared__ int cand_i[64][4 * TK_KMAX + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -64,41 +64,64 @@ __global__ __launch_bounds__(256) void topk_ip_stream_kernel(const float* __rest
     for (int j = 0; j < TK_KMAX; ++j) { bv[j] = TK_NEG; bi[j] = TK_NOIDX; }
     // staging: thread t loads rows (t>>3) and (t>>3)+32 of both tiles, 4 consecutive k at 4*(t&7)
     const int srow = threadIdx.x >> 3, scol = (threadIdx.x & 7) * 4;
+    const int nchunks = (D + TK_BK - 1) / TK_BK;
+    // one (key tile, k chunk) step = fetch -> registers -> LDS stage; the fetch of step n + 1 is issued before the MFMAs of step n
+    float4 fa[2], fb[2];
+    auto fetch = [&](int tile, int kk) {
+        const int k0 = tile * 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = srow + 32 * h;
+            const int gq = min(q0 + r, Q - 1), gk = min(k0 + r, Nk - 1);
+            fa[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            fb[h] = fa[h];
+            if (kk + scol + 3 < D) {
+                fa[h] = *(const float4*)(q + (size_t)gq * D + kk + scol);
+                fb[h] = *(const float4*)(keys + (size_t)gk * D + kk + scol);
+            } else {
+                float ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
+                for (int e = 0; e < 4; ++e)
+                    if (kk + scol + e < D) { ta[e] = q[(size_t)gq * D + kk + scol + e]; tb[e] = keys[(size_t)gk * D + kk + scol + e]; }
+                fa[h] = make_float4(ta[0], ta[1], ta[2], ta[3]);
+                fb[h] = make_float4(tb[0], tb[1], tb[2], tb[3]);
+            }
+        }
+    };
+    auto stash = [&](int stage) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = srow + 32 * h;
+            float* pa = qa[stage] + r * TK_LD + scol;
+            float* pb = kb[stage] + r * TK_LD + scol;
+            pa[0] = fa[h].x; pa[1] = fa[h].y; pa[2] = fa[h].z; pa[3] = fa[h].w;
+            pb[0] = fb[h].x; pb[1] = fb[h].y; pb[2] = fb[h].z; pb[3] = fb[h].w;
+        }
+    };
+    int step = 0;
+    if (tile_beg < tile_end) {
+        fetch(tile_beg, 0);
+        stash(0);
+    }
+    __syncthreads();
     for (int tile = tile_beg; tile < tile_end; ++tile) {
         const int k0 = tile * 64;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        for (int kk = 0; kk < D; kk += TK_BK) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = srow + 32 * h;
-                const int gq = min(q0 + r, Q - 1), gk = min(k0 + r, Nk - 1);
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-                if (kk + scol + 3 < D) {
-                    a = *(const float4*)(q + (size_t)gq * D + kk + scol);
-                    b = *(const float4*)(keys + (size_t)gk * D + kk + scol);
-                } else {
-                    float ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
-                    for (int e = 0; e < 4; ++e)
-                        if (kk + scol + e < D) { ta[e] = q[(size_t)gq * D + kk + scol + e]; tb[e] = keys[(size_t)gk * D + kk + scol + e]; }
-                    a = make_float4(ta[0], ta[1], ta[2], ta[3]);
-                    b = make_float4(tb[0], tb[1], tb[2], tb[3]);
-                }
-                float* pa = qa + r * TK_LD + scol;
-                float* pb = kb + r * TK_LD + scol;
-                pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
-                pb[0] = b.x; pb[1] = b.y; pb[2] = b.z; pb[3] = b.w;
-            }
-            __syncthreads();
+        for (int c = 0; c < nchunks; ++c, ++step) {
+            const int cur = step & 1;
+            // the step after this one: next chunk of this tile, or the first chunk of the next tile
+            const bool more = (c + 1 < nchunks) || (tile + 1 < tile_end);
+            if (more) fetch(c + 1 < nchunks ? tile : tile + 1, c + 1 < nchunks ? (c + 1) * TK_BK : 0);
             // mfma_f32_32x32x2f32: lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; A = keys tile (D rows),
             // B = query tile (D columns): D[key][query]
 #pragma unroll
             for (int s = 0; s < TK_BK; s += 2) {
-                const float av = kb[(wk + (lane & 31)) * TK_LD + s + (lane >> 5)];
-                const float bvq = qa[(wq + (lane & 31)) * TK_LD + s + (lane >> 5)];
+                const float av = kb[cur][(wk + (lane & 31)) * TK_LD + s + (lane >> 5)];
+                const float bvq = qa[cur][(wq + (lane & 31)) * TK_LD + s + (lane >> 5)];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvq, acc, 0, 0, 0);
             }
+            if (more) stash(cur ^ 1);   // the other stage was last read one step ago, before the barrier below
             __syncthreads();
         }
         // C/D layout of 32x32: col = lane&31 (query), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (key)
