@@ -225,6 +225,33 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         BARRIER();                                                                                           \
     } while (0)
 
+    // phase Q8 (2..7) of the LAST K-tile pair of a tile: issues half-tile Q8-2 of the next tile if there is one
+#define PHASE_TAIL(Q8, WAITN_DRAIN)                                                                          \
+    do {                                                                                                     \
+        constexpr int st_ = ((Q8) >> 2) & 1;                                                                 \
+        constexpr int dl_ = (Q8) & 3;                                                                        \
+        if (dl_ == 0) { LOAD_W(w0F, st_, 1); LOAD_A(st_, 0); }                                               \
+        else if (dl_ == 1) { LOAD_W(w1F, st_, 2); }                                                          \
+        else if (dl_ == 2) { LOAD_A(st_, 3); }                                                               \
+        if (has_next) {                                                                                      \
+            constexpr int ju_ = ((Q8) + 2) & 3;                                                              \
+            constexpr int du_ = ((Q8) + 6) >> 2;                                                             \
+            ISSUE(du_ - 2, ju_, du_ & 1);                                                                    \
+            CLIBD_WAIT_VMCNT(8);                                                                             \
+        } else {                                                                                             \
+            CLIBD_WAIT_VMCNT(WAITN_DRAIN);                                                                   \
+        }                                                                                                    \
+        BARRIER();                                                                                           \
+        if (dl_ == 0) { WAIT_FRAGS_W(w0F); WAIT_FRAGS_A(); }                                                 \
+        else if (dl_ == 1) { WAIT_FRAGS_W(w1F); }                                                            \
+        else if (dl_ == 2) { WAIT_FRAGS_A(); }                                                               \
+        if (dl_ == 0) MMA(0, 0, w0F);                                                                        \
+        else if (dl_ == 1) MMA(0, 1, w1F);                                                                   \
+        else if (dl_ == 2) MMA(1, 1, w1F);                                                                   \
+        else MMA(1, 0, w0F);                                                                                 \
+        BARRIER();                                                                                           \
+    } while (0)
+
     // wait at the end of a load segment in the first six phases of a tile (and before its phase 0): the previous
     // epilogue's stores sit between the prologue LDS-DMA and this tile's later issues in the in-order vmcnt queue
 #define WAIT_HEAD()                                         \
@@ -325,9 +352,13 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         // last iteration (kt = nk-2): only L_{4nk-2}, L_{4nk-1} are left to issue; drain with exact counts
         STAMP(3);
         PHASE(0, true, 8); PHASE(1, true, 8);
+        // The ring does not stop at the tile boundary: L_{4nk+i} is half-tile i of the NEXT tile (nk is even, so its K-tile 0
+        // falls on stage 0), issued six phases ahead like any other.  Phases 2..7 carry L'_0..L'_5 through a memory pipe that
+        // would otherwise idle there, and the epilogue below shares it with two half-tiles instead of eight.  Without a next
+        // tile the phases drain with exact counts.  (One code path with a scalar branch around the issue: two copies of the
+        // phases, one per value of has_next, put the 128 accumulators behind phis and spill 180 registers.)
         if (has_next) set_sources(next);  // no more issues for this tile: the source registers now describe the next one
-        PHASE(2, false, 6); PHASE(3, false, 4);
-        PHASE(4, false, 2); PHASE(5, false, 0); PHASE(6, false, 0); PHASE(7, false, 0);
+        PHASE_TAIL(2, 6); PHASE_TAIL(3, 4); PHASE_TAIL(4, 2); PHASE_TAIL(5, 0); PHASE_TAIL(6, 0); PHASE_TAIL(7, 0);
         if (wm == 0) BARRIER();  // group 0 matches group 1's extra barrier; every LDS read of this tile is complete
         STAMP(4);
         // lane coordinates made opaque per tile: everything the epilogue derives from them (16 row offsets x several
@@ -369,13 +400,16 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     }
                 }
         }
-        if (has_next) PROLOGUE_ISSUE();  // next tile's first eight half-tiles fly while this tile's epilogue runs
+        if (has_next) {  // L'_6, L'_7: ahead of the stores in the in-order queue (L'_0..L'_5 went out in phases 2..7)
+            ISSUE(1, 2, 1); __builtin_amdgcn_sched_barrier(0);
+            ISSUE(1, 3, 1); __builtin_amdgcn_sched_barrier(0);
+        }
         // (rebuilt, so that only the requested operands — not the coordinates — are live across the prologue issue)
         erow = frow; egrp = fch;
         asm volatile("" : "+v"(erow), "+v"(egrp));
         nb = n0 + 128 * wm + 8 * erow;
         mb = m0 + 64 * wn + 4 * egrp;
-        // queue now: [bias / LoRA asm loads] [first row group: 8 (aux) or 16 (residual) loads] [16 LDS-DMA loads if has_next]
+        // queue now: [bias / LoRA asm loads] [first row group: 8 (aux) or 16 (residual) loads] [4 LDS-DMA loads if has_next]
 #define EPI_TIED_WAIT(N)                                                                                             \
     do {                                                                                                             \
         if constexpr (BIAS_ASM) asm volatile("s_waitcnt vmcnt(" #N ") ; EPI_OPERAND_WAIT" : "+v"(bias_q[0]), "+v"(bias_q[1])); \
@@ -385,13 +419,13 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         // the operands themselves comes first and the tied one is then a no-op that only carries the data dependence.
         if constexpr (PRELOAD_ROWS && epi_aux_kind(KIND)) {
             if (!has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            EPI_TIED_WAIT(24);
+            EPI_TIED_WAIT(12);
         } else if constexpr (PRELOAD_ROWS) {
             if (!has_next) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            EPI_TIED_WAIT(32);
+            EPI_TIED_WAIT(20);
         } else {
             if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            EPI_TIED_WAIT(16);
+            EPI_TIED_WAIT(4);
         }
 #undef EPI_TIED_WAIT
 #undef GLOAD128
