@@ -19,9 +19,11 @@ restated and pinned to it) timed on this host's cores with a bounded sample, ran
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -30,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+MAX_SCLK_MHZ = 2400.0         # the shader clock that figure is quoted at
 GF_PER_PAIR_TRAIN = 117.6     # LoRA training step, I+D pair (fwd 58.78 GF + dgrad-only bwd)
 
 
@@ -123,6 +126,53 @@ class GemmTimer:
         for (M, N, K, kinds), (n, t) in rows:
             print(f"[gemm] M={M:6d} N={N:5d} K={K:5d} x{n // steps:3d}/step {t / steps:7.3f} ms/step {t / n * 1e3:7.1f} us each "
                   f"{2.0 * M * N * K * n / (t * 1e-3) / 1e12:7.1f} TF  {kinds}", file=sys.stderr, flush=True)
+
+
+class BoardSampler(threading.Thread):
+    """Board power and shader clock (sysfs hwmon, read-only, no GPU call) at 10 Hz while the timed region runs.  Every card the
+    box exposes is sampled; the one reported is the one that drew the most (the bench's own GPU; at N > 1 one of them)."""
+
+    def __init__(self, period=0.1):
+        super().__init__(daemon=True)
+        self.period, self.samples, self._stop_ev = period, [], threading.Event()
+        self.cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for pn in ("power1_input", "power1_average"):
+                if self._rd(f"{d}/{pn}") is not None:
+                    self.cards.append((d, pn))
+                    break
+
+    @staticmethod
+    def _rd(path):
+        try:
+            with open(path) as f:
+                return float(f.read()) / 1e6
+        except (OSError, ValueError):
+            return None
+
+    def run(self):
+        while not self._stop_ev.is_set():
+            self.samples.append((time.perf_counter(), [(self._rd(f"{d}/{pn}"), self._rd(f"{d}/freq1_input")) for d, pn in self.cards]))
+            self._stop_ev.wait(self.period)
+
+    def stop(self):
+        self._stop_ev.set()
+        self.join(timeout=2)
+
+    def window(self, t0, t1):
+        rows = [v for t, v in self.samples if t0 <= t <= t1]
+        if not rows or not self.cards:
+            return None
+        means = [sum((r[i][0] or 0.0) for r in rows) / len(rows) for i in range(len(self.cards))]
+        k = max(range(len(means)), key=means.__getitem__)
+        pw = sorted(r[k][0] for r in rows if r[k][0] is not None)
+        ck = [r[k][1] for r in rows if r[k][1] is not None]
+        if not pw:
+            return None
+        cap = self._rd(f"{self.cards[k][0]}/power1_cap")
+        sclk = sum(ck) / len(ck) if ck else None
+        return {"board_power_w": sum(pw) / len(pw), "board_power_w_p90": pw[min(len(pw) - 1, int(0.9 * len(pw)))], "power_cap_w": cap,
+                "sclk_mhz": sclk, "samples": len(pw), "source": f"{self.cards[k][0]} ({self.cards[k][1]}, freq1_input), 10 Hz over the timed region"}
 
 
 def pmc_traffic(per_gpu_batch: int):
@@ -393,6 +443,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    sampler = BoardSampler() if rank == 0 else None
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()   # the timed region carries NO per-launch event records (they cost ~1.3 ms per step of host+GPU time)
     for _ in range(args.steps):
         loss = one_step()
@@ -401,6 +454,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    board = None
+    if sampler is not None:
+        sampler.stop()
+        board = sampler.window(t0 + min(0.5, 0.25 * elapsed), t0 + elapsed)   # (the first half second: the clocks are still settling)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -512,6 +569,12 @@ def main():
             if serial is not None:
                 roof["timed_region"] = {"achieved": overlapped["tflops"], "gemm_ms_per_step": overlapped["total_ms"] / overlapped["steps"],
                                         "avg_launch_us": overlapped["total_ms"] / overlapped["launches"] * 1e3, "streams": 2}
+        if board is not None and board.get("sclk_mhz"):
+            # The board holds its power cap by lowering the shader clock: the MFMA peak the step was actually offered
+            board["mfma_peak_at_sclk_tflops"] = PEAK_BF16_TFLOPS * board["sclk_mhz"] / MAX_SCLK_MHZ
+            if roof.get("achieved"):
+                roof["frac_at_delivered_clock"] = roof["achieved"] / board["mfma_peak_at_sclk_tflops"]
+            roof["board"] = board
         out = {
             "metric": (f"paired samples/sec/step (I+D contrastive), global batch {b * world}" if not args.tri_modal
                        else f"triples/sec/step (I+D+T contrastive), global batch {b * world}"),

@@ -1,8 +1,11 @@
 """The step's GEMM shapes through the product library, one line per shape (µs per launch, TFLOP/s).
 
-    python tools/bench_gemm_shapes.py [M] [reps]      # default M = 403456 (ViT token rows at b=2048)
+    python tools/bench_gemm_shapes.py [M] [reps] [seconds]   # default M = 403456 (ViT token rows at b=2048)
+
+With [seconds] > 0 every shape runs for about that long and prints its wall-clock window (for tools/power_sampler.py).
 """
 import sys
+import time
 import torch
 
 sys.path.insert(0, ".")
@@ -15,6 +18,7 @@ SHAPES = (("fc1_gelu2", 3072, 768), ("qkv_bf16", 2304, 768), ("proj_res", 768, 7
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 403456
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    secs = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     dev = torch.device("cuda:0"); BF16 = torch.bfloat16
     tot = 0.0
     for name, N, K in SHAPES:
@@ -42,7 +46,18 @@ def main():
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
         tot += us
-        print(f"{name:14s} N={N:5d} K={K:5d} {us:8.1f} us {2.0 * M * N * K / us / 1e6:6.0f} TF", flush=True)
+        line = f"{name:14s} N={N:5d} K={K:5d} {us:8.1f} us {2.0 * M * N * K / us / 1e6:6.0f} TF"
+        if secs > 0:
+            n = max(1, int(secs * 1e6 / us))
+            t0 = time.time()
+            e0.record()
+            for _ in range(n):
+                ops.gemm_nt(a, w, **kw)
+            e1.record(); torch.cuda.synchronize()
+            t1 = time.time()
+            us2 = e0.elapsed_time(e1) / n * 1e3
+            line += f" | sustained {us2:8.1f} us {2.0 * M * N * K / us2 / 1e6:6.0f} TF window {t0:.3f} {t1:.3f}"
+        print(line, flush=True)
         del a, w, kw
     print(f"sum {tot:8.1f} us")
 

@@ -1,15 +1,16 @@
 #!/bin/bash
-# A/B of two library builds on one box: build_ab/libclibd_old.so (CLIBD_HIP_LIB) against the in-tree build.
-# usage: bash tools/gpu_gemm_ab.sh <tag>
+# Same-box A/B of library variants built by tools/build_variant.sh: GEMM shapes (sustained rates) with board power sampled beside them.
+# usage: bash tools/gpu_gemm_ab.sh <tag> "<variant names>" [seconds per shape]
 set -u
 TAG=${1:-ab}
+VARS=${2:-"base"}
+SECS=${3:-1.5}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-timeout 600 python -m pytest tests/test_ops_gpu.py -q -x -k "gemm" -p no:cacheprovider > "$OUT/pytest_gemm.log" 2>&1
-echo "pytest exit $?" >> "$OUT/pytest_gemm.log"; tail -3 "$OUT/pytest_gemm.log"
-for rep in 1 2; do
-  CLIBD_HIP_LIB=$PWD/build_ab/libclibd_old.so timeout 300 python tools/bench_gemm_shapes.py > "$OUT/shapes_old_$rep.log" 2>&1
-  timeout 300 python tools/bench_gemm_shapes.py > "$OUT/shapes_new_$rep.log" 2>&1
+python tools/power_sampler.py "$OUT/power.txt" 600 0.05 &
+SMP=$!
+for v in $VARS; do
+  CLIBD_HIP_LIB=$PWD/build_ab/lib_$v.so timeout 300 python tools/bench_gemm_shapes.py 403456 6 $SECS > "$OUT/shapes_$v.log" 2>&1
+  echo "== $v"; grep -E "sum|TF" "$OUT/shapes_$v.log" | sed -e 's/window.*//' | cut -c1-110
 done
-paste "$OUT/shapes_old_1.log" "$OUT/shapes_new_1.log" | cut -c1-140
-paste "$OUT/shapes_old_2.log" "$OUT/shapes_new_2.log" | cut -c1-140
+kill $SMP 2>/dev/null; wait $SMP 2>/dev/null
