@@ -196,6 +196,27 @@ __device__ __forceinline__ void gelu_and_grad_rows(float* v, float* dg) {
         dg[e] = d[0]; dg[e + 1] = d[1];
     }
 }
+// gelu'(x) lies in [-0.1290, 1.1290]: kept for the backward as ONE BYTE, code = rint((g' - LO) / STEP) over [LO, LO + 255 STEP]
+// (|error| <= STEP / 2 = 2.5e-3: the spacing of bf16 in [0.5, 1) is 3.9e-3, in [1, 2) 7.8e-3).  CLIBD_ACT_GELU_SAVE_GRAD_U8 writes
+// the codes, CLIBD_ACT_MUL_AUX_U8 multiplies by the decoded value: half the bytes of the bf16 form on both sides.
+constexpr float GELUQ_LO = -0.1328125f;
+constexpr float GELUQ_STEP = 1.265625f / 255.0f;
+constexpr float GELUQ_INV = 255.0f / 1.265625f;
+__device__ __forceinline__ unsigned geluq_pack4(float a, float b, float c, float d) {   // v_cvt_pk_u8_f32: round + saturate + insert byte
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(a, GELUQ_INV, -GELUQ_LO * GELUQ_INV), 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(b, GELUQ_INV, -GELUQ_LO * GELUQ_INV), 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(c, GELUQ_INV, -GELUQ_LO * GELUQ_INV), 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, GELUQ_INV, -GELUQ_LO * GELUQ_INV), 3, w);
+    return w;
+}
+__device__ __forceinline__ void geluq_unpack4(unsigned w, float out[4]) {               // v_cvt_f32_ubyte0..3 + fma
+    out[0] = fmaf((float)(w & 0xffu), GELUQ_STEP, GELUQ_LO);
+    out[1] = fmaf((float)((w >> 8) & 0xffu), GELUQ_STEP, GELUQ_LO);
+    out[2] = fmaf((float)((w >> 16) & 0xffu), GELUQ_STEP, GELUQ_LO);
+    out[3] = fmaf((float)(w >> 24), GELUQ_STEP, GELUQ_LO);
+}
+
 // d/dx gelu(x) = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));

@@ -277,10 +277,13 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, int M, int 
     if ((ep->act == CLIBD_ACT_GELU_GRAD || ep->act == CLIBD_ACT_MUL_AUX || ep->act == CLIBD_ACT_ADD_AUX) &&
         (!ep->aux_bf16 || ep->ld_aux % 8 || ep->ld_aux < N))
         return set_error(CLIBD_EINVAL, "gemm: GELU_GRAD / MUL_AUX / ADD_AUX need aux_bf16 with ld_aux >= N, % 8");
-    if (ep->act == CLIBD_ACT_GELU_SAVE_GRAD && !ep->out_pre_bf16) return set_error(CLIBD_EINVAL, "gemm: GELU_SAVE_GRAD needs out_pre_bf16");
-    if (ep->act < 0 || ep->act > CLIBD_ACT_ADD_AUX) return set_error(CLIBD_EINVAL, "gemm: bad act");
+    if (ep->act == CLIBD_ACT_MUL_AUX_U8 && (!ep->aux_bf16 || ep->ld_aux % 16 || ep->ld_aux < N))
+        return set_error(CLIBD_EINVAL, "gemm: MUL_AUX_U8 needs aux (one byte per element) with ld_aux >= N, % 16");
+    if ((ep->act == CLIBD_ACT_GELU_SAVE_GRAD || ep->act == CLIBD_ACT_GELU_SAVE_GRAD_U8) && !ep->out_pre_bf16)
+        return set_error(CLIBD_EINVAL, "gemm: GELU_SAVE_GRAD needs out_pre_bf16");
+    if (ep->act < 0 || ep->act > CLIBD_ACT_MUL_AUX_U8) return set_error(CLIBD_EINVAL, "gemm: bad act");
     if (ep->residual_f32 && (ep->ld_res % 4 || ep->ld_res < N)) return set_error(CLIBD_EINVAL, "gemm: ld_res");
-    if (ep->out_pre_bf16 && (ep->ld_pre % 8 || ep->ld_pre < N)) return set_error(CLIBD_EINVAL, "gemm: ld_pre");
+    if (ep->out_pre_bf16 && (ep->ld_pre % (ep->act == CLIBD_ACT_GELU_SAVE_GRAD_U8 ? 16 : 8) || ep->ld_pre < N)) return set_error(CLIBD_EINVAL, "gemm: ld_pre");
     if (ep->out_bf16 && (ep->ld_out_bf16 % 8 || ep->ld_out_bf16 < N)) return set_error(CLIBD_EINVAL, "gemm: ld_out_bf16");
     if (ep->out_f32 && (ep->ld_out_f32 % 4 || ep->ld_out_f32 < N)) return set_error(CLIBD_EINVAL, "gemm: ld_out_f32");
     if (ep->drop_thr16 < 0 || ep->drop_thr16 > 65535 || (ep->drop_thr16 > 0 && (ep->drop_ld < N || (ep->drop_ld & 1) || ep->split_k > 1)))

@@ -391,7 +391,10 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int mc = min(mb + 16 * n + r, p.M - 1);
-                    if constexpr (epi_aux_kind(KIND)) {
+                    if constexpr (KIND == EPI_MUL_AUX_U8) {
+                        const uint2 c8 = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
+                        in_aux[4 * n + r] = make_uint4(c8.x, c8.y, 0u, 0u);
+                    } else if constexpr (epi_aux_kind(KIND)) {
                         in_aux[4 * n + r] = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
                     } else {
                         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)mc * ep.ld_res + nb);
@@ -611,6 +614,8 @@ static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
         case EPI_GELU_SAVE: return K256(EPI_GELU_SAVE);
         case EPI_MUL_AUX: return K256(EPI_MUL_AUX);
         case EPI_ADD_AUX: return K256(EPI_ADD_AUX);
+        case EPI_GELU_SAVE_U8: return K256(EPI_GELU_SAVE_U8);
+        case EPI_MUL_AUX_U8: return K256(EPI_MUL_AUX_U8);
         case EPI_RES_F32: return K256(EPI_RES_F32);
         case EPI_RES_F32_DROP: return K256(EPI_RES_F32_DROP);
         case EPI_SPLITK_F32: return (const void*)gemm256_bf16_nt_kernel<EPI_SPLITK_F32, false, false, false, false>;

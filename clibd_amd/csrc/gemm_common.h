@@ -79,7 +79,14 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
             v[e + 1] *= f1;
         }
     }
-    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
+    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8) {
+        float dg[16];
+        gelu_and_grad_rows<16>(v, dg);
+        uint4 c;
+        c.x = geluq_pack4(dg[0], dg[1], dg[2], dg[3]);   c.y = geluq_pack4(dg[4], dg[5], dg[6], dg[7]);
+        c.z = geluq_pack4(dg[8], dg[9], dg[10], dg[11]); c.w = geluq_pack4(dg[12], dg[13], dg[14], dg[15]);
+        store16_stream((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb, c);
+    } else if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
         float dg[16];
         gelu_and_grad_rows<16>(v, dg);
         uint4 lo, hi;
@@ -107,6 +114,16 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
         for (int e = 0; e < 8; ++e) {
             v[2 * e] *= gelu_grad_f(bf2f((unsigned short)(xs[e] & 0xffffu)));
             v[2 * e + 1] *= gelu_grad_f(bf2f((unsigned short)(xs[e] >> 16)));
+        }
+    }
+    if (ep.act == CLIBD_ACT_MUL_AUX_U8) {
+        const uint4 c = *(const uint4*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        const unsigned cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float d[4];
+            geluq_unpack4(cs[q], d);
+            v[4 * q] *= d[0]; v[4 * q + 1] *= d[1]; v[4 * q + 2] *= d[2]; v[4 * q + 3] *= d[3];
         }
     }
     if (ep.act == CLIBD_ACT_MUL_AUX || ep.act == CLIBD_ACT_ADD_AUX) {
@@ -170,9 +187,11 @@ enum : int {
     EPI_RES_F32_DROP = 5,  // [bias] -> dropout -> + residual_f32 -> out_f32    (BERT proj / fc2 forward, train mode)
     EPI_SPLITK_F32 = 6,    // plain fp32 store of this split's partial tile (split-K workspace mode)
     EPI_ADD_AUX = 7,       // + aux_bf16 -> out_bf16                            (dgrad joining a bf16 residual-gradient stream)
-    EPI_NUM_KINDS = 8,
+    EPI_GELU_SAVE_U8 = 8,  // EPI_GELU_SAVE with gelu' as one byte per element     (fc1 forward, default)
+    EPI_MUL_AUX_U8 = 9,    // EPI_MUL_AUX reading those bytes                      (fc2 dgrad x gelu', default)
+    EPI_NUM_KINDS = 10,
 };
-constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX; }
+constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX || kind == EPI_MUL_AUX_U8; }
 
 __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.split_k > 1) return EPI_GENERIC;
@@ -181,6 +200,8 @@ __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE;
     if (ep.act == CLIBD_ACT_MUL_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX;
     if (ep.act == CLIBD_ACT_ADD_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_ADD_AUX;
+    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8 && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE_U8;
+    if (ep.act == CLIBD_ACT_MUL_AUX_U8 && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX_U8;
     if (ep.act == CLIBD_ACT_NONE && !ep.out_pre_bf16 && ep.residual_f32 && ep.out_f32 && !ep.out_bf16) return drop ? EPI_RES_F32_DROP : EPI_RES_F32;
     return EPI_GENERIC;
 }
@@ -197,6 +218,24 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
         float dg[8];
         gelu_and_grad_rows<8>(v, dg);
         *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(dg);
+        *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
+    if (KIND == EPI_GELU_SAVE_U8) {
+        float dg[8];
+        gelu_and_grad_rows<8>(v, dg);
+        *(uint2*)((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) =
+            make_uint2(geluq_pack4(dg[0], dg[1], dg[2], dg[3]), geluq_pack4(dg[4], dg[5], dg[6], dg[7]));
+        *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
+    if (KIND == EPI_MUL_AUX_U8) {
+        const uint2 c = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        float d0[4], d1[4];
+        geluq_unpack4(c.x, d0);
+        geluq_unpack4(c.y, d1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
         *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
         return;
     }
@@ -225,7 +264,12 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
         }
     }
     if (KIND == EPI_GENERIC) {
-        if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
+        if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8) {
+            float dg[8];
+            gelu_and_grad_rows<8>(v, dg);
+            *(uint2*)((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) =
+                make_uint2(geluq_pack4(dg[0], dg[1], dg[2], dg[3]), geluq_pack4(dg[4], dg[5], dg[6], dg[7]));
+        } else if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD) {
             float dg[8];
             gelu_and_grad_rows<8>(v, dg);
             *(uint4*)((unsigned short*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) = pack8bf(dg);
@@ -237,6 +281,13 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
         if (ep.act == CLIBD_ACT_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (ep.act == CLIBD_ACT_MUL_AUX_U8) {
+            const uint2 c = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+            float d0[4], d1[4];
+            geluq_unpack4(c.x, d0);
+            geluq_unpack4(c.y, d1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
         } else if (ep.act == CLIBD_ACT_GELU_GRAD || ep.act == CLIBD_ACT_MUL_AUX || ep.act == CLIBD_ACT_ADD_AUX) {
             const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
             const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
@@ -283,7 +334,13 @@ __device__ __forceinline__ void store_row8_gelu_fp8(const clibd_gemm_epilogue& e
 template <int KIND>
 __device__ __forceinline__ void fold_row8_in(const clibd_gemm_epilogue& ep, int m, int nb, float v[8], const uint4& ax, const f32x4& r0,
                                              const f32x4& r1) {
-    if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
+    if (KIND == EPI_MUL_AUX_U8) {   // ax.x, ax.y: the row's eight codes
+        float d0[4], d1[4];
+        geluq_unpack4(ax.x, d0);
+        geluq_unpack4(ax.y, d1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
+    } else if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
         const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -312,7 +369,10 @@ template <int KIND>
 __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
     uint4 ax = make_uint4(0u, 0u, 0u, 0u);
     f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;
-    if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
+    if (KIND == EPI_MUL_AUX_U8) {
+        const uint2 c = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        ax.x = c.x; ax.y = c.y;
+    } else if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
         ax = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
     } else {
         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);

@@ -39,6 +39,21 @@ def residual_grad_bf16() -> bool:
     return os.environ.get("CLIBD_RESIDUAL_GRAD", "bf16").lower() != "fp32"
 
 
+# gelu'(fc1 out) is all the MLP's backward needs (frozen fc1 / fc2 carry no weight gradient that would want the activation), and it
+# lies in [-0.129, 1.129].  CLIBD_GELU_GRAD=u8 (opt-in) keeps it as ONE BYTE per element (CLIBD_ACT_GELU_SAVE_GRAD_U8, |error| <=
+# 2.5e-3 everywhere; bf16's half-spacing is 2.0e-3 in [0.5, 1), 3.9e-3 in [1, 2), finer below 0.5) and the fc2 dgrad multiplies by
+# the decoded byte (CLIBD_ACT_MUL_AUX_U8): 50 GB less per step at b=2048, 285.1 -> 282.5 ms.  Gradient effect at full size (DESIGN.md
+# §4): 5e-4 (ViT) / 4e-5 (BERT) relative, invisible against the oracle; on the tiny fixtures the WORST per-tensor error moves by
+# +-10 % (medians unchanged), which the tightest gate (x1.6 of the reference's own autocast error) does not always absorb — so the
+# default stays the bf16 form.  The fp8-forward mode always uses bf16.
+def _mul_aux_act(h) -> int:
+    return ops.ACT_MUL_AUX_U8 if h.dtype == torch.uint8 else ops.ACT_MUL_AUX
+
+
+def gelu_grad_u8() -> bool:
+    return os.environ.get("CLIBD_GELU_GRAD", "bf16").lower() == "u8"
+
+
 # Attention backward: "2phase" (default) = the kernel that derives the softmax statistics itself and evaluates every score twice;
 # "sp" = single pass (ops.attention_bwd_sp; the training forward then also saves its per-layer output, the rounding residual of
 # that output and the log-sum-exp: 4 more bytes per element of activation memory per layer).  The single-pass form needs full
@@ -289,6 +304,8 @@ class TransformerStack:
         a = None if keep else new(FF, AT)           # post-GELU activation (temporary)
         xn2 = new(H, AT) if (self.pre_ln and not keep) else None
         xn8 = new(H, ops.FP8) if f8s is not None else None   # fp8 image of the first LayerNorm's output (temporary)
+        GG = torch.uint8 if (gelu_grad_u8() and f8s is None) else BF16            # storage of gelu'(fc1 out)
+        act_save = ops.ACT_GELU_SAVE_GRAD_U8 if GG == torch.uint8 else ops.ACT_GELU_SAVE_GRAD
         h_tmp = new(FF, BF16) if (f8s is not None and not save) else None       # the fp8 fc1 form always writes gelu'
         t = t0
         sp_ok = save and key_mask is None and f8s is None and S <= 224 and attention_backward_single_pass()
@@ -326,9 +343,9 @@ class TransformerStack:
                 st2 = torch.empty((B, 2), dtype=F32, device=dev)
                 xn2c = newB(H, BF16)
                 ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2c, stats=st2)
-                h = newB(FF, BF16) if save else None
+                h = newB(FF, GG) if save else None
                 ac = newB(FF, BF16)
-                ops.gemm_nt(xn2c, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h, out_bf16=ac)
+                ops.gemm_nt(xn2c, c.w1, bias=c.b1, act=act_save if save else ops.ACT_GELU, out_pre=h, out_bf16=ac)
                 x2 = newB(H, F32)
                 ops.gemm_nt(ac, c.w2, bias=c.b2, residual=x1, out_f32=x2)
                 if save:
@@ -344,7 +361,7 @@ class TransformerStack:
                 qkv = new(3 * H, BF16)
                 x1 = new(H, F32)
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
-                h = new(FF, BF16) if save else None      # holds gelu'(fc1 out): all the backward needs
+                h = new(FF, GG) if save else None        # holds gelu'(fc1 out): all the backward needs
                 x2 = new(H, F32)
                 if f8 is not None:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t,
@@ -367,7 +384,7 @@ class TransformerStack:
                         ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
                     ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
                     ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
-                    ops.gemm_nt(xn2, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
+                    ops.gemm_nt(xn2, c.w1, bias=c.b1, act=act_save if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                     ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1, out_f32=x2)
                     if crec is not None:
                         crec.update(qkv_in=amax(xn), proj_in=amax(o), fc1_in=amax(xn2), fc2_in=amax(a))
@@ -389,7 +406,7 @@ class TransformerStack:
                 s1 = new(H, F32)
                 x1_f32 = new(H, F32)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
-                h = new(FF, BF16) if save else None
+                h = new(FF, GG) if save else None
                 s2 = new(H, F32)
                 x2_f32, x2_bf16 = new(H, F32), new(H, BF16)
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
@@ -423,7 +440,7 @@ class TransformerStack:
                         ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att)
                     ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=s1, drop=d_h1)
                     ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_bf16=x1_bf16, y_f32=x1_f32, stats=st1)
-                    ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=ops.ACT_GELU_SAVE_GRAD if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
+                    ops.gemm_nt(x1_bf16, c.w1, bias=c.b1, act=act_save if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                     ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1_f32, out_f32=s2, drop=d_h2)
                     ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next)
                     if crec is not None:
@@ -479,7 +496,7 @@ class TransformerStack:
                 newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
                 dhc, dtc = newB(FF, BF16), newB(H, BF16)
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
-                ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dhc)
+                ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dhc)
                 wg(dhc, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                 ops.gemm_nt(dhc, c.w1_t, out_bf16=dtc)
                 dx1_f32, dx1_bf16 = newB(H, F32), newB(H, BF16)
@@ -505,7 +522,7 @@ class TransformerStack:
                         dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif self.pre_ln:
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
-                ops.gemm_nt(dx_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)          # d(fc1 out)
+                ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)          # d(fc1 out)
                 wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                 ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
                 if r16:
@@ -544,7 +561,7 @@ class TransformerStack:
                     return res, res
 
                 ds2_res, ds2_b = ln_back(dx_f32, rec["s2"], rec["st2"], c.g2, rec["d_h2"])
-                ops.gemm_nt(ds2_b, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)
+                ops.gemm_nt(ds2_b, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)
                 dx1 = new(H, BF16)
                 ops.gemm_nt(dh, c.w1_t, act=ops.ACT_ADD_AUX, aux=ds2_res, out_bf16=dx1)
                 ds1_res, ds1_b = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"])
@@ -562,7 +579,7 @@ class TransformerStack:
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"], **pg(L.ln2_w, L.ln2_b))
                 wg(ds2_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
-                ops.gemm_nt(ds2_bf16, c.w2_t, act=ops.ACT_MUL_AUX, aux=rec["h"], out_bf16=dh)
+                ops.gemm_nt(ds2_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)
                 wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                 dx1 = new(H, F32)
                 ops.gemm_nt(dh, c.w1_t, residual=ds2_f32, out_f32=dx1)

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import GemmEpilogue, check
 
-ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX, ACT_ADD_AUX = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX, ACT_ADD_AUX, ACT_GELU_SAVE_GRAD_U8, ACT_MUL_AUX_U8 = 0, 1, 2, 3, 4, 5, 6, 7
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
 FP8 = torch.float8_e4m3fn  # OCP e4m3 (gfx950's fp8 MFMA operand format); max finite 448
 
@@ -108,7 +108,7 @@ def gemm_nt(
             raise ValueError("gemm_nt: rank_u must be [M,>=8], rank_v [N,8]")
         ep.rank_u, ep.rank_v, ep.ld_rank_u = rank_u.data_ptr(), rank_v.data_ptr(), _rowmajor(rank_u, "rank_u")
     if aux is not None:
-        _chk(aux, BF16, "aux", contiguous=False)
+        _chk(aux, torch.uint8 if act == ACT_MUL_AUX_U8 else BF16, "aux", contiguous=False)   # _U8: gelu' codes, one byte per element
         if tuple(aux.shape) != (M, N):
             raise ValueError("gemm_nt: aux must be [M,N]")
         ep.aux_bf16, ep.ld_aux = aux.data_ptr(), _rowmajor(aux, "aux")
@@ -117,7 +117,7 @@ def gemm_nt(
         if tuple(residual.shape) != (M, N):
             raise ValueError("gemm_nt: residual must be [M,N]")
         ep.residual_f32, ep.ld_res = residual.data_ptr(), _rowmajor(residual, "residual")
-    for name, t, dt in (("out_pre", out_pre, BF16), ("out_bf16", out_bf16, BF16), ("out_f32", out_f32, F32)):
+    for name, t, dt in (("out_pre", out_pre, torch.uint8 if act == ACT_GELU_SAVE_GRAD_U8 else BF16), ("out_bf16", out_bf16, BF16), ("out_f32", out_f32, F32)):
         if t is not None:
             _chk(t, dt, name, contiguous=False)
             if tuple(t.shape) != (M, N):

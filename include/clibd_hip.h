@@ -52,13 +52,17 @@ const char* clibd_build_hash(void);
  *                                   v = gelu_erf(x)    (training forward: the backward then needs no transcendental)
  *   if act == CLIBD_ACT_MUL_AUX:    v = v * aux_bf16[m,n]                       (dgrad through GELU with saved gelu')
  *   if act == CLIBD_ACT_ADD_AUX:    v = v + aux_bf16[m,n]                       (dgrad joining a bf16 residual-gradient stream)
+ *   if act == CLIBD_ACT_GELU_SAVE_GRAD_U8 / CLIBD_ACT_MUL_AUX_U8: the two forms above with gelu' kept as ONE BYTE per element:
+ *                                   out_pre_bf16 / aux_bf16 then point to uint8 [M,N] (ld_pre / ld_aux in bytes, % 16),
+ *                                   code = rint((gelu'(x) + 0.1328125) * 255 / 1.265625), decoded as code * 1.265625 / 255 - 0.1328125
+ *                                   (gelu' lies in [-0.129, 1.129]; |error| <= 2.5e-3, the spacing of bf16 in [0.5, 1) is 3.9e-3)
  *   if residual_f32:  v += residual_f32[m,n]
  *   out_bf16[m,n] = bf16(v) ; out_f32[m,n] = v   (either or both)
  *   split_k > 1: only out_f32 allowed; partial sums are atomically added into a caller-zeroed out_f32.
  * Constraints: K % 64 == 0, lda/ldw % 8 == 0, N % 16 == 0, all ld_* % 8 == 0, 16-byte aligned pointers.
  * ------------------------------------------------------------------------------------------------ */
 enum { CLIBD_ACT_NONE = 0, CLIBD_ACT_GELU = 1, CLIBD_ACT_GELU_GRAD = 2, CLIBD_ACT_GELU_SAVE_GRAD = 3, CLIBD_ACT_MUL_AUX = 4,
-       CLIBD_ACT_ADD_AUX = 5 };
+       CLIBD_ACT_ADD_AUX = 5, CLIBD_ACT_GELU_SAVE_GRAD_U8 = 6, CLIBD_ACT_MUL_AUX_U8 = 7 };
 
 typedef struct clibd_gemm_epilogue {
     const float* bias;          /* [N] fp32 */

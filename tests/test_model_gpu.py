@@ -921,3 +921,32 @@ def test_single_pass_attention_backward_in_the_towers(dev, monkeypatch):
             ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
             go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
         assert_grads(res["sp"][1], go, rel_tol=2e-2, cos_tol=0.999, what="sp vs oracle")
+
+
+def test_gelu_grad_kept_as_one_byte_in_the_towers(dev, monkeypatch):
+    """CLIBD_GELU_GRAD=u8 (opt-in): the fc1 epilogue keeps gelu' as one byte per element and the fc2 dgrad decodes it (engine.gelu_grad_u8).
+    Forward untouched (embeddings bit for bit), gradients equal to the default path's within the stated quantisation budget and still
+    within the oracle gates, both tower kinds; the full fine-tune walk uses the same two epilogues."""
+    from oracle import clibd_oracle as O
+
+    gd, gi = load("dna_tiny_golden.pt"), load("image_tiny_golden.pt")
+    from tests.test_oracle import build_dna, build_image
+
+    for hm, om, x in ((hip_image(gi, dev), build_image(gi), gi["image_u8"].float() / 255.0), (hip_dna(gd, dev), build_dna(gd), gd["ids"])):
+        g = torch.Generator().manual_seed(5)
+        res = {}
+        for mode in ("bf16", "u8"):
+            monkeypatch.setenv("CLIBD_GELU_GRAD", mode)
+            y = hm(x.to(dev))
+            if mode == "bf16":
+                cot = torch.randn(y.shape, generator=g)
+            res[mode] = (y.detach().cpu(), grads_named(hm, (y * cot.to(dev)).sum()))
+        monkeypatch.delenv("CLIBD_GELU_GRAD")
+        assert torch.equal(res["u8"][0], res["bf16"][0])
+        assert any(not torch.equal(res["u8"][1][n], res["bf16"][1][n]) for n in res["bf16"][1]), "the knob did not reach the kernels"
+        assert_grads(res["u8"][1], res["bf16"][1], rel_tol=2e-2, cos_tol=0.9995, what="u8 vs bf16 gelu'")
+        with O.precision("bf16"):
+            yo = om(x)
+            ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+            go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
+        assert_grads(res["u8"][1], go, rel_tol=2e-2, cos_tol=0.999, what="u8 gelu' vs oracle")

@@ -648,6 +648,9 @@ def test_gemm256_epilogues(ops, dev):
     assert rel_err(outf.cpu(), ref) < 1e-4
 
 
+GELUQ_LO, GELUQ_STEP = -0.1328125, 1.265625 / 255.0   # include/clibd_hip.h: CLIBD_ACT_GELU_SAVE_GRAD_U8 / CLIBD_ACT_MUL_AUX_U8
+
+
 def test_gemm_gelu_save_grad_and_mul_aux(ops, dev):
     g = torch.Generator().manual_seed(91)
     M, N, K = 300, 256, 128
@@ -670,7 +673,9 @@ def test_gemm_gelu_save_grad_and_mul_aux(ops, dev):
 @pytest.mark.parametrize("kind,bias,lora", [("bf16", False, False), ("bf16", True, True), ("bf16", False, True), ("gelu_save", True, False),
                                             ("gelu_save", False, False), ("mul_aux", False, False), ("res_f32", True, False),
                                             ("res_f32", False, True), ("res_f32_drop", True, False), ("generic_two_outputs", True, False),
-                                            ("add_aux", False, False), ("add_aux", False, True), ("add_aux", True, False)])
+                                            ("add_aux", False, False), ("add_aux", False, True), ("add_aux", True, False),
+                                            ("gelu_save_u8", True, False), ("gelu_save_u8", False, True), ("mul_aux_u8", False, False),
+                                            ("mul_aux_u8", True, True)])
 def test_gemm256_epilogue_kinds(ops, dev, kind, bias, lora, K):
     """Every specialised epilogue instantiation of the 256x256 kernel (kind x bias x rank-8 update) on a ragged M (last
     m-tile has 5 live rows), against a torch fp32 reference with the kernel's rounding points; rows past M stay untouched."""
@@ -709,6 +714,37 @@ def test_gemm256_epilogue_kinds(ops, dev, kind, bias, lora, K):
         full, out = buf(BF16)
         ops.gemm_nt(a, w, act=ops.ACT_MUL_AUX, aux=aux, out_bf16=out, **kw)
         checks.append((full, ref * aux.float(), 4e-3))
+    elif kind == "gelu_save_u8":   # gelu' as one byte per element: code = rint((g' - LO) / STEP), exact against the stated code
+        fa, act = buf(BF16)
+        fg = torch.full((M + GUARD, N), 7, dtype=torch.uint8, device=dev)
+        ops.gemm_nt(a, w, act=ops.ACT_GELU_SAVE_GRAD_U8, out_pre=fg[:M], out_bf16=act, **kw)
+        pre = ref.to(BF16).float()
+        checks.append((fa, torch.nn.functional.gelu(pre), 5e-3))
+        torch.cuda.synchronize()
+        dec = fg[:M].float().cpu() * GELUQ_STEP + GELUQ_LO
+        gref = gelu_grad(pre.cpu())
+        # half a step, plus what one bf16 ulp of the pre-activation (accumulation order) moves gelu' by: |gelu''| <= 0.8, ulp(4) = 0.03
+        assert float((dec - gref).abs().max()) <= 0.5 * GELUQ_STEP + 8e-3
+        assert float(((dec - gref).abs() > 0.5 * GELUQ_STEP + 1e-3).float().mean()) < 2e-2
+        assert float((dec - gref).abs().mean()) < 0.3 * GELUQ_STEP
+        assert bool((fg[M:] == 7).all()), "rows past M were written"
+        small_a = torch.empty((300, 256), dtype=BF16, device=dev)     # the same epilogue through the 128x128 kernel (M < 1024)
+        small_g = torch.empty((300, 256), dtype=torch.uint8, device=dev)
+        ops.gemm_nt(a[:300], w[:256], act=ops.ACT_GELU_SAVE_GRAD_U8, out_pre=small_g, out_bf16=small_a, bias=b[:256] if bias else None,
+                    rank_u=u[:300] if lora else None, rank_v=v[:256] if lora else None)
+        torch.cuda.synchronize()
+        assert float((small_g.float().cpu() * GELUQ_STEP + GELUQ_LO - gref[:300, :256]).abs().max()) <= 0.5 * GELUQ_STEP + 8e-3
+        assert rel_err(small_a.float().cpu(), torch.nn.functional.gelu(pre[:300, :256]).cpu()) < 5e-3
+    elif kind == "mul_aux_u8":
+        codes = torch.randint(0, 256, (M, N), generator=g, dtype=torch.int64).to(torch.uint8).to(dev)
+        auxf = codes.float() * GELUQ_STEP + GELUQ_LO
+        full, out = buf(BF16)
+        ops.gemm_nt(a, w, act=ops.ACT_MUL_AUX_U8, aux=codes, out_bf16=out, **kw)
+        checks.append((full, ref * auxf, 4e-3))
+        small = torch.empty((300, 256), dtype=BF16, device=dev)
+        ops.gemm_nt(a[:300], w[:256], act=ops.ACT_MUL_AUX_U8, aux=codes[:300, :256], out_bf16=small, bias=b[:256] if bias else None,
+                    rank_u=u[:300] if lora else None, rank_v=v[:256] if lora else None)
+        assert rel_err(small.float().cpu(), (ref[:300, :256] * auxf[:300, :256]).cpu()) < 4e-3
     elif kind == "add_aux":   # dgrad joining a bf16 residual-gradient stream (CLIBD_ACT_ADD_AUX)
         aux = torch.randn(M, N, generator=g).to(dev, BF16)
         full, out = buf(BF16)

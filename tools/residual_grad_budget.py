@@ -6,7 +6,8 @@ CPU oracle in fp32 (the reference's default arithmetic) and in its bf16 mode (th
 gradients like the reference's autocast).  Prints relative L2 error and cosine over all trainable tensors and the worst
 per-tensor relative error, per tower and mode.
 
-    python tools/residual_grad_budget.py
+    python tools/residual_grad_budget.py                                  # CLIBD_RESIDUAL_GRAD: fp32 | bf16
+    python tools/residual_grad_budget.py CLIBD_GELU_GRAD bf16 u8          # any two-valued knob: reference mode first
 """
 import os
 import sys
@@ -34,11 +35,12 @@ def compare(tag, got, ref):
     rel = float((a - e).norm() / e.norm())
     cosv = float(a @ e / (a.norm() * e.norm()))
     worst = max(float((got[n] - ref[n]).norm() / (ref[n].norm() + 1e-30)) for n in names if float(ref[n].norm()) > 0)
-    print(f"    {tag:34s} rel {rel:.4e}  cos {cosv:.6f}  worst tensor rel {worst:.4e}")
+    print(f"    {tag:44s} rel {rel:.4e}  cos {cosv:.6f}  worst tensor rel {worst:.4e}")
     return rel
 
 
 def main():
+    knob, mode_a, mode_b = (sys.argv[1:4] if len(sys.argv) >= 4 else ("CLIBD_RESIDUAL_GRAD", "fp32", "bf16"))
     torch.manual_seed(3)
     g = torch.Generator().manual_seed(4)
     om = O.build_image_dna_model()
@@ -59,17 +61,17 @@ def main():
         henc.load_state_dict(oenc.state_dict(), strict=True)
         henc = henc.to(dev).eval()
         res = {}
-        for mode in ("fp32", "bf16"):
-            os.environ["CLIBD_RESIDUAL_GRAD"] = mode
+        for mode in (mode_a, mode_b):
+            os.environ[knob] = mode
             out = henc(inp.to(dev))
             res[mode] = grads(henc, out, cot.to(dev))
             torch.cuda.synchronize()
         compare("oracle bf16 mode  vs oracle fp32", ref16, ref32)
-        for mode in ("fp32", "bf16"):
-            compare(f"HIP, {mode} stream  vs oracle fp32", res[mode], ref32)
-            compare(f"HIP, {mode} stream  vs oracle bf16", res[mode], ref16)
-        compare("HIP bf16 stream   vs HIP fp32 stream", res["bf16"], res["fp32"])
-    os.environ.pop("CLIBD_RESIDUAL_GRAD", None)
+        for mode in (mode_a, mode_b):
+            compare(f"HIP, {knob}={mode}  vs oracle fp32", res[mode], ref32)
+            compare(f"HIP, {knob}={mode}  vs oracle bf16", res[mode], ref16)
+        compare(f"HIP {mode_b}  vs HIP {mode_a}", res[mode_b], res[mode_a])
+    os.environ.pop(knob, None)
 
 
 if __name__ == "__main__":
