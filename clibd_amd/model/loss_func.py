@@ -22,6 +22,7 @@ loss carries a gradient) is the same schedule without the world_size factor on t
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -70,8 +71,15 @@ def _check_criterion(criterion):
         raise NotImplementedError("the HIP loss implements nn.CrossEntropyLoss() (mean reduction, probability targets) only")
 
 
+def collectives_forced() -> bool:
+    """CLIBD_FORCE_COLLECTIVES=1 (tests): with a process group initialised, a world of ONE rank takes the data-parallel code path
+    too — packed all-gather, reduce-scatter, gradient all-reduce, broadcast — so that path can run over RCCL on a 1-GPU box
+    (tests/test_multi_gpu.py).  Values are those of the local path (every collective of one rank returns its input)."""
+    return os.environ.get("CLIBD_FORCE_COLLECTIVES") == "1" and has_distributed and dist.is_available() and dist.is_initialized()
+
+
 def _dist_on(world_size: int) -> bool:
-    return world_size > 1 and has_distributed and dist.is_available() and dist.is_initialized()
+    return (world_size > 1 and has_distributed and dist.is_available() and dist.is_initialized()) or collectives_forced()
 
 
 class _SoftCEFn(torch.autograd.Function):
@@ -79,7 +87,7 @@ class _SoftCEFn(torch.autograd.Function):
     feat_grad: 0 = world_size x dL/df (gather_with_grad=True), 1 = dL/df (gather_with_grad=False), 2 = none (+ local_loss)."""
 
     @staticmethod
-    def forward(ctx, pairs, labels, scale, rank, world, reduce_value, feat_grad, *feats):
+    def forward(ctx, pairs, labels, scale, rank, world, reduce_value, feat_grad, use_dist, *feats):
         dev = feats[0].device
         b, D = feats[0].shape
         M = len(feats)
@@ -89,7 +97,7 @@ class _SoftCEFn(torch.autograd.Function):
             ys.append(y)
             invs.append(inv)
         labels = labels.detach().to(torch.int64).contiguous()
-        if world > 1:
+        if use_dist:   # world > 1, or a forced one-rank group (collectives_forced)
             nf = M * b * D
             packed = torch.empty((nf + 2 * b,), dtype=F32, device=dev)     # [M, b, D] embeddings | b int64 labels as 2b fp32 slots
             torch.stack(ys, dim=0, out=packed[:nf].view(M, b, D))
@@ -110,9 +118,9 @@ class _SoftCEFn(torch.autograd.Function):
             ops.softce_rows_fwd(ys[ia], all_y[ib], all_labels, row0, scale_t, loss_sum, ws)
             wss.append(ws)
         loss = loss_sum / float(len(pairs) * N)
-        if world > 1 and reduce_value:
+        if use_dist and reduce_value:
             dist.all_reduce(loss)
-        ctx.pairs, ctx.rank, ctx.world, ctx.dims, ctx.feat_grad = pairs, rank, world, (b, N, D, M, row0), feat_grad
+        ctx.pairs, ctx.rank, ctx.world, ctx.dims, ctx.feat_grad, ctx.use_dist = pairs, rank, world, (b, N, D, M, row0), feat_grad, use_dist
         ctx.saved = (ys, invs, all_y, all_labels, scale_t, wss)
         ctx.scale_needs_grad = scale.requires_grad
         return loss.reshape(())
@@ -129,15 +137,15 @@ class _SoftCEFn(torch.autograd.Function):
         weight = float(world) / float(len(pairs) * N)
         wscale = dloss.detach().to(F32).reshape(1).contiguous()
         dlocal = torch.zeros((M, b, D), dtype=F32, device=dev)
-        dall = torch.zeros((M, N, D), dtype=F32, device=dev) if world > 1 else dlocal
+        dall = torch.zeros((M, N, D), dtype=F32, device=dev) if ctx.use_dist else dlocal
         dscale = torch.zeros((1,), dtype=F32, device=dev)
         for (ia, ib), ws in zip(pairs, wss):
             ops.softce_rows_bwd(all_labels, b, N, D, row0, scale_t, weight, dlocal[ia], dall[ib], dscale, ws, weight_scale=wscale)
         ctx.saved = None
         ds = dscale.reshape(()) if ctx.scale_needs_grad else None
         if ctx.feat_grad == 2:
-            return (None, None, ds, None, None, None, None, *([None] * M))
-        if world > 1:
+            return (None, None, ds, None, None, None, None, None, *([None] * M))
+        if ctx.use_dist:
             send = dall.view(M, world, b, D).permute(1, 0, 2, 3).contiguous()   # [W, M, b, D]
             recv = torch.empty((M, b, D), dtype=F32, device=dev)
             dist.reduce_scatter_tensor(recv.view(-1), send.view(-1))               # the ONE backward collective
@@ -145,10 +153,11 @@ class _SoftCEFn(torch.autograd.Function):
             if ctx.feat_grad == 1:
                 dlocal = dlocal / float(world)
         grads = [ops.l2norm_bwd(dlocal[m], ys[m], invs[m]) for m in range(M)]
-        return (None, None, ds, None, None, None, None, *grads)
+        return (None, None, ds, None, None, None, None, None, *grads)
 
 
-def _contrastive(features, labels, logit_scale, rank, world, bind_to=None, no_image_text_loss=False, reduce_value=True, feat_grad=0):
+def _contrastive(features, labels, logit_scale, rank, world, bind_to=None, no_image_text_loss=False, reduce_value=True, feat_grad=0,
+                 use_dist=None):
     present = [(i, f) for i, f in enumerate(features) if f is not None]
     if len(present) < 2:
         raise ValueError("Too less element for calculating the contrastive loss.")
@@ -164,7 +173,9 @@ def _contrastive(features, labels, logit_scale, rank, world, bind_to=None, no_im
             raise ValueError("all modality features must be [batch, dim] with equal shapes")
     if not torch.is_tensor(logit_scale):
         logit_scale = torch.tensor(float(logit_scale), dtype=F32, device=dev)
-    return _SoftCEFn.apply(pairs, labels.to(dev), logit_scale.to(dev), rank, world, reduce_value, feat_grad, *feats)
+    if use_dist is None:
+        use_dist = world > 1
+    return _SoftCEFn.apply(pairs, labels.to(dev), logit_scale.to(dev), rank, world, reduce_value, feat_grad, bool(use_dist), *feats)
 
 
 class ContrastiveLoss(nn.Module):
@@ -223,12 +234,13 @@ class ClipLoss(nn.Module):
         self.reduce_loss_value = True
 
     def forward(self, image_features, dna_features, text_features, labels, logit_scale, output_dict=False):
-        world = self.world_size if _dist_on(self.world_size) else 1
+        use_dist = _dist_on(self.world_size)
+        world = self.world_size if use_dist else 1
         if self.world_size > 1 and world == 1:
             raise RuntimeError("ClipLoss(world_size>1) needs an initialised torch.distributed process group")
         feat_grad = 0
         if world > 1 and not self.gather_with_grad:
             feat_grad = 2 if self.local_loss else 1   # loss_func.py:99-105
         total = _contrastive([image_features, dna_features, text_features], labels, logit_scale, self.rank, world, self.bind_to,
-                             self.no_image_text_loss, reduce_value=self.reduce_loss_value, feat_grad=feat_grad)
+                             self.no_image_text_loss, reduce_value=self.reduce_loss_value, feat_grad=feat_grad, use_dist=use_dist)
         return {"contrastive_loss": total} if output_dict else total

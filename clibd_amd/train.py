@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from .model.loss_func import ClipLoss, ContrastiveLoss
+from .model.loss_func import ClipLoss, ContrastiveLoss, collectives_forced
 from .optim import FusedAdamW
 
 try:
@@ -77,6 +77,8 @@ class Trainer:
         scales on the incoming batch before steps 0, N, 2N, ... (one extra bf16 forward each time), so the static scales of
         a long run follow the activations as the adapters train."""
         self.model, self.world_size, self.rank = model, world_size, rank
+        # the data-parallel path: world_size > 1, or a one-rank group under CLIBD_FORCE_COLLECTIVES=1 (tests: RCCL on a 1-GPU box)
+        self._dist = world_size > 1 or collectives_forced()
         self.fix_temperature = fix_temperature
         self.fp8_recalibrate_every, self._steps_done = int(fp8_recalibrate_every), 0
         ordered, counts = _backward_order(model, _gradient_reachable(model, fix_temperature))
@@ -86,11 +88,11 @@ class Trainer:
             self.criterion = ClipLoss(local_loss=False, gather_with_grad=True, rank=rank, world_size=world_size,
                                       criterion=torch.nn.CrossEntropyLoss(), bind_to=bind_to, no_image_text_loss=no_image_text_loss)
             # the rank's partial loss rides in a spare slot of the gradient all-reduce: no separate scalar collective
-            self.criterion.reduce_loss_value = world_size == 1
+            self.criterion.reduce_loss_value = not self._dist
         else:
             self.criterion = ContrastiveLoss(criterion=torch.nn.CrossEntropyLoss(), logit_scale=1 / 0.07)
         self.optimizer.grad_scale = 1.0 / world_size  # SUM all-reduce then mean: what DDP does (train_cl.py:204)
-        if world_size > 1 and broadcast_parameters:
+        if self._dist and broadcast_parameters:
             # DDP(model) broadcasts rank 0's parameters and buffers at construction (train_cl.py:204): adapters, heads and the
             # replaced decoder are randomly initialised per process.  Trainable values live in the flat bucket (one message);
             # frozen weights and buffers follow tensor by tensor (once, at start-up).
@@ -128,7 +130,7 @@ class Trainer:
             self._group_end.append(ends)
         self._tail_start = offs[k]            # logit_scale & co, then the AUX slots
         self._bucket_elems = max(1, bucket_bytes // 4)
-        self._bucketed = self.world_size > 1 and n >= 2 * self._bucket_elems
+        self._bucketed = self._dist and n >= 2 * self._bucket_elems
         self._done = list(self._tower_start)  # per tower: flat offset up to which the all-reduce has been issued this step
         self._works = []
 
@@ -161,7 +163,7 @@ class Trainer:
         if hasattr(self.model, "join_streams"):
             self.model.join_streams()  # tower backward passes ran on the towers' own streams
         loss = loss.detach()
-        if self.world_size > 1:
+        if self._dist:
             fold = not getattr(self.criterion, "reduce_loss_value", True)
             if fold:
                 self.optimizer.aux[0:1].copy_(loss.reshape(1))     # partial sums add up to the full-batch loss

@@ -304,3 +304,129 @@ def test_reference_training_loop_ddp_gradscaler_autocast():
         for a, e in zip(res[r]["losses"], ref):
             assert abs(a - e) < 2e-3 * max(1.0, abs(e)), (r, res[r]["losses"], ref)     # every rank reports the full-batch loss
         assert res[r]["losses"][-1] < res[r]["losses"][0] and res[r]["train_loss"] == res[r]["train_loss"]
+
+
+_RCCL_W1 = r'''
+import os, sys, json
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", sys.argv[1]
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+res = {"backend": dist.get_backend()}
+b, D = 256, 768
+packed = torch.randn(b, 2 * D + 2, device=dev)                       # embeddings of two modalities + the labels' fp32 slots (loss_func.py)
+gathered = torch.empty_like(packed)
+dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1))      # the ONE forward collective
+res["all_gather"] = bool(torch.equal(gathered, packed))
+send = torch.randn(b, 2 * D, device=dev); recv = torch.empty_like(send)
+dist.reduce_scatter_tensor(recv.view(-1), send.view(-1))             # the ONE backward collective
+res["reduce_scatter"] = bool(torch.equal(recv, send))
+flat = torch.randn(1_480_000 + 64, device=dev); ref = flat.clone()   # the flat gradient bucket + spare slots (train.py)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):                                        # issued from a tower's stream, awaited before AdamW
+    works = [dist.all_reduce(flat[a:a + 370_016], async_op=True) for a in range(0, flat.numel(), 370_016)]
+for w in works:
+    w.wait()
+torch.cuda.current_stream().wait_stream(side)
+res["all_reduce_async_buckets"] = bool(torch.equal(flat, ref))
+p = torch.randn(4096, device=dev); q = p.clone()
+dist.broadcast(p, src=0)
+res["broadcast"] = bool(torch.equal(p, q))
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_W1 " + json.dumps(res), flush=True)
+'''
+
+
+def test_rccl_single_rank_group_runs_the_steps_collectives():
+    """RCCL itself on the one GPU a test box has: a world-size-1 "nccl" process group (own process, as every rank is) issues the
+    collectives of the data-parallel step in their real shapes — the packed all-gather, the reduce-scatter, the bucketed async
+    all-reduce issued from a side stream, the parameter broadcast — and each must return its input.  It cannot show scaling; it
+    shows that librccl loads, initialises with HSA_ENABLE_IPC_MODE_LEGACY=0 and runs these calls on device buffers and streams
+    exactly as train.py / loss_func.py issue them (the W > 1 arithmetic is covered by the two-rank tests above)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-c", _RCCL_W1, str(port)], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL_W1 ")]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    import json
+
+    res = json.loads(line[0][len("RCCL_W1 "):])
+    assert res.pop("backend") == "nccl"
+    assert all(res.values()), res
+
+
+_RCCL_STEP = r'''
+import os, sys, json
+ROOT = sys.argv[2]
+sys.path.insert(0, ROOT)
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", sys.argv[1]
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+from clibd_amd.model import SimpleCLIP
+from clibd_amd.train import Trainer
+from tests.test_model_gpu import hip_dna, hip_image, hip_text, load
+
+gs, gd, gt, gi = load("step_tiny_golden.pt"), load("dna_tiny_golden.pt"), load("text_tiny_golden.pt"), load("image_tiny_golden.pt")
+img = (gs["image_u8"].float() / 255.0).to(dev)
+text = {k: v.to(dev) for k, v in gs["text"].items()}
+
+def run(bucket_bytes):
+    model = SimpleCLIP(hip_image(gi, dev), hip_dna(gd, dev), hip_text(gt, dev)).to(dev)
+    with torch.no_grad():
+        model.logit_scale.copy_(gs["logit_scale"])
+    tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True, bucket_bytes=bucket_bytes)
+    losses = [float(tr.step(img, gs["dna"].to(dev), text, gs["labels"].to(dev)))]
+    torch.cuda.synchronize()
+    g1 = tr.optimizer.flat_g.detach().clone()          # the (all-reduced) gradient of step 1, as AdamW consumed it
+    losses += [float(tr.step(img, gs["dna"].to(dev), text, gs["labels"].to(dev))) for _ in range(2)]
+    torch.cuda.synchronize()
+    return losses, g1, tr._dist, tr._bucketed
+
+local = run(1 << 22)                                   # no process group: the local path
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+os.environ["CLIBD_FORCE_COLLECTIVES"] = "1"
+one = run(1 << 22)                                     # one all-reduce over the flat bucket
+many = run(4096)                                       # bucketed async all-reduces issued from the towers' backward
+dist.destroy_process_group()
+res = {"backend_ran": True, "dist_flags": [local[2], one[2], many[2], many[3]],
+       "loss_local": local[0], "loss_one": one[0], "loss_many": many[0],
+       "dg_one": float((one[1] - local[1]).abs().max()), "dg_many": float((many[1] - local[1]).abs().max()),
+       "g_scale": float(local[1].abs().max())}
+print("RCCL_STEP " + json.dumps(res), flush=True)
+'''
+
+
+def test_training_step_over_a_single_rank_rccl_group_equals_the_local_step():
+    """The data-parallel code path of Trainer.step / ClipLoss — packed all-gather, reduce-scatter, parameter broadcast, the flat
+    gradient all-reduce in one piece and as async buckets issued from the towers' backward streams — executed over RCCL with a
+    process group of ONE rank (CLIBD_FORCE_COLLECTIVES=1; loss_func.collectives_forced): the first step must give the local path's
+    loss and gradient bucket (every collective of one rank is the identity; what differs is the order of two float additions in
+    the loss backward and the float-atomic sums of the adapter gradients, 1e-5 of the largest element), and the next two steps its
+    loss trajectory (AdamW's normalisation amplifies that noise on near-zero gradient elements, hence 1e-4 there)."""
+    import json
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-c", _RCCL_STEP, str(port), ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL_STEP ")]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    res = json.loads(line[0][len("RCCL_STEP "):])
+    assert res["dist_flags"] == [False, True, True, True], res["dist_flags"]
+    assert abs(res["loss_local"][0] - res["loss_one"][0]) < 2e-6 and abs(res["loss_local"][0] - res["loss_many"][0]) < 2e-6, res
+    for a, b, c in zip(res["loss_local"], res["loss_one"], res["loss_many"]):
+        assert abs(a - b) < 1e-4 and abs(a - c) < 1e-4, res
+    assert res["loss_local"][2] < res["loss_local"][0]
+    assert res["dg_one"] <= 2e-5 * res["g_scale"] and res["dg_many"] <= 2e-5 * res["g_scale"], res
