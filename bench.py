@@ -26,6 +26,11 @@ import sys
 import threading
 import time
 
+# More hardware queues than ROCm's default of 4 per priority level, before the HIP runtime starts: with a process group the process
+# holds RCCL's streams beside the towers', and streams that share a queue serialize.  The towers' side streams are
+# also high-priority (their own queue pool), so this is the second line of defence.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -342,7 +347,19 @@ def eval_bench(args, model, batch, b, world, rank, dev, dist, timer):
                                            f"{world} GPU x {b}, then top-5 inner-product search", "per_gpu_batch": b, "global_batch": b * world,
                                "parallelism": f"dp{world}"},
                     "roofline": roof, "k10": k10}
-        print(json.dumps(out_line), flush=True)
+        emit(out_line)
+
+
+_JSON_FD = None   # the process's original stdout, saved by main() before fd 1 is pointed at stderr
+
+
+def emit(obj) -> None:
+    """The ONE line of stdout: written to the saved descriptor (libraries that print to fd 1 - librccl's banner - land on stderr)."""
+    sys.stdout.flush()
+    if _JSON_FD is None:
+        print(json.dumps(obj), flush=True)
+    else:
+        os.write(_JSON_FD, (json.dumps(obj) + "\n").encode())
 
 
 def self_launch(n: int) -> int:
@@ -374,6 +391,13 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
+    # stdout carries rank 0's JSON line and nothing else: librccl prints a version banner to fd 1 when a process group is
+    # created (seen with the one-rank group of CLIBD_FORCE_COLLECTIVES), so fd 1 is pointed at stderr for the whole run and the
+    # line is written to the saved descriptor at the end
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -390,7 +414,18 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    # CLIBD_FORCE_COLLECTIVES=1 at N = 1 (code-path check on a 1-GPU box): a ONE-rank RCCL group, and the step takes its data-parallel
+    # path over it (packed all-gather, reduce-scatter, gradient all-reduce: clibd_amd.model.loss_func.collectives_forced)
+    forced = world == 1 and os.environ.get("CLIBD_FORCE_COLLECTIVES") == "1"
+    if forced:
+        import socket
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    if world > 1 or forced:
         if shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -591,6 +626,8 @@ def main():
         }
         if shared_gpu:
             out["invalid"] = "CLIBD_BENCH_SHARED_GPU: ranks shared a GPU over gloo (code-path check, not a measurement)"
+        if forced:
+            out["collectives"] = "CLIBD_FORCE_COLLECTIVES: the step's three collectives ran over a ONE-rank RCCL group (their launch path, no transfer)"
         if h2d is not None:
             out["h2d_inclusive"] = h2d
         if world == 1 and not args.no_cpu_baseline:
@@ -598,8 +635,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit(out)
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

@@ -69,7 +69,14 @@ class SimpleCLIP(nn.Module):
     def _side_streams(self, device):
         cache = self.__dict__.setdefault("_streams", {})
         if device not in cache:
-            cache[device] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            # HIGH priority, so that the side streams never share a hardware queue with the current stream.  ROCm multiplexes
+            # the streams of one priority onto GPU_MAX_HW_QUEUES (4) hardware queues, and two streams on one queue run their kernels
+            # back to back: once torch.distributed has created its process group (RCCL brings streams of its own) the towers'
+            # streams landed on the current stream's queue and the overlap was gone — 284 -> 296 ms at b=2048, 37.7 -> 42.0 ms
+            # at b=256, i.e. in every multi-GPU run (found with the one-rank RCCL group of CLIBD_FORCE_COLLECTIVES).
+            # High-priority streams draw from their own queue pool.  CLIBD_TOWER_STREAM_PRIORITY=0 restores normal priority.
+            prio = int(os.environ.get("CLIBD_TOWER_STREAM_PRIORITY", "-1"))
+            cache[device] = (torch.cuda.Stream(device=device, priority=prio), torch.cuda.Stream(device=device, priority=prio))
         return cache[device]
 
     def forward(self, image_input, dna_input, language_input):

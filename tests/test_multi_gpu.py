@@ -430,3 +430,64 @@ def test_training_step_over_a_single_rank_rccl_group_equals_the_local_step():
         assert abs(a - b) < 1e-4 and abs(a - c) < 1e-4, res
     assert res["loss_local"][2] < res["loss_local"][0]
     assert res["dg_one"] <= 2e-5 * res["g_scale"] and res["dg_many"] <= 2e-5 * res["g_scale"], res
+
+
+_STREAMS_UNDER_PG = r'''
+import os, sys, json, time
+ROOT = sys.argv[2]
+sys.path.insert(0, ROOT)
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", sys.argv[1]
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+t = torch.ones(8, device=dev); dist.all_reduce(t)                      # RCCL's streams exist now
+from clibd_amd import ops
+from clibd_amd.model import SimpleCLIP
+m = SimpleCLIP.__new__(SimpleCLIP); m.__dict__["_streams"] = {}
+side = SimpleCLIP._side_streams(m, dev)[0]
+BF16 = torch.bfloat16
+M, N, K = 512, 256, 32768                                             # 8 workgroups of the 128x128 kernel: a long launch on a few CUs
+a1, w1, o1 = (torch.randn(M, K, device=dev).to(BF16), torch.randn(N, K, device=dev).to(BF16), torch.empty(M, N, device=dev, dtype=BF16))
+a2, w2, o2 = (torch.randn(M, K, device=dev).to(BF16), torch.randn(N, K, device=dev).to(BF16), torch.empty(M, N, device=dev, dtype=BF16))
+REPS = 40
+def burst(a, w, o):
+    for _ in range(REPS):
+        ops.gemm_nt(a, w, out_bf16=o)
+def timed(fn):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); return time.perf_counter() - t0
+burst(a1, w1, o1); burst(a2, w2, o2)
+alone = timed(lambda: burst(a1, w1, o1))
+def both():
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        burst(a2, w2, o2)
+    burst(a1, w1, o1)
+    torch.cuda.current_stream().wait_stream(side)
+together = min(timed(both) for _ in range(3))
+dist.destroy_process_group()
+print("STREAMS_PG " + json.dumps({"alone_ms": alone * 1e3, "together_ms": together * 1e3, "priority": side.priority}), flush=True)
+'''
+
+
+def test_tower_streams_stay_concurrent_once_a_process_group_exists():
+    """ROCm multiplexes the HIP streams of one priority onto 4 hardware queues, and two streams on one queue run their kernels back
+    to back.  With torch.distributed's process group created (RCCL's own streams), the towers' normal-priority side streams used to
+    land on the current stream's queue: the two-tower overlap vanished in every multi-GPU run (b=256: 37.7 -> 42.0 ms per step,
+    profiles/r03_exp_process_group_streams.log).  The side streams are therefore high-priority (their own queue pool).  Here, under a
+    one-rank RCCL group: two bursts of long 8-workgroup GEMM launches, one on the current stream and one on the towers' side stream,
+    must take clearly less than twice one burst."""
+    import json
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-c", _STREAMS_UNDER_PG, str(port), ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("STREAMS_PG ")]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    res = json.loads(line[0][len("STREAMS_PG "):])
+    assert res["priority"] == -1, res
+    assert res["together_ms"] < 1.5 * res["alone_ms"], res
