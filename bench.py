@@ -30,6 +30,7 @@ import time
 # holds RCCL's streams beside the towers', and streams that share a queue serialize.  The towers' side streams are
 # also high-priority (their own queue pool), so this is the second line of defence.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's peer mappings need it on this driver (also under torchrun)
 
 import torch
 
