@@ -610,6 +610,10 @@ def main():
             board["mfma_peak_at_sclk_tflops"] = PEAK_BF16_TFLOPS * board["sclk_mhz"] / MAX_SCLK_MHZ
             if roof.get("achieved"):
                 roof["frac_at_delivered_clock"] = roof["achieved"] / board["mfma_peak_at_sclk_tflops"]
+            board["note"] = ("the step runs at the board's power cap: the shader clock is what gives (DESIGN.md §3.1, last bullet). Measured on this "
+                             "board (profiles/r03_exp_power_roof.log): bare v_mfma_f32_16x16x32_bf16 with nothing else running 2034 TFLOP/s at "
+                             "2.07 GHz / 1313 W; the same beside a 3.07 TB/s copy 1281 TFLOP/s at 1.61 GHz / 1400 W; every GEMM shape of the step "
+                             "draws 1400 W at 1.63-1.83 GHz")
             roof["board"] = board
         out = {
             "metric": (f"paired samples/sec/step (I+D contrastive), global batch {b * world}" if not args.tri_modal
