@@ -1,0 +1,36 @@
+"""bench.py's output contract on a GPU box: ONE line on stdout, a JSON object with the driver's keys, also when a process group
+exists (librccl prints a version banner to fd 1 when the group is created; bench.py points fd 1 at stderr and writes its line to
+the saved descriptor).  Small per-GPU batch so the check takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("forced", ["0", "1"])
+def test_bench_prints_exactly_one_json_line(forced):
+    env = dict(os.environ, CLIBD_FORCE_COLLECTIVES=forced)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--per-gpu-batch", "32", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-h2d"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    roof = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] == "mfma" and roof["peak"] == 2500.0 and 0 < roof["frac"] < 1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert "workload" in d["config"] and "model" not in d["config"]
+    if forced == "1":
+        assert "collectives" in d
