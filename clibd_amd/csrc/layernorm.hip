@@ -40,7 +40,9 @@ __device__ __forceinline__ float wave_reduce8(float v[8], int lane) {
 
 // LORA: the adapter matrix A_cat [8,H] sits in LDS as fp32 (conflict-free 16-byte reads), so the kernel stays at
 // high occupancy (HBM-bound: what matters is bytes in flight per CU, i.e. resident waves).
-template <int NCH, bool LORA>
+// ROWS adjacent rows per wave and iteration: twice the bytes in flight per wave, and with LORA every adapter vector read from
+// LDS serves ROWS rows (the down-projection is LDS-read bound: 24 KB of adapter reads per row at ROWS = 1).
+template <int NCH, bool LORA, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int M, int H,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
@@ -68,67 +70,89 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         b[j] = act[j] ? *(const f32x4*)(beta + c) : (f32x4){0, 0, 0, 0};
     }
     const float invH = 1.0f / (float)H;
-    for (int row = wave_in_grid; row < M; row += nwaves) {
-        const float* xr = x + (size_t)row * H;
-        f32x4 v[NCH];
-        float s = 0.f;
+    for (int row0 = wave_in_grid * ROWS; row0 < M; row0 += nwaves * ROWS) {
+        f32x4 v[ROWS][NCH];
+        float mean[ROWS], rstd[ROWS];
+        bool live[ROWS];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            v[j] = act[j] ? *(const f32x4*)(xr + 4 * (lane + 64 * j)) : (f32x4){0, 0, 0, 0};
-            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        for (int rr = 0; rr < ROWS; ++rr) {
+            live[rr] = row0 + rr < M;
+            const float* xr = x + (size_t)min(row0 + rr, M - 1) * H;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) v[rr][j] = act[j] ? *(const f32x4*)(xr + 4 * (lane + 64 * j)) : (f32x4){0, 0, 0, 0};
         }
-        const float mean = wave_sum(s) * invH;
-        float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            if (act[j]) {
+        for (int rr = 0; rr < ROWS; ++rr) {
+            float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = v[j][e] - mean;
-                    q += d * d;
+            for (int j = 0; j < NCH; ++j) s += (v[rr][j][0] + v[rr][j][1]) + (v[rr][j][2] + v[rr][j][3]);
+            mean[rr] = wave_sum(s) * invH;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                if (act[j]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[rr][j][e] - mean[rr];
+                        q += d * d;
+                    }
                 }
             }
+            const float var = wave_sum(q) * invH;
+            rstd[rr] = rsqrtf(var + eps);
+            if (stats != nullptr && lane == 0 && live[rr]) *(float2*)(stats + 2 * (size_t)(row0 + rr)) = make_float2(mean[rr], rstd[rr]);
         }
-        const float var = wave_sum(q) * invH;
-        const float rstd = rsqrtf(var + eps);
-        if (stats != nullptr && lane == 0) *(float2*)(stats + 2 * (size_t)row) = make_float2(mean, rstd);
-        float tp[8];
+        float tp[ROWS][8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) tp[r] = 0.f;
+        for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) tp[rr][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             if (!act[j]) continue;
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mean) * rstd * g[j][e] + b[j][e];
             const int c = 4 * (lane + 64 * j);
-            if (drop_thr16 > 0) {  // y = dropout(LN(x)): HF BertEmbeddings
-                const unsigned base = (unsigned)row * (unsigned)H + (unsigned)c;
-                float f0, f1, f2, f3;
-                drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
-                drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
-                y[0] *= f0; y[1] *= f1; y[2] *= f2; y[3] *= f3;
+            float yb[ROWS][4];   // the bf16-rounded outputs, as the GEMM will read them (LORA)
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int row = row0 + rr;
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[rr][j][e] - mean[rr]) * rstd[rr] * g[j][e] + b[j][e];
+                if (drop_thr16 > 0) {  // y = dropout(LN(x)): HF BertEmbeddings
+                    const unsigned base = (unsigned)row * (unsigned)H + (unsigned)c;
+                    float f0, f1, f2, f3;
+                    drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
+                    drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
+                    y[0] *= f0; y[1] *= f1; y[2] *= f2; y[3] *= f3;
+                }
+                uint2 pk;
+                pk.x = pack2bf(y[0], y[1]);
+                pk.y = pack2bf(y[2], y[3]);
+                if (live[rr]) {
+                    if (y_f32 != nullptr) *(f32x4*)(y_f32 + (size_t)row * H + c) = y;
+                    if (y_bf16 != nullptr) *(uint2*)(y_bf16 + (size_t)row * H + c) = pk;
+                    if (y_fp8 != nullptr)  // fp8-forward mode: the next GEMM's operand, quantised from the fp32 value
+                        *(unsigned*)(y_fp8 + (size_t)row * H + c) = pack4fp8(y[0] * fp8_scale, y[1] * fp8_scale, y[2] * fp8_scale, y[3] * fp8_scale);
+                }
+                yb[rr][0] = bf2f((unsigned short)(pk.x & 0xffff)); yb[rr][1] = bf2f((unsigned short)(pk.x >> 16));
+                yb[rr][2] = bf2f((unsigned short)(pk.y & 0xffff)); yb[rr][3] = bf2f((unsigned short)(pk.y >> 16));
             }
-            if (y_f32 != nullptr) *(f32x4*)(y_f32 + (size_t)row * H + c) = y;
-            uint2 pk;
-            pk.x = pack2bf(y[0], y[1]);
-            pk.y = pack2bf(y[2], y[3]);
-            if (y_bf16 != nullptr) *(uint2*)(y_bf16 + (size_t)row * H + c) = pk;
-            if (y_fp8 != nullptr)  // fp8-forward mode: the next GEMM's operand, quantised from the fp32 value
-                *(unsigned*)(y_fp8 + (size_t)row * H + c) = pack4fp8(y[0] * fp8_scale, y[1] * fp8_scale, y[2] * fp8_scale, y[3] * fp8_scale);
             if (LORA) {
-                const float y0 = bf2f((unsigned short)(pk.x & 0xffff)), y1 = bf2f((unsigned short)(pk.x >> 16));
-                const float y2 = bf2f((unsigned short)(pk.y & 0xffff)), y3 = bf2f((unsigned short)(pk.y >> 16));
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const f32x4 a = *(const f32x4*)(a_lds + r * H + c);
-                    tp[r] += (y0 * a[0] + y1 * a[1]) + (y2 * a[2] + y3 * a[3]);
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr)
+                        tp[rr][r] += (yb[rr][0] * a[0] + yb[rr][1] * a[1]) + (yb[rr][2] * a[2] + yb[rr][3] * a[3]);
                 }
             }
         }
         if (LORA) {
-            const float tv = wave_reduce8(tp, lane);
-            if ((lane & 7) == 0) t_bf16[(size_t)row * 8 + (lane >> 3)] = f2bf(tv);
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const float tv = wave_reduce8(tp[rr], lane);
+                if ((lane & 7) == 0 && live[rr]) t_bf16[(size_t)(row0 + rr) * 8 + (lane >> 3)] = f2bf(tv);
+            }
         }
     }
 }
@@ -140,7 +164,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // PG (full fine-tune mode): also dgamma[c] += sum_rows dy * xhat, dbeta[c] += sum_rows dy — the kernel has dy and xhat in
 // registers anyway; every wave keeps its columns' partial sums over the rows it walks, the block combines its four waves in
 // LDS and issues ONE float atomic per column and parameter (the grid is capped so that these stay a few microseconds).
-template <int NCH, bool PG>
+template <int NCH, bool PG, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy_bf16,
                                                             const float* __restrict__ dy_f32,
                                                             const float* __restrict__ x,
@@ -166,72 +190,92 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
         if (PG) { pgam[j] = (f32x4){0, 0, 0, 0}; pbet[j] = (f32x4){0, 0, 0, 0}; }
     }
     const float invH = 1.0f / (float)H;
-    for (int row = wave_in_grid; row < M; row += nwaves) {
-        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
-        f32x4 gy[NCH], xh[NCH];
-        float s1 = 0.f, s2 = 0.f;
+    // ROWS adjacent rows per wave and iteration, and EVERY input of a row — the incoming residual gradient included — requested
+    // before the first reduction: one memory round trip per iteration instead of two per row.
+    for (int row0 = wave_in_grid * ROWS; row0 < M; row0 += nwaves * ROWS) {
+        f32x4 gy[ROWS][NCH], xh[ROWS][NCH], rs[ROWS][NCH];
+        float rstd[ROWS], m1[ROWS], m2[ROWS];
+        bool live[ROWS];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            gy[j] = (f32x4){0, 0, 0, 0};
-            xh[j] = (f32x4){0, 0, 0, 0};
-            if (!act[j]) continue;
-            const int c = 4 * (lane + 64 * j);
-            f32x4 d;
-            if (dy_f32 != nullptr) {
-                d = *(const f32x4*)(dy_f32 + (size_t)row * H + c);
-            } else {
-                const uint2 pk = *(const uint2*)(dy_bf16 + (size_t)row * H + c);
-                d[0] = bf2f((unsigned short)(pk.x & 0xffff)); d[1] = bf2f((unsigned short)(pk.x >> 16));
-                d[2] = bf2f((unsigned short)(pk.y & 0xffff)); d[3] = bf2f((unsigned short)(pk.y >> 16));
-            }
-            const f32x4 xv = *(const f32x4*)(x + (size_t)row * H + c);
+        for (int rr = 0; rr < ROWS; ++rr) {
+            live[rr] = row0 + rr < M;
+            const size_t row = (size_t)min(row0 + rr, M - 1);
+            const float mean = stats[2 * row];
+            rstd[rr] = stats[2 * row + 1];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gy[j][e] = d[e] * g[j][e];
-                xh[j][e] = (xv[e] - mean) * rstd;
-                s1 += gy[j][e];
-                s2 += gy[j][e] * xh[j][e];
-                if (PG) { pgam[j][e] += d[e] * xh[j][e]; pbet[j][e] += d[e]; }
+            for (int j = 0; j < NCH; ++j) {
+                gy[rr][j] = (f32x4){0, 0, 0, 0};
+                xh[rr][j] = (f32x4){0, 0, 0, 0};
+                rs[rr][j] = (f32x4){0, 0, 0, 0};
+                if (!act[j]) continue;
+                const int c = 4 * (lane + 64 * j);
+                f32x4 d;
+                if (dy_f32 != nullptr) {
+                    d = *(const f32x4*)(dy_f32 + row * H + c);
+                } else {
+                    const uint2 pk = *(const uint2*)(dy_bf16 + row * H + c);
+                    d[0] = bf2f((unsigned short)(pk.x & 0xffff)); d[1] = bf2f((unsigned short)(pk.x >> 16));
+                    d[2] = bf2f((unsigned short)(pk.y & 0xffff)); d[3] = bf2f((unsigned short)(pk.y >> 16));
+                }
+                const f32x4 xv = *(const f32x4*)(x + row * H + c);
+                if (dres != nullptr) rs[rr][j] = *(const f32x4*)(dres + row * H + c);
+                if (dres_b16 != nullptr) {
+                    const uint2 pk = *(const uint2*)(dres_b16 + row * H + c);
+                    rs[rr][j][0] += bf2f((unsigned short)(pk.x & 0xffff)); rs[rr][j][1] += bf2f((unsigned short)(pk.x >> 16));
+                    rs[rr][j][2] += bf2f((unsigned short)(pk.y & 0xffff)); rs[rr][j][3] += bf2f((unsigned short)(pk.y >> 16));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gy[rr][j][e] = d[e] * g[j][e];
+                    xh[rr][j][e] = (xv[e] - mean) * rstd[rr];
+                    if (PG && live[rr]) { pgam[j][e] += d[e] * xh[rr][j][e]; pbet[j][e] += d[e]; }
+                }
             }
         }
-        const float m1 = wave_sum(s1) * invH;
-        const float m2 = wave_sum(s2) * invH;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            if (!act[j]) continue;
-            const int c = 4 * (lane + 64 * j);
-            f32x4 o;
+        for (int rr = 0; rr < ROWS; ++rr) {
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[j][e] - m1 - xh[j][e] * m2);
-            if (dres != nullptr) {
-                const f32x4 r = *(const f32x4*)(dres + (size_t)row * H + c);
+            for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += r[e];
-            }
-            if (dres_b16 != nullptr) {
-                const uint2 pk = *(const uint2*)(dres_b16 + (size_t)row * H + c);
-                o[0] += bf2f((unsigned short)(pk.x & 0xffff)); o[1] += bf2f((unsigned short)(pk.x >> 16));
-                o[2] += bf2f((unsigned short)(pk.y & 0xffff)); o[3] += bf2f((unsigned short)(pk.y >> 16));
-            }
-            if (dx_f32 != nullptr) *(f32x4*)(dx_f32 + (size_t)row * H + c) = o;
-            if (dx_res_b16 != nullptr) {
-                uint2 pk;
-                pk.x = pack2bf(o[0], o[1]);
-                pk.y = pack2bf(o[2], o[3]);
-                *(uint2*)(dx_res_b16 + (size_t)row * H + c) = pk;
-            }
-            if (dx_bf16 != nullptr) {
-                if (drop_thr16 > 0) {  // this copy is d(dense out) = d(sum) * mask / (1-p) of the forward's hidden dropout
-                    const unsigned base = (unsigned)row * (unsigned)H + (unsigned)c;
-                    float f0, f1, f2, f3;
-                    drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
-                    drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
-                    o[0] *= f0; o[1] *= f1; o[2] *= f2; o[3] *= f3;
+                for (int e = 0; e < 4; ++e) {
+                    s1 += gy[rr][j][e];
+                    s2 += gy[rr][j][e] * xh[rr][j][e];
                 }
-                uint2 pk;
-                pk.x = pack2bf(o[0], o[1]);
-                pk.y = pack2bf(o[2], o[3]);
-                *(uint2*)(dx_bf16 + (size_t)row * H + c) = pk;
+            m1[rr] = wave_sum(s1) * invH;
+            m2[rr] = wave_sum(s2) * invH;
+        }
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            if (!live[rr]) continue;
+            const size_t row = (size_t)(row0 + rr);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                if (!act[j]) continue;
+                const int c = 4 * (lane + 64 * j);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd[rr] * (gy[rr][j][e] - m1[rr] - xh[rr][j][e] * m2[rr]) + rs[rr][j][e];
+                if (dx_f32 != nullptr) *(f32x4*)(dx_f32 + row * H + c) = o;
+                if (dx_res_b16 != nullptr) {
+                    uint2 pk;
+                    pk.x = pack2bf(o[0], o[1]);
+                    pk.y = pack2bf(o[2], o[3]);
+                    *(uint2*)(dx_res_b16 + row * H + c) = pk;
+                }
+                if (dx_bf16 != nullptr) {
+                    if (drop_thr16 > 0) {  // this copy is d(dense out) = d(sum) * mask / (1-p) of the forward's hidden dropout
+                        const unsigned base = (unsigned)row * (unsigned)H + (unsigned)c;
+                        float f0, f1, f2, f3;
+                        drop_pair(drop_seed, base, (unsigned)drop_thr16, drop_scale, f0, f1);
+                        drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
+                        o[0] *= f0; o[1] *= f1; o[2] *= f2; o[3] *= f3;
+                    }
+                    uint2 pk;
+                    pk.x = pack2bf(o[0], o[1]);
+                    pk.y = pack2bf(o[2], o[3]);
+                    *(uint2*)(dx_bf16 + row * H + c) = pk;
+                }
             }
         }
     }
@@ -263,6 +307,9 @@ static inline int ln_grid(int M) {
 
 using namespace clibd;
 
+// rows per wave and iteration (A/B at M = 403 456, H = 768: with the down-projection 479 -> 392 us at 2 rows, 391 at 4; without it
+// 352-363 -> 335-347 us at 2, 330 at 4; profiles/r03_exp_layernorm_rows.log)
+constexpr int LN_FWD_ROWS_LORA = 2, LN_FWD_ROWS_PLAIN = 4;
 static int layernorm_fwd_impl(const float* x, int M, int H, const float* gamma, const float* beta, float eps,
                               void* y_bf16, float* y_f32, float* stats, const void* lora_a_bf16, void* t_bf16,
                               uint32_t drop_seed, int drop_thr16, float drop_scale, void* y_fp8, float fp8_scale, void* stream) {
@@ -283,11 +330,11 @@ static int layernorm_fwd_impl(const float* x, int M, int H, const float* gamma, 
 #define LAUNCH(N)                                                                                              \
     do {                                                                                                       \
         if (lora)                                                                                              \
-            hipLaunchKernelGGL((layernorm_fwd_kernel<N, true>), grid, block, lds, st, x, M, H, gamma, beta, eps, \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<N, true, LN_FWD_ROWS_LORA>), grid, block, lds, st, x, M, H, gamma, beta, eps, \
                                (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)lora_a_bf16,      \
                                (unsigned short*)t_bf16, drop_seed, drop_thr16, drop_scale, (unsigned char*)y_fp8, fp8_scale); \
         else                                                                                                   \
-            hipLaunchKernelGGL((layernorm_fwd_kernel<N, false>), grid, block, 0, st, x, M, H, gamma, beta, eps, \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<N, false, LN_FWD_ROWS_PLAIN>), grid, block, 0, st, x, M, H, gamma, beta, eps, \
                                (unsigned short*)y_bf16, y_f32, stats, (const unsigned short*)nullptr,          \
                                (unsigned short*)nullptr, drop_seed, drop_thr16, drop_scale, (unsigned char*)y_fp8, fp8_scale); \
     } while (0)
@@ -337,16 +384,25 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const fl
     // parameter-gradient mode: at most 4 blocks per CU-slot (1024 blocks): 2 x H float atomics per block stay ~1.5 M per launch
     dim3 grid(min((M + 3) / 4, pg ? 1024 : 4096)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(N)                                                                                              \
+    // rows per wave and iteration: two pay for the long launches of the bf16 residual-gradient form (M = 403 456: 716-722 -> 652 us;
+    // at M = 50 432 one row is the faster form: 97 -> 85-87 us against 91); the fp32 / parameter-gradient forms are indifferent
+    // and keep one (profiles/r03_exp_layernorm_rows.log)
+    const bool two_rows = !pg && dy_f32 == nullptr && dres_f32 == nullptr && dx_f32 == nullptr && M >= 131072;
+#define LAUNCH_R(N, R)                                                                                         \
     do {                                                                                                       \
         if (pg)                                                                                                \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<N, true>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<N, true, 1>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
                                stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma, dbeta, \
                                (const unsigned short*)dres_b16, (unsigned short*)dx_res_b16);                  \
         else                                                                                                   \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<N, false>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<N, false, R>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
                                stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale, \
                                (float*)nullptr, (float*)nullptr, (const unsigned short*)dres_b16, (unsigned short*)dx_res_b16); \
+    } while (0)
+#define LAUNCH(N)                    \
+    do {                             \
+        if (two_rows) LAUNCH_R(N, 2); \
+        else LAUNCH_R(N, 1);         \
     } while (0)
     switch (nch) {
         case 1: LAUNCH(1); break;
@@ -355,6 +411,7 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const fl
         default: LAUNCH(4); break;
     }
 #undef LAUNCH
+#undef LAUNCH_R
     return check_launch("layernorm_bwd");
 }
 

@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from clibd_amd import ops
 from tools.bench_ops import timeit
 dev = torch.device("cuda:0"); BF16 = torch.bfloat16; F32 = torch.float32
-for M in (50432, 34048):
+for M in (403456, 272384, 50432):
     H = 768
     x = torch.randn(M, H, device=dev)
     g, b = torch.randn(H, device=dev), torch.randn(H, device=dev)
