@@ -93,30 +93,58 @@ def _summarise(stderr: str) -> list[str]:
     return out
 
 
+def _unit_hash(name: str) -> str:
+    """Content hash of everything one object file is compiled from: its .hip, every shared header, the flags that change code."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in [CSRC / f"{name}.hip"] + sorted(_deps()):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    h.update(os.environ.get("CLIBD_GEMM_DIAG", "0").encode())
+    if name == "capi":
+        h.update(csrc_hash().encode())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, report: bool = False, verbose: bool = True) -> Path:
+    """Recompile every unit whose CONTENT hash (source + headers) differs from the one its object was built from.
+
+    mtimes are not consulted: a copied / rsync'd / restored tree keeps them while the text changes, and the
+    load-time check of `clibd_build_hash()` must never accept a library whose kernel objects predate the sources.  A unit's
+    stamp is written only after its object exists; the library's stamp (`capi.hash`, = csrc_hash()) only after the link.
+    """
     OBJ.mkdir(parents=True, exist_ok=True)
-    deps = _deps()
-    todo = [n for n in SOURCES if force or report or _stale(OBJ / f"{n}.o", [CSRC / f"{n}.hip"] + deps)]
-    # the unit that carries the source hash is rebuilt whenever the hash it was built with differs (content, not mtime)
+
+    def unit_stamp(n: str) -> Path:
+        return OBJ / f"{n}.unit_hash"
+
+    def unit_current(n: str) -> bool:
+        st = unit_stamp(n)
+        return (OBJ / f"{n}.o").exists() and st.exists() and st.read_text().strip() == _unit_hash(n)
+
+    todo = [n for n in SOURCES if force or report or not unit_current(n)]
     stamp = OBJ / "capi.hash"
-    if "capi" not in todo and (not stamp.exists() or stamp.read_text().strip() != csrc_hash()):
-        todo.append("capi")
     if todo:
+        for n in todo:
+            unit_stamp(n).unlink(missing_ok=True)
+        stamp.unlink(missing_ok=True)
         if verbose:
             print(f"[clibd_amd.build] hipcc --offload-arch={ARCH}: {', '.join(todo)}", flush=True)
         with cf.ThreadPoolExecutor(max_workers=min(4, len(todo))) as ex:
             for name, err in ex.map(lambda n: _compile_one(n, report), todo):
+                unit_stamp(name).write_text(_unit_hash(name))
                 if report:
                     print(f"== {name}")
                     print("\n".join(_summarise(err)))
-    if "capi" in todo:
-        stamp.write_text(csrc_hash())
     objs = [OBJ / f"{n}.o" for n in SOURCES]
-    if force or todo or _stale(LIB, objs):
+    linked_ok = LIB.exists() and stamp.exists() and stamp.read_text().strip() == csrc_hash()
+    if force or todo or not linked_ok or _stale(LIB, objs):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+        stamp.write_text(csrc_hash())
         if verbose:
             print(f"[clibd_amd.build] linked {LIB}", flush=True)
     return LIB
