@@ -134,19 +134,45 @@ class GemmTimer:
                   f"{2.0 * M * N * K * n / (t * 1e-3) / 1e12:7.1f} TF  {kinds}", file=sys.stderr, flush=True)
 
 
-class BoardSampler(threading.Thread):
-    """Board power and shader clock (sysfs hwmon, read-only, no GPU call) at 10 Hz while the timed region runs.  Every card the
-    box exposes is sampled; the one reported is the one that drew the most (the bench's own GPU; at N > 1 one of them)."""
+def _pci_slot(local_rank: int):
+    """'dddd:bb:dd' of the bench's own device (torch device properties; no GPU call beyond what the bench already made)."""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        return f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}"
+    except Exception:
+        return None
 
-    def __init__(self, period=0.1):
+
+class BoardSampler(threading.Thread):
+    """Board power and shader clock (sysfs hwmon, read-only, no GPU call) at 10 Hz while the timed region runs — of the bench's OWN
+    device only: the card whose PCI slot (`/sys/class/drm/card*/device/uevent` PCI_SLOT_NAME) equals the slot torch reports for
+    `local_rank`.  On a shared or multi-GPU host another tenant's card may draw more, so nothing is guessed: when the slot cannot
+    be matched there is no `board` entry and no `frac_at_delivered_clock`."""
+
+    def __init__(self, local_rank=0, period=0.1):
         super().__init__(daemon=True)
         self.period, self.samples, self._stop_ev = period, [], threading.Event()
-        self.cards = []
-        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
-            for pn in ("power1_input", "power1_average"):
-                if self._rd(f"{d}/{pn}") is not None:
-                    self.cards.append((d, pn))
+        self.card = None
+        slot = _pci_slot(local_rank)
+        for dev_dir in sorted(glob.glob("/sys/class/drm/card*/device")):
+            name = None
+            try:
+                with open(f"{dev_dir}/uevent") as f:
+                    for line in f:
+                        if line.startswith("PCI_SLOT_NAME="):
+                            name = line.split("=", 1)[1].strip().lower()
+            except OSError:
+                continue
+            if slot is None or name is None or not name.startswith(slot):   # PCI_SLOT_NAME = dddd:bb:dd.f
+                continue
+            for d in sorted(glob.glob(f"{dev_dir}/hwmon/hwmon*")):
+                for pn in ("power1_input", "power1_average"):
+                    if self._rd(f"{d}/{pn}") is not None:
+                        self.card = (d, pn, name)
+                        break
+                if self.card:
                     break
+            break
 
     @staticmethod
     def _rd(path):
@@ -157,8 +183,11 @@ class BoardSampler(threading.Thread):
             return None
 
     def run(self):
+        if self.card is None:
+            return
+        d, pn, _ = self.card
         while not self._stop_ev.is_set():
-            self.samples.append((time.perf_counter(), [(self._rd(f"{d}/{pn}"), self._rd(f"{d}/freq1_input")) for d, pn in self.cards]))
+            self.samples.append((time.perf_counter(), self._rd(f"{d}/{pn}"), self._rd(f"{d}/freq1_input")))
             self._stop_ev.wait(self.period)
 
     def stop(self):
@@ -166,19 +195,18 @@ class BoardSampler(threading.Thread):
         self.join(timeout=2)
 
     def window(self, t0, t1):
-        rows = [v for t, v in self.samples if t0 <= t <= t1]
-        if not rows or not self.cards:
+        if self.card is None:
             return None
-        means = [sum((r[i][0] or 0.0) for r in rows) / len(rows) for i in range(len(self.cards))]
-        k = max(range(len(means)), key=means.__getitem__)
-        pw = sorted(r[k][0] for r in rows if r[k][0] is not None)
-        ck = [r[k][1] for r in rows if r[k][1] is not None]
+        rows = [(p, c) for t, p, c in self.samples if t0 <= t <= t1]
+        pw = sorted(p for p, _ in rows if p is not None)
+        ck = [c for _, c in rows if c is not None]
         if not pw:
             return None
-        cap = self._rd(f"{self.cards[k][0]}/power1_cap")
+        d, pn, name = self.card
+        cap = self._rd(f"{d}/power1_cap")
         sclk = sum(ck) / len(ck) if ck else None
         return {"board_power_w": sum(pw) / len(pw), "board_power_w_p90": pw[min(len(pw) - 1, int(0.9 * len(pw)))], "power_cap_w": cap,
-                "sclk_mhz": sclk, "samples": len(pw), "source": f"{self.cards[k][0]} ({self.cards[k][1]}, freq1_input), 10 Hz over the timed region"}
+                "sclk_mhz": sclk, "samples": len(pw), "source": f"{d} ({pn}, freq1_input; PCI {name} = this rank's device), 10 Hz over the timed region"}
 
 
 def pmc_traffic(per_gpu_batch: int):
@@ -479,7 +507,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    sampler = BoardSampler() if rank == 0 else None
+    sampler = BoardSampler(local_rank) if rank == 0 else None
     if sampler is not None:
         sampler.start()
     t0 = time.perf_counter()   # the timed region carries NO per-launch event records (they cost ~1.3 ms per step of host+GPU time)
@@ -626,7 +654,8 @@ def main():
                                    (", bf16 MFMA" if not args.fp8_forward else ", fp8-forward mode (BASELINE configs[4]): forward GEMMs on the fp8 MFMA, backward bf16") +
                                    (" + BERT-small text tower" if args.tri_modal else ""),
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}", "image": "3x224x224", "dna_tokens": 133,
-                       "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW"},
+                       "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW",
+                       "numerics": model.numerics(), "train_mode": bool(model.training)},
             "loss": loss_val, "roofline": roof,
         }
         if shared_gpu:

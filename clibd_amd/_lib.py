@@ -104,6 +104,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2   # what this binding was written against (clibd_abi_version(), csrc/capi.hip); load() refuses any other library
 
 
 class ClibdHipError(RuntimeError):
@@ -132,6 +133,8 @@ def load() -> C.CDLL:
             raise ClibdHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.clibd_abi_version() != ABI_VERSION:
+        raise ClibdHipError(f"{LIB_PATH} speaks C-ABI version {lib.clibd_abi_version()}, this binding {ABI_VERSION}: rebuild with `python -m clibd_amd.build`")
     _check_build_hash(lib)
     _lib = lib
     return lib

@@ -41,10 +41,11 @@ def remove_module_from_state_dict(state_dict: dict) -> dict:
 
 
 def drop_hf_buffer_keys(state_dict: dict) -> dict:
-    """The reference pins transformers==4.29.2 (requirements.txt:6), whose BertEmbeddings registers `position_ids` (and
-    `token_type_ids`) as PERSISTENT buffers: best.pth / last.pth of both BERT towers carry
-    `...embeddings.position_ids` / `...embeddings.token_type_ids` entries that are not parameters (arange / zeros, recomputed
-    here).  They are dropped before the strict load, as load_pre_trained_bioscan_bert does for the BarcodeBERT pretrain file."""
+    """The reference pins transformers==4.29.2 (requirements.txt:6), whose BertEmbeddings registers `position_ids` as a
+    PERSISTENT buffer (`token_type_ids` is registered persistent=False there and is not written): best.pth / last.pth of both
+    BERT towers carry `...embeddings.position_ids` entries that are not parameters (an arange, recomputed here).  They are dropped
+    before the strict load, as load_pre_trained_bioscan_bert does for the BarcodeBERT pretrain file; a `token_type_ids` entry —
+    which other transformers versions do persist — is dropped as well if present."""
     return {k: v for k, v in state_dict.items() if not (k.endswith("embeddings.position_ids") or k.endswith("embeddings.token_type_ids"))}
 
 
@@ -113,6 +114,8 @@ def _optimizer_layout(model: torch.nn.Module, optimizer) -> list:
 
 def save_training_state(path: str, model: torch.nn.Module, optimizer=None, scheduler=None, epoch: Optional[int] = None):
     state = {"model": model.state_dict(), "epoch": epoch}
+    if hasattr(model, "numerics"):
+        state["numerics"] = model.numerics()   # which arithmetic produced these weights (engine.NUMERICS_CHOICES + fp8-forward flag)
     if optimizer is not None and hasattr(optimizer, "exp_avg"):
         state["optimizer"] = {"exp_avg": optimizer.exp_avg.detach().cpu(), "exp_avg_sq": optimizer.exp_avg_sq.detach().cpu(),
                               "step_count": optimizer.step_count, "layout": _optimizer_layout(model, optimizer),

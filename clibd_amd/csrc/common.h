@@ -197,7 +197,8 @@ __device__ __forceinline__ void gelu_and_grad_rows(float* v, float* dg) {
     }
 }
 // gelu'(x) lies in [-0.1290, 1.1290]: kept for the backward as ONE BYTE, code = rint((g' - LO) / STEP) over [LO, LO + 255 STEP]
-// (|error| <= STEP / 2 = 2.5e-3: the spacing of bf16 in [0.5, 1) is 3.9e-3, in [1, 2) 7.8e-3).  CLIBD_ACT_GELU_SAVE_GRAD_U8 writes
+// (|error| <= STEP / 2 = 2.5e-3; bf16's SPACING is 3.9e-3 in [0.5, 1) and 7.8e-3 in [1, 2), i.e. a rounding error of at most half of
+// that: 2.0e-3 / 3.9e-3 — the figures engine.py quotes).  CLIBD_ACT_GELU_SAVE_GRAD_U8 writes
 // the codes, CLIBD_ACT_MUL_AUX_U8 multiplies by the decoded value: half the bytes of the bf16 form on both sides.
 constexpr float GELUQ_LO = -0.1328125f;
 constexpr float GELUQ_STEP = 1.265625f / 255.0f;

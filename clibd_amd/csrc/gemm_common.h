@@ -187,8 +187,8 @@ enum : int {
     EPI_RES_F32_DROP = 5,  // [bias] -> dropout -> + residual_f32 -> out_f32    (BERT proj / fc2 forward, train mode)
     EPI_SPLITK_F32 = 6,    // plain fp32 store of this split's partial tile (split-K workspace mode)
     EPI_ADD_AUX = 7,       // + aux_bf16 -> out_bf16                            (dgrad joining a bf16 residual-gradient stream)
-    EPI_GELU_SAVE_U8 = 8,  // EPI_GELU_SAVE with gelu' as one byte per element     (fc1 forward, default)
-    EPI_MUL_AUX_U8 = 9,    // EPI_MUL_AUX reading those bytes                      (fc2 dgrad x gelu', default)
+    EPI_GELU_SAVE_U8 = 8,  // EPI_GELU_SAVE with gelu' as one byte per element     (fc1 forward; opt-in: numerics gelu_grad="u8")
+    EPI_MUL_AUX_U8 = 9,    // EPI_MUL_AUX reading those bytes                      (fc2 dgrad x gelu'; opt-in, same switch)
     EPI_NUM_KINDS = 10,
 };
 constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX || kind == EPI_MUL_AUX_U8; }

@@ -30,39 +30,53 @@ class NotSupportedYet(NotImplementedError):
     pass
 
 
-# Frozen-base (LoRA) backward: the gradient of the residual stream travels between blocks as bf16 instead of fp32 — the
-# LayerNorm backward then moves 10 instead of 16 bytes per element and the BERT dgrad GEMMs join the stream with a bf16 add
-# (CLIBD_ACT_ADD_AUX) instead of an fp32 read + write.  The reference's autograd keeps this stream in fp32 (also under
-# autocast); the extra rounding (one bf16 rounding per block-half: ~0.1 % rms each, independent) is budgeted in DESIGN.md §4.
-# CLIBD_RESIDUAL_GRAD=fp32 restores the fp32 stream.  Full fine-tune mode always keeps fp32.
-def residual_grad_bf16() -> bool:
-    return os.environ.get("CLIBD_RESIDUAL_GRAD", "bf16").lower() != "fp32"
+# ---- numerics switches of the backward --------------------------------------------------------------------------------------------
+# Explicit per-stack settings (`TransformerStack.numerics`, set through `SimpleCLIP.set_numerics(...)` / `Trainer(numerics=...)`);
+# the environment variables only give the DEFAULT a stack is constructed with, so two trainers in one process can differ and a
+# bench line / training state records which arithmetic produced it (`bench.py` config.numerics, `checkpoint.save_training_state`).
+#
+# residual_grad ("bf16" default | "fp32"; env CLIBD_RESIDUAL_GRAD).  Frozen-base (LoRA) backward: the gradient of the residual stream
+#   travels between blocks as bf16 instead of fp32 — the LayerNorm backward then moves 10 instead of 16 bytes per element and the
+#   BERT dgrad GEMMs join the stream with a bf16 add (CLIBD_ACT_ADD_AUX) instead of an fp32 read + write.  The reference's autograd
+#   keeps this stream in fp32 (also under autocast); the extra rounding (one bf16 rounding per block-half: ~0.1 % rms each,
+#   independent) is budgeted in DESIGN.md §4.  Full fine-tune mode always keeps fp32.
+# gelu_grad ("bf16" default | "u8"; env CLIBD_GELU_GRAD).  gelu'(fc1 out) is all the MLP's backward needs (frozen fc1 / fc2 carry no
+#   weight gradient that would want the activation), and it lies in [-0.129, 1.129].  "u8" keeps it as ONE BYTE per element
+#   (CLIBD_ACT_GELU_SAVE_GRAD_U8, |error| <= 2.5e-3 everywhere; bf16's half-spacing is 2.0e-3 in [0.5, 1), 3.9e-3 in [1, 2), finer
+#   below 0.5) and the fc2 dgrad multiplies by the decoded byte (CLIBD_ACT_MUL_AUX_U8): 50 GB less per step at b=2048, 285.1 -> 282.5
+#   ms.  Gradient effect at full size: 5e-4 (ViT) / 4e-5 (BERT) relative, invisible against the oracle; on the tiny
+#   fixtures the WORST per-tensor error moves by +-10 % (medians unchanged), which the tightest gate (x1.6 of the reference's own
+#   autocast error) does not always absorb — so the default stays the bf16 form.  The fp8-forward mode always uses bf16.
+# attn_bwd ("2phase" default | "sp"; env CLIBD_ATTN_BWD).  "2phase" = the kernel that derives the softmax statistics itself and
+#   evaluates every score twice; "sp" = single pass (ops.attention_bwd_sp; the training forward then also saves its per-layer output,
+#   the rounding residual of that output and the log-sum-exp: 4 more bytes per element of activation memory per layer).  The
+#   single-pass form needs full sequences without a key mask, S <= 224 and the bf16 forward; everything else (text tower, the
+#   class-row-only last ViT block, fp8-forward mode) keeps the two-phase kernel.  Round 3 measurement: parity-green,
+#   1.7 x fewer MFMAs and half the exponentials per head, but as built 1.17 - 1.24 x SLOWER — it stays opt-in.
+NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"))
+_NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD")
 
 
-# gelu'(fc1 out) is all the MLP's backward needs (frozen fc1 / fc2 carry no weight gradient that would want the activation), and it
-# lies in [-0.129, 1.129].  CLIBD_GELU_GRAD=u8 (opt-in) keeps it as ONE BYTE per element (CLIBD_ACT_GELU_SAVE_GRAD_U8, |error| <=
-# 2.5e-3 everywhere; bf16's half-spacing is 2.0e-3 in [0.5, 1), 3.9e-3 in [1, 2), finer below 0.5) and the fc2 dgrad multiplies by
-# the decoded byte (CLIBD_ACT_MUL_AUX_U8): 50 GB less per step at b=2048, 285.1 -> 282.5 ms.  Gradient effect at full size (DESIGN.md
-# §4): 5e-4 (ViT) / 4e-5 (BERT) relative, invisible against the oracle; on the tiny fixtures the WORST per-tensor error moves by
-# +-10 % (medians unchanged), which the tightest gate (x1.6 of the reference's own autocast error) does not always absorb — so the
-# default stays the bf16 form.  The fp8-forward mode always uses bf16.
+def default_numerics() -> dict:
+    """The settings a new stack starts with: the first choice of each switch unless its environment variable names another."""
+    out = {}
+    for k, choices in NUMERICS_CHOICES.items():
+        v = os.environ.get(_NUMERICS_ENV[k], choices[0]).lower()
+        out[k] = v if v in choices else choices[0]
+    return out
+
+
+def check_numerics(settings: dict) -> dict:
+    for k, v in settings.items():
+        if k not in NUMERICS_CHOICES:
+            raise ValueError(f"unknown numerics switch {k!r} (known: {sorted(NUMERICS_CHOICES)})")
+        if v not in NUMERICS_CHOICES[k]:
+            raise ValueError(f"numerics switch {k}: {v!r} is not one of {NUMERICS_CHOICES[k]}")
+    return settings
+
+
 def _mul_aux_act(h) -> int:
     return ops.ACT_MUL_AUX_U8 if h.dtype == torch.uint8 else ops.ACT_MUL_AUX
-
-
-def gelu_grad_u8() -> bool:
-    return os.environ.get("CLIBD_GELU_GRAD", "bf16").lower() == "u8"
-
-
-# Attention backward: "2phase" (default) = the kernel that derives the softmax statistics itself and evaluates every score twice;
-# "sp" = single pass (ops.attention_bwd_sp; the training forward then also saves its per-layer output, the rounding residual of
-# that output and the log-sum-exp: 4 more bytes per element of activation memory per layer).  The single-pass form needs full
-# sequences without a key mask, S <= 224 and the bf16 forward; everything else (text tower, the class-row-only last ViT block,
-# fp8-forward mode) keeps the two-phase kernel.  Round 3 measurement: parity-green, 1.7 x fewer MFMAs and half the
-# exponentials per head, but as built 1.17 - 1.24 x SLOWER (one 8-wave workgroup per CU runs its phases in lockstep and cannot put
-# the staging of its 192 KB per head under compute) — it stays opt-in until its pipeline is rebuilt.
-def attention_backward_single_pass() -> bool:
-    return os.environ.get("CLIBD_ATTN_BWD", "2phase").lower() == "sp"
 
 
 @dataclass
@@ -146,6 +160,10 @@ class TransformerStack:
         self._cache_key = None
         self.fp8 = None  # fp8-forward mode: [{site: activation scale}] per layer; see enable_fp8
         self._calib = None
+        self.numerics = default_numerics()   # backward arithmetic switches (see NUMERICS_CHOICES above); set_numerics() changes them
+
+    def set_numerics(self, **settings):
+        self.numerics.update(check_numerics(settings))
 
     # ---- fp8-forward mode (BASELINE.json configs[4]) ----------------------------------------------------------------
     # activation sites, named by the GEMM that consumes them
@@ -304,11 +322,11 @@ class TransformerStack:
         a = None if keep else new(FF, AT)           # post-GELU activation (temporary)
         xn2 = new(H, AT) if (self.pre_ln and not keep) else None
         xn8 = new(H, ops.FP8) if f8s is not None else None   # fp8 image of the first LayerNorm's output (temporary)
-        GG = torch.uint8 if (gelu_grad_u8() and f8s is None) else BF16            # storage of gelu'(fc1 out)
+        GG = torch.uint8 if (self.numerics["gelu_grad"] == "u8" and f8s is None) else BF16            # storage of gelu'(fc1 out)
         act_save = ops.ACT_GELU_SAVE_GRAD_U8 if GG == torch.uint8 else ops.ACT_GELU_SAVE_GRAD
         h_tmp = new(FF, BF16) if (f8s is not None and not save) else None       # the fp8 fc1 form always writes gelu'
         t = t0
-        sp_ok = save and key_mask is None and f8s is None and S <= 224 and attention_backward_single_pass()
+        sp_ok = save and key_mask is None and f8s is None and S <= 224 and self.numerics["attn_bwd"] == "sp"
         for i, (L, c) in enumerate(zip(self.layers, self._cache)):
             has_lora = L.lora is not None
             rec = {}
@@ -481,7 +499,7 @@ class TransformerStack:
         first_lora = min((i for i, L in enumerate(self.layers) if L.lora is not None), default=len(self.layers))
         if full:
             first_lora = -1  # every layer has trainable parameters and the input gradient is needed
-        r16 = residual_grad_bf16() and not full   # bf16 residual-gradient stream (see residual_grad_bf16)
+        r16 = self.numerics["residual_grad"] == "bf16" and not full   # bf16 residual-gradient stream (see NUMERICS_CHOICES)
         # full fine-tune: the LayerNorm backward accumulates d(gamma), d(beta) in the same pass (it holds dy and xhat anyway)
         pg = lambda w, b: (dict(dgamma=grads[id(w)].view(-1), dbeta=grads[id(b)].view(-1)) if full and id(w) in grads else {})
         wg = lambda dy, x, ws, bs: linear_wgrad(dy, x, ws, bs, grads) if full else None

@@ -140,6 +140,28 @@ class SimpleCLIP(nn.Module):
             st.enable_fp8(scales, amax=am if am else None, margin=margin)
         return self
 
+    def _stacks(self):
+        return [enc.tower().stack for enc in (self.image_encoder, self.dna_encoder, self.language_encoder)
+                if enc is not None and hasattr(enc, "tower")]
+
+    def set_numerics(self, **settings):
+        """Backward arithmetic switches of every tower (clibd_amd.engine.NUMERICS_CHOICES: residual_grad = "bf16" | "fp32",
+        gelu_grad = "bf16" | "u8", attn_bwd = "2phase" | "sp").  The CLIBD_* environment variables only give the defaults a
+        tower is constructed with; this is the explicit form (per model, recorded by bench.py and save_training_state)."""
+        for st in self._stacks():
+            st.set_numerics(**settings)
+        return self
+
+    def numerics(self) -> dict:
+        """{tower: settings}: what produced this model's gradients (written into the bench line and the training state)."""
+        out = {}
+        for name in ("image_encoder", "dna_encoder", "language_encoder"):
+            enc = getattr(self, name)
+            if enc is not None and hasattr(enc, "tower"):
+                st = enc.tower().stack
+                out[name] = dict(st.numerics, forward="fp8 (e4m3) GEMM operands" if st.fp8 is not None else "bf16")
+        return out
+
     def join_streams(self):
         """Make the current stream wait for the towers' side streams (call after backward(): gradients written into the
         fused optimizer's flat buffers by a tower's backward are produced on that tower's stream)."""

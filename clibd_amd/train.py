@@ -69,14 +69,19 @@ def _backward_order(model, params):
 class Trainer:
     def __init__(self, model, lr: float = 1e-3, world_size: int = 1, rank: int = 0, all_gather: bool = True,
                  fix_temperature: Optional[float] = None, bind_to=None, no_image_text_loss=False, weight_decay: float = 1e-2,
-                 broadcast_parameters: bool = True, bucket_bytes: int = 64 << 20, fp8_recalibrate_every: int = 0):
+                 broadcast_parameters: bool = True, bucket_bytes: int = 64 << 20, fp8_recalibrate_every: int = 0,
+                 numerics: Optional[dict] = None):
         """bucket_bytes: at world_size > 1, when the gradients are at least two buckets long (full fine-tune: 694 MB), the
         all-reduce is issued in pieces of about this size as the backward completes them, each on the stream that produced
         it, so RCCL runs under the rest of the backward; smaller gradient sets (LoRA: 6 MB) keep the single all-reduce.
         fp8_recalibrate_every = N > 0: fp8-forward mode (SimpleCLIP.enable_fp8_forward) re-measures its per-layer activation
         scales on the incoming batch before steps 0, N, 2N, ... (one extra bf16 forward each time), so the static scales of
-        a long run follow the activations as the adapters train."""
+        a long run follow the activations as the adapters train.
+        numerics: backward arithmetic switches for every tower of `model` (clibd_amd.engine.NUMERICS_CHOICES); None keeps what the
+        towers were constructed with (environment defaults)."""
         self.model, self.world_size, self.rank = model, world_size, rank
+        if numerics:    # e.g. dict(residual_grad="fp32"): the reference's fp32 residual-gradient stream (engine.NUMERICS_CHOICES)
+            model.set_numerics(**numerics)
         # the data-parallel path: world_size > 1, or a one-rank group under CLIBD_FORCE_COLLECTIVES=1 (tests: RCCL on a 1-GPU box)
         self._dist = world_size > 1 or collectives_forced()
         self.fix_temperature = fix_temperature

@@ -256,3 +256,65 @@ def test_training_state_records_and_remaps_the_optimizer_layout(tmp_path):
     load_training_state(path, m, _FakeFlatOptimizer(train))
     with pytest.raises(ValueError, match="no optimizer layout"):
         load_training_state(path, m, d)
+
+
+def _cpu_adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """torch.optim.AdamW arithmetic on the flat bucket (the contract of clibd_adamw_step, include/clibd_hip.h)."""
+    with torch.no_grad():
+        gg = g * grad_scale
+        p.mul_(1 - lr * weight_decay)
+        m.mul_(beta1).add_(gg, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        p.addcdiv_(m / (1 - beta1 ** step), (v / (1 - beta2 ** step)).sqrt().add_(eps), value=-lr)
+
+
+@pytest.mark.parametrize("sched", ["one_cycle", "cosine", "exponential", "step"])
+def test_fused_adamw_follows_the_references_lr_schedulers(monkeypatch, sched):
+    """`FusedAdamW` is a real torch.optim.Optimizer, so the reference's schedulers (scripts/train_cl.py:222-246: OneCycleLR with
+    pct_start 0.3 / cos / cycle_momentum=False, CosineAnnealingLR, ExponentialLR, StepLR) drive `param_groups[0]['lr']`, which
+    the fused step reads every call: ten steps under each scheduler equal torch.optim.AdamW under the same scheduler.  The
+    device kernel is replaced by its CPU statement here (the kernel itself: tests/test_ops_gpu.py::test_adamw_matches_torch and
+    ::test_fused_adamw_under_one_cycle_lr_on_the_gpu)."""
+    from torch.optim import lr_scheduler
+
+    from clibd_amd import optim
+
+    monkeypatch.setattr(optim.ops, "adamw_step", _cpu_adamw_step)
+    monkeypatch.setattr(optim.FusedAdamW, "_check_params", staticmethod(lambda ps, dev: None))
+    g = torch.Generator().manual_seed(31)
+    shapes = [(4, 96), (96, 4), (33,), ()]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    mine = [torch.nn.Parameter(t.clone()) for t in init]
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    lr = 1e-3 * 2048 / 500          # util.scale_learning_rate at the metric's global batch
+    fo = optim.FusedAdamW(mine, lr=lr)
+    ro = torch.optim.AdamW(ref, lr=lr)
+    total = 10
+
+    def make(o):
+        if sched == "one_cycle":
+            return lr_scheduler.OneCycleLR(o, max_lr=4 * lr, total_steps=total, pct_start=0.3, anneal_strategy="cos", cycle_momentum=False)
+        if sched == "cosine":
+            return lr_scheduler.CosineAnnealingLR(o, T_max=total, eta_min=1e-9)
+        if sched == "exponential":
+            return lr_scheduler.ExponentialLR(o, gamma=0.95)
+        return lr_scheduler.StepLR(o, step_size=3, gamma=0.5)
+
+    fs, rs = make(fo), make(ro)
+    lrs = []
+    for step in range(total):
+        fo.zero_grad()
+        ro.zero_grad()
+        for a, b in zip(mine, ref):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad.copy_(gr)            # gradients live as views of the flat bucket
+            b.grad = gr.clone()
+        fo.step()
+        ro.step()
+        fs.step()
+        rs.step()
+        assert fo.param_groups[0]["lr"] == ro.param_groups[0]["lr"]
+        lrs.append(fo.param_groups[0]["lr"])
+    assert len(set(lrs)) > 1                      # the schedule moved, and the fused step saw it
+    for a, b in zip(mine, ref):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (sched, (a - b).abs().max())

@@ -108,6 +108,43 @@ def test_b2048_training_step_runs_and_learns(dev, big):
     assert torch.isfinite(tr.optimizer.flat_p).all()
 
 
+def test_b2048_train_mode_step_is_finite_and_bit_reproducible(dev, big):
+    """The path `bench.py` actually times: the model in TRAIN mode (`train_epoch.py:19`; HF BERT dropout p = 0.1 puts the DNA
+    tower on attention_*<10,...,DROP=true> and the dropout epilogues of the 256x256 GEMM at M = 272 384 rows) at the metric's
+    batch.  No oracle runs this size, so: finite, |loss - ln 2048| < 0.5 at random init, and — the masks being a pure function
+    of (seed, element index) — the embeddings, the loss and (up to float-atomic order) the gradients repeat bit for bit when
+    the same base seed is drawn again, and change when another one is drawn."""
+    from clibd_amd.model import ClipLoss
+
+    model, batch = big
+    crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+    ps = _params(model)
+    model.train()
+    try:
+        def run(seed):
+            torch.manual_seed(seed)        # the towers draw their dropout base seed from the CPU generator
+            i, d, _, scale, _ = model(batch["image"], batch["dna"], None)
+            loss = crit(i, d, None, batch["labels"], scale)
+            gs = torch.autograd.grad(loss, ps, allow_unused=True)
+            model.join_streams()
+            torch.cuda.synchronize()
+            g = torch.cat([(torch.zeros_like(p) if g_ is None else g_).flatten() for p, g_ in zip(ps, gs)])
+            return i.detach().clone(), d.detach().clone(), float(loss.detach()), g.detach().clone()
+
+        i1, d1, l1, g1 = run(77)
+        i2, d2, l2, g2 = run(77)
+        i3, d3, l3, _ = run(78)
+    finally:
+        model.eval()
+    assert math.isfinite(l1) and torch.isfinite(i1).all() and torch.isfinite(d1).all() and torch.isfinite(g1).all()
+    assert abs(l1 - math.log(NB)) < 0.5, l1
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)                       # same seed: the same masks, the same bits
+    assert abs(l1 - l2) <= 1e-5 * abs(l1)                                    # the loss value is a float-atomic sum
+    assert (g1 - g2).abs().max().item() <= 1e-4 * g1.abs().max().item()      # adapter gradients: float-atomic order only
+    assert torch.equal(i1, i3)                                               # timm ViT has no dropout: the image rows do not move
+    assert not torch.equal(d1, d3) and (d1 - d3).abs().max().item() > 1e-5   # BERT dropout with fresh masks does
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[4]: BIOSCAN-5M-shaped run, per-GPU batch 1024 of a global batch 8192, fp8 MFMA GEMM path
 # (reference shape: config/model_config/for_bioscan_5m/final_experiments/image_dna_seed_42.yaml:1-2).  Same property style:

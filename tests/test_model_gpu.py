@@ -404,6 +404,53 @@ def test_bert_train_mode_dropout_matches_oracle_masks(dev):
     assert rel(y2.cpu(), y.detach().cpu()) < 2e-3 and rel(y3.cpu(), y2.cpu()) > 5e-3
 
 
+def test_bert_base_width_train_mode_matches_oracle_masks(dev):
+    """The DNA tower at the width the bench times it — 12 layers, H = 768, 12 heads, FF = 3072, S = 133 — in TRAIN mode (HF BERT
+    dropout p = 0.1 on the embeddings, the attention probabilities and both dense outputs of every layer: what
+    `train_epoch.py:19` model.train() switches on and what `bench.py` measures), batch 16, against the oracle evaluating the
+    same counter-based masks.  This is the kernel set of the timed step — attention_*<10,...,DROP=true>, the dropout epilogue
+    of the 256x256 GEMM at K = 768 / 3072, the dropout LayerNorm — at full width; the tiny fixture (H = 128) reaches them
+    only through the 128x128 kernel.  Embeddings 1e-3 on the unit-scale head output, adapter / decoder
+    gradients rel 2e-2, cosine 0.999."""
+    from oracle import clibd_oracle as O
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import CLIBDDNAEncoder, load_pre_trained_bioscan_bert
+
+    torch.manual_seed(23)
+    om = O.build_image_dna_model().dna_encoder
+    with torch.no_grad():
+        for n, p in om.named_parameters():
+            if ".w_b." in n:
+                p.normal_(0, 0.02)      # adapters that do something (B = 0 at initialisation)
+    m = CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), r=4, num_classes=768)
+    m.load_state_dict(om.state_dict(), strict=True)
+    m = m.to(dev).train()
+    B = 16
+    ids = synthetic_batch(B, torch.device("cpu"), seed=9, rank=0, with_text=False)["dna"]
+    cot = torch.randn(B, 768, generator=torch.Generator().manual_seed(5))
+    torch.manual_seed(4321)
+    base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    torch.manual_seed(4321)       # the tower draws the same base seed from the CPU generator
+    y = m(ids.to(dev))
+    got = grads_named(m, (y * cot.to(dev)).sum())
+    with O.precision("bf16"), O.dropout(0.1, 0.1, base):
+        yo = om(ids)
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps], allow_unused=True)))
+    go = {n: (torch.zeros_like(p) if go[n] is None else go[n]) for n, p in ps}
+    # rows of the head output are probability vectors averaged over 133 tokens (sum 1, entries ~ 1/768): compare on the rows'
+    # own scale, i.e. after the L2 normalisation SimpleCLIP applies (unit-norm rows, north_star's 1e-3)
+    yn, yon = torch.nn.functional.normalize(y.detach().float().cpu(), dim=1), torch.nn.functional.normalize(yo.detach(), dim=1)
+    err = (yn - yon).abs().max().item()
+    print(f"[BERT-base train mode vs oracle with identical masks] unit-norm embedding error {err:.2e}, rel {rel(y.cpu(), yo.detach()):.2e}")
+    assert err < 1e-3
+    got = {n: g for n, g in got.items() if n in go}
+    assert_grads(got, go, rel_tol=2e-2, cos_tol=0.999, what="BERT-base train mode", zero_rel=1e-6)
+    with torch.no_grad():
+        ye = m.eval()(ids.to(dev))
+    assert rel(ye.cpu(), y.detach().cpu()) > 1e-4     # and the masks did something
+
+
 def test_text_tower_train_mode_dropout_with_mask(dev):
     from oracle import clibd_oracle as O
 
@@ -896,7 +943,7 @@ def test_get_feature_and_label_matches_the_reference_loop(dev):
 
 
 def test_single_pass_attention_backward_in_the_towers(dev, monkeypatch):
-    """CLIBD_ATTN_BWD=sp (opt-in): the towers' training forward saves lse / output residual and the backward takes the single-pass
+    """numerics attn_bwd="sp" (opt-in; CLIBD_ATTN_BWD=sp as the construction default): the towers' training forward saves lse / output residual and the backward takes the single-pass
     attention kernel (the class-row-only last ViT block and masked sequences keep the two-phase one).  Same embeddings bit for
     bit, gradients equal to the default path's up to the kernels' rounding points, and still within the oracle gates."""
     from oracle import clibd_oracle as O
@@ -908,12 +955,12 @@ def test_single_pass_attention_backward_in_the_towers(dev, monkeypatch):
         g = torch.Generator().manual_seed(3)
         res = {}
         for mode in ("2phase", "sp"):
-            monkeypatch.setenv("CLIBD_ATTN_BWD", mode)
+            hm.tower().stack.set_numerics(attn_bwd=mode)
             y = hm(x.to(dev))
             if mode == "2phase":
                 cot = torch.randn(y.shape, generator=g)
             res[mode] = (y.detach().cpu(), grads_named(hm, (y * cot.to(dev)).sum()))
-        monkeypatch.delenv("CLIBD_ATTN_BWD")
+        hm.tower().stack.set_numerics(attn_bwd="2phase")
         assert torch.equal(res["sp"][0], res["2phase"][0])
         assert_grads(res["sp"][1], res["2phase"][1], rel_tol=2e-2, cos_tol=0.9995, what="sp vs two-phase")
         with O.precision("bf16"):
@@ -924,7 +971,7 @@ def test_single_pass_attention_backward_in_the_towers(dev, monkeypatch):
 
 
 def test_gelu_grad_kept_as_one_byte_in_the_towers(dev, monkeypatch):
-    """CLIBD_GELU_GRAD=u8 (opt-in): the fc1 epilogue keeps gelu' as one byte per element and the fc2 dgrad decodes it (engine.gelu_grad_u8).
+    """numerics gelu_grad="u8" (opt-in; CLIBD_GELU_GRAD=u8 as the construction default): the fc1 epilogue keeps gelu' as one byte per element and the fc2 dgrad decodes it.
     Forward untouched (embeddings bit for bit), gradients equal to the default path's within the stated quantisation budget and still
     within the oracle gates, both tower kinds; the full fine-tune walk uses the same two epilogues."""
     from oracle import clibd_oracle as O
@@ -936,12 +983,12 @@ def test_gelu_grad_kept_as_one_byte_in_the_towers(dev, monkeypatch):
         g = torch.Generator().manual_seed(5)
         res = {}
         for mode in ("bf16", "u8"):
-            monkeypatch.setenv("CLIBD_GELU_GRAD", mode)
+            hm.tower().stack.set_numerics(gelu_grad=mode)
             y = hm(x.to(dev))
             if mode == "bf16":
                 cot = torch.randn(y.shape, generator=g)
             res[mode] = (y.detach().cpu(), grads_named(hm, (y * cot.to(dev)).sum()))
-        monkeypatch.delenv("CLIBD_GELU_GRAD")
+        hm.tower().stack.set_numerics(gelu_grad="bf16")
         assert torch.equal(res["u8"][0], res["bf16"][0])
         assert any(not torch.equal(res["u8"][1][n], res["bf16"][1][n]) for n in res["bf16"][1]), "the knob did not reach the kernels"
         assert_grads(res["u8"][1], res["bf16"][1], rel_tol=2e-2, cos_tol=0.9995, what="u8 vs bf16 gelu'")

@@ -599,6 +599,37 @@ def test_adamw_matches_torch(ops, dev):
     assert (p.cpu() - pt.detach()).abs().max().item() < 2e-6
 
 
+def test_fused_adamw_under_one_cycle_lr_on_the_gpu(ops, dev):
+    """`clibd_amd.optim.FusedAdamW` (flat bucket + clibd_adamw_step) driven by the reference's OneCycleLR configuration
+    (scripts/train_cl.py:222-236: max_lr scaled by the batch, pct_start 0.3, cos, cycle_momentum=False) for ten steps equals
+    torch.optim.AdamW under the same scheduler on the CPU."""
+    from torch.optim import lr_scheduler
+
+    from clibd_amd.optim import FusedAdamW
+
+    g = torch.Generator().manual_seed(41)
+    shapes = [(4, 768), (768, 4), (768, 768), (768,), ()]
+    init = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    mine = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    lr = 1e-3 * 2048 / 500
+    fo, ro = FusedAdamW(mine, lr=lr), torch.optim.AdamW(ref, lr=lr)
+    mk = lambda o: lr_scheduler.OneCycleLR(o, max_lr=4 * lr, total_steps=10, pct_start=0.3, anneal_strategy="cos", cycle_momentum=False)
+    fs, rs = mk(fo), mk(ro)
+    for _ in range(10):
+        fo.zero_grad()
+        ro.zero_grad()
+        for a, b in zip(mine, ref):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad.copy_(gr.to(dev))
+            b.grad = gr.clone()
+        fo.step(); ro.step(); fs.step(); rs.step()
+        assert fo.param_groups[0]["lr"] == ro.param_groups[0]["lr"]
+    torch.cuda.synchronize()
+    for a, b in zip(mine, ref):
+        assert (a.detach().cpu() - b.detach()).abs().max().item() < 5e-6
+
+
 # ----------------------------------------------------------------------------------------------- GEMM, 256x256 8-phase kernel
 @pytest.mark.parametrize("M,N,K", [(2048, 4096, 128), (2000, 4096, 256), (4096, 2048, 768), (1500, 6144, 3072), (50432, 768, 768), (2048, 4096, 1536), (3000, 2304, 64 * 7)])
 def test_gemm256_exact_integers(ops, dev, M, N, K):

@@ -1,4 +1,4 @@
-"""Gradient budget of the bf16 residual-gradient stream (clibd_amd.engine.residual_grad_bf16).
+"""Gradient budget of the bf16 residual-gradient stream (clibd_amd.engine.NUMERICS_CHOICES['residual_grad']).
 
 Full-size towers (ViT-B/16, BERT-base), batch 8, LoRA B matrices non-zero, one random cotangent on the tower output: the
 trainable gradients (adapters + head) of the HIP tower with the residual gradient carried in fp32 and in bf16, against the
@@ -62,7 +62,7 @@ def main():
         henc = henc.to(dev).eval()
         res = {}
         for mode in (mode_a, mode_b):
-            os.environ[knob] = mode
+            henc.tower().stack.set_numerics(**{knob.replace("CLIBD_", "").lower(): mode})   # CLIBD_RESIDUAL_GRAD -> residual_grad
             out = henc(inp.to(dev))
             res[mode] = grads(henc, out, cot.to(dev))
             torch.cuda.synchronize()
@@ -71,7 +71,6 @@ def main():
             compare(f"HIP, {knob}={mode}  vs oracle fp32", res[mode], ref32)
             compare(f"HIP, {knob}={mode}  vs oracle bf16", res[mode], ref16)
         compare(f"HIP {mode_b}  vs HIP {mode_a}", res[mode_b], res[mode_a])
-    os.environ.pop(knob, None)
 
 
 if __name__ == "__main__":
