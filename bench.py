@@ -56,7 +56,9 @@ def parse():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-batch (PCIe-inclusive) side measurement")
     ap.add_argument("--no-gemm-timing", action="store_true")
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
-    ap.add_argument("--fp8-forward", action="store_true", help="BASELINE configs[4]: forward GEMMs on the fp8 MFMA (not the headline config)")
+    ap.add_argument("--fp8-forward", nargs="?", const="pooled", default=None, choices=["pooled", "all"],
+                    help="BASELINE configs[4] (not the headline config): forward GEMMs on the fp8 MFMA.  'pooled' (default) = the towers whose head "
+                         "averages its tokens (BarcodeBERT, BERT-small): gradient-faithful; 'all' adds the ViT: embedding-grade")
     ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
     ap.add_argument("--eval", action="store_true", help="eval path (SURVEY §8f-2, not the headline metric): no-grad embedding forward + K10 top-k search")
     ap.add_argument("--eval-queries", type=int, default=1024, help="--eval: queries per top-k launch")
@@ -487,7 +489,7 @@ def main():
     trainer = Trainer(model, lr=scale_learning_rate(1e-3, b, world_size=world), world_size=world, rank=rank, all_gather=True)
     batch = synthetic_batch(b, dev, seed=42, rank=rank, with_text=args.tri_modal)
     if args.fp8_forward:   # per-layer activation scales from one bf16 forward over the batch (outside the timed region)
-        model.enable_fp8_forward(calibration_inputs=(batch["image"], batch["dna"], batch["text"]))
+        model.enable_fp8_forward(calibration_inputs=(batch["image"], batch["dna"], batch["text"]), towers=args.fp8_forward)
 
     timer = GemmTimer()
     if not args.no_gemm_timing:
@@ -511,8 +513,12 @@ def main():
     if sampler is not None:
         sampler.start()
     t0 = time.perf_counter()   # the timed region carries NO per-launch event records (they cost ~1.3 ms per step of host+GPU time)
+    host_wall, host_cpu = [], []   # per step: wall and CPU time this thread spent ENQUEUEING it (two clock reads per step, no sync)
     for _ in range(args.steps):
+        hw, hc = time.perf_counter(), time.thread_time()
         loss = one_step()
+        host_wall.append(time.perf_counter() - hw)
+        host_cpu.append(time.thread_time() - hc)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -651,13 +657,21 @@ def main():
             "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights)",
             "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune and not args.fp8_forward else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
                                    ("FULL fine-tune (disable_lora)" if args.full_finetune else "LoRA r=4") +
-                                   (", bf16 MFMA" if not args.fp8_forward else ", fp8-forward mode (BASELINE configs[4]): forward GEMMs on the fp8 MFMA, backward bf16") +
+                                   (", bf16 MFMA" if not args.fp8_forward else f", fp8-forward mode (BASELINE configs[4], towers={args.fp8_forward}): forward GEMMs of " + ("the mean-pooled towers (BarcodeBERT)" if args.fp8_forward == "pooled" else "every tower") + " on the fp8 MFMA, backward bf16") +
                                    (" + BERT-small text tower" if args.tri_modal else ""),
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}", "image": "3x224x224", "dna_tokens": 133,
                        "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW",
                        "numerics": model.numerics(), "train_mode": bool(model.training)},
             "loss": loss_val, "roofline": roof,
         }
+        hw_ms, hc_ms = sorted(1e3 * t for t in host_wall), sorted(1e3 * t for t in host_cpu)
+        pick = lambda v, q: v[min(len(v) - 1, int(q * len(v)))]
+        out["host_enqueue_ms"] = {
+            "mean": sum(hw_ms) / len(hw_ms), "median": pick(hw_ms, 0.5), "p95": pick(hw_ms, 0.95),
+            "cpu_mean": sum(hc_ms) / len(hc_ms), "cpu_median": pick(hc_ms, 0.5),
+            "note": "rank 0, per timed step: wall time of Trainer.step() returning (no sync) and the CPU time this thread spent in it.  "
+                    "wall > cpu means the host was BLOCKED (the HIP queue's back-pressure once it is a few steps ahead), not busy: the "
+                    "host cost of a step is the cpu figure; it is on the critical path only if it exceeds ms_per_step"}
         if shared_gpu:
             out["invalid"] = "CLIBD_BENCH_SHARED_GPU: ranks shared a GPU over gloo (code-path check, not a measurement)"
         if forced:

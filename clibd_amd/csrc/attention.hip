@@ -15,6 +15,7 @@
 #include "common.h"
 #include "../../include/clibd_hip.h"
 #include "host_util.h"
+#include <stdlib.h>
 
 namespace clibd {
 
@@ -135,8 +136,11 @@ __device__ long long* g_att_stamps = nullptr;   // [workgroup][8]
 // select code — emitted for every (key tile, register) pair when the test is a run-time pointer check — cost the unmasked
 // towers ~400 SGPR-spill v_readlane/v_writelane and ~450 exec-mask scalar ops per query tile (ISA of the round-1 kernel).
 // DROP: dropout on the probabilities (HF BERT train mode); compile-time for the same reason (its counter hash is ~7 VALU per score).
-template <int NKT, bool PAIR, bool MASK, bool DROP>  // NKT: number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32); PAIR: two query tiles per sweep
-__global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int S,
+// NW: waves per workgroup (4; 3 for nine query tiles — S in (128, 144], the DNA tower — where four waves would take 3 + 2 + 2 + 2 tiles
+// one by one or, two at a time, 2 + 1 + 1 + 1 pairs of which the last is half padding: three waves take 3 + 3 + 3 single tiles, capped at
+// three waves per SIMD so that four such workgroups share a CU).
+template <int NKT, bool PAIR, bool MASK, bool DROP, int NW = ATT_WAVES>  // NKT: number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32); PAIR: two query tiles per sweep
+__global__ __launch_bounds__(64 * NW, (NW == 3 ? 3 : 2)) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ out, float scale,
                                                                     int nq, int out_seq, unsigned drop_seed,
@@ -168,15 +172,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (size_t)qc0 * ld + 32 * ks + 8 * g);
     }
-    stage_head_tile(kt_lds, qbase + H, ld, S, S_pad, wave, lane);
-    stage_head_tile(vt_lds, qbase + 2 * H, ld, S, S_pad, wave, lane);
+    stage_head_tile(kt_lds, qbase + H, ld, S, S_pad, wave, lane, NW);
+    stage_head_tile(vt_lds, qbase + 2 * H, ld, S, S_pad, wave, lane, NW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     if constexpr (PAIR) {
         // Two query tiles per wave and sweep: every K row fragment and every transposed V fragment read from LDS feeds two
         // MFMAs (the one-tile sweep moves 1 KiB of LDS per MFMA and is bound by it).  Arithmetic per element is unchanged.
-        for (int p = wave; p < ((nqt + 1) >> 1); p += ATT_WAVES) {
+        for (int p = wave; p < ((nqt + 1) >> 1); p += NW) {
             bf16x8 qf2[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
         }
         return;
     }
-    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
+    for (int qt = wave; qt < nqt; qt += NW) {
         const int q = qt * 16 + i;
         f32x4 sc[NKT];
 #pragma unroll
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_fwd_kernel(const uns
                 sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(kt_lds, kt * 16 + i, ks, g), qf[ks], sc[kt], 0, 0, 0);
         }
         {   // prefetch the next tile's Q fragment (clamped; unused after the last tile)
-            const int qn = min((qt + ATT_WAVES) * 16 + i, S - 1);
+            const int qn = min((qt + NW) * 16 + i, S - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (size_t)qn * ld + 32 * ks + 8 * g);
         }
@@ -532,8 +536,14 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
 // ============================================ backward =========================================================
 // PAIR: phase 2 sweeps two key tiles per wave (long sequences: halves the LDS traffic per MFMA; costs ~60 VGPRs, so the
 // short-sequence instantiations, which fit three waves per SIMD without it, keep the one-tile sweep)
-template <int NKT, bool PAIR, bool MASK, bool DROP>
-__global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
+// NW: waves per workgroup.  4 everywhere except S in (128, 144] (the DNA tower's 133 tokens = 9 tiles of 16): four waves take
+// 3 + 2 + 2 + 2 of the nine query tiles in phase 1 and of the nine key tiles in phase 2, so the workgroup lives for 6 tile sweeps while
+// its average wave has 4.5 to do; THREE waves take 3 + 3 + 3.  The register cap stays at three waves per SIMD, i.e. FOUR such
+// workgroups per CU, and for four of them to fit the LDS each image is 144 rows instead of S_pad = 160 (IMG): rows 144 .. 159 of the
+// first image then alias rows 0 .. 15 of the second, those of the second a zeroed 2-KiB pad.  Every such row is only ever multiplied
+// by an exact zero (key tile 9 / query tile 9 are skipped: `last_live` is false, `nqt` = 9), so finite bytes are all that is needed.
+template <int NKT, bool PAIR, bool MASK, bool DROP, int NW = ATT_WAVES, int IMG = 16 * NKT>
+__global__ __launch_bounds__(64 * NW, (NKT <= 10 ? 3 : 2)) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                                     const unsigned short* __restrict__ dout, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ dqkv, float scale,
@@ -541,11 +551,13 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
                                                                     int drop_thr16, float drop_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
+    static_assert(IMG == S_pad || (IMG == S_pad - 16 && !PAIR), "a short image drops exactly the all-padding last tile, one-tile phase 2 only");
+    constexpr int PADB = (IMG < S_pad) ? (S_pad - IMG) * 128 : 0;   // zeroed rows IMG .. S_pad-1 of the second image
     char* t0 = smem;                      // phase 1: K   | phase 2: Q
-    char* t1 = smem + S_pad * 128;        // phase 1: V   | phase 2: dO
+    char* t1 = smem + IMG * 128;          // phase 1: V   | phase 2: dO
     // per query row: m' = c2 * max + log2(row sum), so P = exp2(c2 * s - m') is the normalised probability with one FMA and one
     // v_exp; rows that carry no gradient (q >= nq) hold m' = +BIG, i.e. P = 0 exactly, and need no per-element test in phase 2
-    float* st_m = (float*)(smem + 2 * S_pad * 128);
+    float* st_m = (float*)(smem + 2 * IMG * 128 + PADB);
     float* st_d = st_m + S_pad;                       // delta = sum_k P dP
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -568,9 +580,12 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
         }
     }
     ATT_STAMP(0);
-    stage_head_tile(t0, qbase + H, ld, S, S_pad, wave, lane);
-    stage_head_tile(t1, qbase + 2 * H, ld, S, S_pad, wave, lane);
-    for (int r = threadIdx.x; r < S_pad; r += ATT_THREADS) { st_m[r] = -NEG_BIG; st_d[r] = 0.f; }
+    stage_head_tile(t0, qbase + H, ld, S, IMG, wave, lane, NW);
+    stage_head_tile(t1, qbase + 2 * H, ld, S, IMG, wave, lane, NW);
+    for (int r = threadIdx.x; r < S_pad; r += 64 * NW) { st_m[r] = -NEG_BIG; st_d[r] = 0.f; }
+    if constexpr (PADB > 0) {
+        for (int r = threadIdx.x; r < PADB / 16; r += 64 * NW) *(uint4*)(t1 + IMG * 128 + 16 * r) = make_uint4(0u, 0u, 0u, 0u);
+    }
     const bool last_live = S > 16 * (NKT - 1);  // S <= 16 (NKT - 1): the last key tile is all padding and is skipped (see forward)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -579,7 +594,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
     // ---------------- phase 1: per 16-query tile: softmax statistics, dS, dQ ----------------
     const int nqt = (nq + 15) >> 4;      // query tiles that carry a gradient (rows >= nq have dO = 0)
     const int nqt_all = (S + 15) >> 4;
-    for (int qt = nqt + wave; qt < nqt_all; qt += ATT_WAVES) {  // dQ of the inactive query rows is exactly zero
+    for (int qt = nqt + wave; qt < nqt_all; qt += NW) {  // dQ of the inactive query rows is exactly zero
         const int q = qt * 16 + i;
         if (q < S) {
             unsigned short* orow = dqbase + (size_t)q * ld;
@@ -587,7 +602,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
             for (int dt = 0; dt < 4; ++dt) *(uint2*)(orow + 16 * dt + 4 * g) = make_uint2(0u, 0u);
         }
     }
-    for (int qt = wave; qt < nqt; qt += ATT_WAVES) {
+    for (int qt = wave; qt < nqt; qt += NW) {
         const int q = qt * 16 + i;
         if (q >= nq) {  // rows of an active tile beyond nq: their dO is zero
 #pragma unroll
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
             }
         }
         {   // prefetch the next tile's Q / dO fragments
-            const int qn = min((qt + ATT_WAVES) * 16 + i, S - 1);
+            const int qn = min((qt + NW) * 16 + i, S - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 qf[ks] = *(const bf16x8*)(qbase + (size_t)qn * ld + 32 * ks + 8 * g);
@@ -687,6 +702,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
     ATT_STAMP(3);
 
     if constexpr (PAIR) {
+    static_assert(!PAIR || NW == ATT_WAVES, "the two-key-tile phase 2 deals pairs to four waves");
     // ---------------- phase 2: dV, dK — TWO 16-key tiles per wave (query on the MFMA row, key on the lane) ----------------
     // Every Q / dO fragment read from LDS (row form for S and dP, transposed form for dK and dV) feeds two MFMAs, one per
     // key tile: half the LDS traffic per MFMA of a one-tile sweep (this phase was LDS-bandwidth bound: 1 KiB per MFMA).
@@ -828,18 +844,18 @@ __global__ __launch_bounds__(ATT_THREADS, (NKT <= 10 ? 3 : 2)) void attention_bw
             vf[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kc0 * ld + 32 * ks + 8 * g);
         }
     }
-    stage_head_tile(t0, qbase, ld, S, S_pad, wave, lane);
-    stage_head_tile(t1, dobase, (size_t)H, nq, S_pad, wave, lane);  // rows >= nq are clamped copies, masked below
+    stage_head_tile(t0, qbase, ld, S, IMG, wave, lane, NW);
+    stage_head_tile(t1, dobase, (size_t)H, nq, IMG, wave, lane, NW);  // rows >= nq are clamped copies, masked below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nkt = (S + 15) >> 4;
-    for (int kt = wave; kt < nkt; kt += ATT_WAVES) {
+    for (int kt = wave; kt < nkt; kt += NW) {
         const int key = kt * 16 + i;
         bool key_ok = key < S;
         if (MASK) key_ok = key_ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
         {   // next key tile's K / V fragments fly during this tile's sweep over the queries
-            const int kn = min((kt + ATT_WAVES) * 16 + i, S - 1);
+            const int kn = min((kt + NW) * 16 + i, S - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 kfn[ks] = *(const bf16x8*)(qbase + H + (size_t)kn * ld + 32 * ks + 8 * g);
@@ -1181,6 +1197,7 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
     // many heads of a long sequence: the persistent kernel (K / V of the next head land under the current head's arithmetic)
     const int total = B * nheads;
     const size_t ldsp = (size_t)2 * lds;
+    static const bool three_waves = [] { const char* e = getenv("CLIBD_ATTN_FWD_WAVES"); return !(e && e[0] == '4'); }();
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
         if (N >= 12 && total >= 2 * num_cus) {   /* S > 160: at S = 133 only 9 of the 16 waves have a tile and the per-head kernel wins */ \
@@ -1188,6 +1205,11 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
             hipFuncSetAttribute((const void*)attention_fwd_persistent_kernel<NP, MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
             hipLaunchKernelGGL((attention_fwd_persistent_kernel<NP, MSK, DRP>), dim3(num_cus), dim3(64 * ATTP_WAVES), ldsp, st, \
                                (const unsigned short*)qkv, S, nheads, total, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
+                               drop_seed, drop_thr16, drop_scale, out_fp8_scale, lse, (unsigned short*)o_lo);      \
+        } else if (N == 10 && S <= 144 && S > 128 && nq > 128 && three_waves) {   /* nine query tiles: 3 + 3 + 3 on three waves */ \
+            hipFuncSetAttribute((const void*)attention_fwd_kernel<10, false, MSK, DRP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((attention_fwd_kernel<10, false, MSK, DRP, 3>), dim3(B * nheads), dim3(192), lds, st,   \
+                               (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
                                drop_seed, drop_thr16, drop_scale, out_fp8_scale, lse, (unsigned short*)o_lo);      \
         } else {                                                                                                  \
         hipFuncSetAttribute((const void*)attention_fwd_kernel<N, (N >= 10), MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -1281,6 +1303,23 @@ extern "C" int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B
     const size_t lds = (size_t)2 * nkt * 16 * 128 + (size_t)2 * nkt * 16 * sizeof(float);
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
+    // S in (128, 144] — the DNA tower's 133 tokens: nine tiles on THREE waves per workgroup, four workgroups per CU (see the kernel)
+    static const bool three_waves = [] { const char* e = getenv("CLIBD_ATTN_BWD_WAVES"); return !(e && e[0] == '4'); }();
+    if (nkt == 10 && S <= 144 && key_mask == nullptr && three_waves) {
+        constexpr int IMG3 = 144;
+        const size_t lds3 = (size_t)2 * IMG3 * 128 + 16 * 128 + (size_t)2 * 160 * sizeof(float);
+#define LAUNCH_3(DRP)                                                                                             \
+    do {                                                                                                          \
+        hipFuncSetAttribute((const void*)attention_bwd_kernel<10, false, false, DRP, 3, IMG3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
+        hipLaunchKernelGGL((attention_bwd_kernel<10, false, false, DRP, 3, IMG3>), dim3(B * nheads), dim3(192), lds3, st, \
+                           (const unsigned short*)qkv, (const unsigned short*)dout, S, nheads, (const int*)nullptr,   \
+                           (unsigned short*)dqkv, scale, nq, dout_seq, drop_seed, drop_thr16, drop_scale);        \
+    } while (0)
+        if (drop_thr16 > 0) LAUNCH_3(true);
+        else LAUNCH_3(false);
+#undef LAUNCH_3
+        return check_launch("attention_bwd");
+    }
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
         hipFuncSetAttribute((const void*)attention_bwd_kernel<N, (N >= 12), MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

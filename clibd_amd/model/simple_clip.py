@@ -109,22 +109,41 @@ class SimpleCLIP(nn.Module):
         dna_output, image_output, language_output = outs
         return image_output, dna_output, language_output, self.logit_scale.exp(), self.logit_bias
 
-    def enable_fp8_forward(self, scales: Optional[dict] = None, enabled: bool = True, calibration_inputs=None, margin: float = 2.0):
-        """fp8-forward mode (BASELINE.json configs[4]; not in the reference, which trains under bf16 autocast): the towers'
+    # fp8-forward mode: which towers take it.  "pooled" (default) = the towers whose head AVERAGES its tokens — BarcodeBERT's
+    # softmax-mean over 133 tokens (dna_encoder.py:131-137), BERT-small's mean over 20 positions (language_encoder.py:89): the e4m3
+    # operand noise of a token row (~4 % per GEMM output) averages out in the embedding (measured 6-8e-3 on unit-norm rows) and the
+    # contrastive gradient stays that of the bf16 step (cosine 0.990-0.9999 on trained weights).  The ViT reads ONE row, the class
+    # token, whose embedding moves by 4-5e-2 under e4m3 — x14.3 in the logits — whatever the scale granularity (per tensor, per row,
+    # MXFP8 per 32) and whichever rows / blocks are kept in bf16 (tools/fp8_policy_study.py, profiles/r04_exp_fp8_policy_study.log):
+    # "all" adds it for an embedding-grade mode that is 6 % faster still and not gradient-faithful.
+    FP8_TOWER_SETS = {"pooled": ("dna_encoder", "language_encoder"), "all": ("image_encoder", "dna_encoder", "language_encoder")}
+
+    def enable_fp8_forward(self, scales: Optional[dict] = None, enabled: bool = True, calibration_inputs=None, margin: float = 2.0,
+                           towers=None):
+        """fp8-forward mode (BASELINE.json configs[4]; not in the reference, which trains under bf16 autocast): the selected towers'
         forward GEMMs run on the fp8 MFMA, see TransformerStack.enable_fp8.  Needs frozen base weights (LoRA mode).
+        towers: "pooled" (default: the mean-pooled towers, training-grade), "all" (adds the ViT: embedding-grade), or an iterable of
+        encoder attribute names; None keeps the previous selection (what Trainer's periodic re-calibration passes).
         calibration_inputs = (image_input, dna_input, language_input): one bf16 no-grad forward over that batch measures
         max |activation| per layer and site and sets the per-layer power-of-two scales with `margin` headroom; without it
         the static FP8_SCALES are used."""
-        stacks = [enc.tower().stack for enc in (self.image_encoder, self.dna_encoder, self.language_encoder)
-                  if enc is not None and hasattr(enc, "tower")]
+        if towers is None:
+            towers = self.__dict__.get("_fp8_towers", "pooled")
+        names = self.FP8_TOWER_SETS[towers] if isinstance(towers, str) else tuple(towers)
+        for n in names:
+            if n not in self.FP8_TOWER_SETS["all"]:
+                raise ValueError(f"enable_fp8_forward: unknown tower {n!r}")
+        self.__dict__["_fp8_towers"] = towers if isinstance(towers, str) else names
+        every = [getattr(self, n).tower().stack for n in self.FP8_TOWER_SETS["all"]
+                 if getattr(self, n) is not None and hasattr(getattr(self, n), "tower")]
+        stacks = [getattr(self, n).tower().stack for n in names if getattr(self, n) is not None and hasattr(getattr(self, n), "tower")]
+        for st in every:
+            st.disable_fp8()
         if not enabled:
-            for st in stacks:
-                st.disable_fp8()
             return self
         amax = [None] * len(stacks)
         if calibration_inputs is not None:
             for st in stacks:
-                st.disable_fp8()
                 st.calibrate(True)
             with torch.no_grad():
                 self(*calibration_inputs)

@@ -140,7 +140,7 @@ def test_full_size_fp8_forward_close_to_bf16_path(dev):
         return hi.detach().float().cpu(), hd.detach().float().cpu(), float(loss.detach()), gd
 
     i16, d16, l16, g16 = run()
-    model.enable_fp8_forward()
+    model.enable_fp8_forward(towers="all")     # the embedding-grade form: every tower, the ViT included
     i8, d8, l8, g8 = run()
     model.enable_fp8_forward(enabled=False)
     i16b, d16b, l16b, _ = run()
@@ -178,7 +178,7 @@ def test_fp8_calibration_sets_per_layer_scales(dev):
 
     cosr = lambda a, b: ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).min().item()
     i16, d16 = emb()
-    model.enable_fp8_forward(calibration_inputs=cal)
+    model.enable_fp8_forward(calibration_inputs=cal, towers="all")
     i_cal, d_cal = emb()
     st = model.image_encoder.tower().stack
     assert len(st.fp8) == 12 and all(set(d) == set(st.FP8_SITES) for d in st.fp8)
@@ -191,9 +191,9 @@ def test_fp8_calibration_sets_per_layer_scales(dev):
     with torch.no_grad():
         model.image_encoder.base_image_encoder.blocks[3].norm1.weight.mul_(96.0)
     i16, _ = emb()
-    model.enable_fp8_forward()
+    model.enable_fp8_forward(towers="all")
     i_static, _ = emb()
-    model.enable_fp8_forward(calibration_inputs=cal)
+    model.enable_fp8_forward(calibration_inputs=cal)      # towers=None keeps the selection
     i_cal, _ = emb()
     assert st.fp8[3]["qkv_in"] * 16 <= scale2                                      # the hot layer got a much smaller scale
     assert (i_cal - i16).abs().max() < (i_static - i16).abs().max()               # saturation hurts the static scales
@@ -226,6 +226,7 @@ def test_fp8_training_steps_reduce_loss(dev):
     assert all(l == l and l < 1e4 for l in losses) and losses[-1] < losses[0]
     st = model.dna_encoder.tower().stack
     assert st.fp8 is not None and len(st.fp8) == 12 and all(v > 0 for d in st.fp8 for v in d.values())
+    assert model.image_encoder.tower().stack.fp8 is None     # default selection: the mean-pooled towers only (training-grade)
 
 
 # ----------------------------------------------------------------------------------------------- round 3: the mode against ITS oracle
@@ -255,8 +256,11 @@ def _hand_scales_to_oracle(model, om):
     """The oracle quantises with the scales the HIP towers hold (TransformerStack.fp8: [{site: scale}] per layer)."""
     from oracle import clibd_oracle as O
 
-    O.set_fp8_scales(om.image_encoder.base_image_encoder.blocks, model.image_encoder.tower().stack.fp8, last_block_qkv_only=True)
-    O.set_fp8_scales(om.dna_encoder.base_dna_encoder.bert.encoder.layer, model.dna_encoder.tower().stack.fp8)
+    blocks, layers = om.image_encoder.base_image_encoder.blocks, om.dna_encoder.base_dna_encoder.bert.encoder.layer
+    f_img, f_dna = model.image_encoder.tower().stack.fp8, model.dna_encoder.tower().stack.fp8
+    # a tower outside the selection evaluates in the oracle's bf16 arithmetic: no site carries a scale
+    O.set_fp8_scales(blocks, f_img if f_img is not None else [{} for _ in blocks], last_block_qkv_only=f_img is not None)
+    O.set_fp8_scales(layers, f_dna if f_dna is not None else [{} for _ in layers])
 
 
 def _named_grads(module, loss):
@@ -265,8 +269,8 @@ def _named_grads(module, loss):
     return {n: (torch.zeros_like(p) if g is None else g).detach().float().cpu() for (n, p), g in zip(ps.items(), gs)}
 
 
-@pytest.mark.parametrize("calibrated", [False, True])
-def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated):
+@pytest.mark.parametrize("calibrated,towers", [(False, "all"), (True, "all"), (True, "pooled")])
+def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated, towers):
     """configs[4]'s mode against a CPU statement of the SAME arithmetic (oracle precision("fp8"): e4m3 operands with the towers'
     scales, fp32 accumulation, bf16 backward), ViT-B/16 + BERT-base at batch 16 — no longer HIP against HIP.
     What separates the two sides is summation order and the places where a last-bit difference of a producer lands on the
@@ -276,7 +280,10 @@ def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated):
     the same weights, i.e. the quantisation error itself is reproduced to a third; loss 1.8e-3 with the static scales, 1.0e-4
     with calibrated ones; gradient cosine 0.88-0.89 over all trainable tensors, 0.92-0.94 on the DNA adapters: two correct
     implementations of this mode do not agree better than that on the gradient, which is why DESIGN.md §3.1b calls the mode
-    embedding-grade, not gradient-faithful.  Gates: embeddings 1e-2, loss 3e-3, cosines 0.8 / 0.85."""
+    embedding-grade, not gradient-faithful.  Gates: embeddings 1e-2, loss 3e-3, cosines 0.8 / 0.85.
+    Round 4, towers="pooled" (the default selection: fp8 only where the head averages its tokens, the ViT in bf16): the image side is
+    the bf16 path, the DNA side's quantisation noise is averaged by its head, and HIP and oracle agree on the gradient like two bf16
+    implementations do: gate cosine >= 0.97 over all trainable tensors."""
     from oracle import clibd_oracle as O
     from clibd_amd.data import synthetic_batch
     from clibd_amd.model import ClipLoss
@@ -286,10 +293,10 @@ def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated):
     batch = synthetic_batch(B, torch.device("cpu"), seed=5, rank=0, with_text=False)
     labels = torch.arange(B) % 11
     img, dna = batch["image"].to(dev), batch["dna"].to(dev)
-    model.enable_fp8_forward(calibration_inputs=(img, dna, None) if calibrated else None)
+    model.enable_fp8_forward(calibration_inputs=(img, dna, None) if calibrated else None, towers=towers)
     _hand_scales_to_oracle(model, om)
     if calibrated:   # per-layer powers of two, not all equal to the static defaults
-        sc = model.image_encoder.tower().stack.fp8
+        sc = (model.image_encoder if towers == "all" else model.dna_encoder).tower().stack.fp8
         assert any(d != sc[0] for d in sc[1:]) or sc[0] != dict(model.image_encoder.tower().stack.FP8_SCALES)
     with O.precision("fp8"):
         oi, od, _, osc, _ = om(batch["image"], batch["dna"], None)
@@ -311,26 +318,31 @@ def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated):
     dna_ad = [n for n in names if n.startswith("dna") and (".w_a." in n or ".w_b." in n)]
     c_all = _cosv(allg, allo)
     c_dna = _cosv(torch.cat([got[n].flatten() for n in dna_ad]), torch.cat([go[n].flatten() for n in dna_ad]))
-    print(f"[fp8 vs fp8 oracle, calibrated={calibrated}] emb err image {errs[0]:.2e} dna {errs[1]:.2e} loss {dl:.2e} grad cos all {c_all:.4f} dna adapters {c_dna:.4f}")
+    print(f"[fp8 vs fp8 oracle, calibrated={calibrated}, towers={towers}] emb err image {errs[0]:.2e} dna {errs[1]:.2e} loss {dl:.2e} grad cos all {c_all:.4f} dna adapters {c_dna:.4f}")
     assert errs[0] < 1e-2 and errs[1] < 3e-3, errs
     assert dl < 3e-3, dl
-    assert c_all > 0.8 and c_dna > 0.85, (c_all, c_dna)
+    assert c_all > (0.97 if towers == "pooled" else 0.8) and c_dna > 0.85, (c_all, c_dna)
+    if towers == "pooled":
+        assert errs[0] < 1e-3 and errs[1] < 3e-3, errs      # the image side IS the bf16 path
 
 
 def test_fp8_gradients_on_spread_embeddings(dev):
-    """VERDICT r2 asked whether the fp8-forward gradient is better aligned with the bf16 path's once the embeddings are spread
-    (at random init the rows of a tower's output are nearly parallel, cosine(fp8, bf16) = 0.81).  It is not.  Measured on
-    MI355X in round 3 — adapters and heads trained in bf16 on a fixed batch of 32 pairs, fp8 scales calibrated on the batch
-    under test, gradients of all trainable tensors:
+    """Is the fp8-forward gradient the bf16 step's gradient once the embeddings are spread?  Adapters and heads are trained in bf16
+    on a fixed batch of 32 pairs (8, then 40 steps), fp8 scales calibrated on the batch under test, cosine over ALL trainable tensors.
+
+    towers="all" (every tower, round 3's mode) — it is not: measured on MI355X in round 3
         after  8 steps (loss 3.47 -> 3.20, mean mutual cosine of the image embeddings 0.90): cosine(fp8, bf16) 0.92 on the
                        training batch, 0.70 on a fresh batch; max |embedding difference| 0.08;
         after 40 steps (loss 0.03, mutual cosine 0.18): 0.45 / 0.61; max |embedding difference| 0.10 - 0.13.
-    The fp8 forward perturbs the unit-norm embeddings of trained towers by ~0.1 (5e-3 at random init: trained adapters raise
-    the dynamic range of the residual stream); the temperature (x14.3) turns that into O(1) noise on the logits, and the
-    gradient p - t of a batch the model already fits is smaller than that noise.  The mode is therefore embedding-grade at
-    initialisation only, and as a training mode a noisy-gradient accelerator (+11 % step rate; the loss still falls:
-    test_fp8_training_steps_reduce_loss), never the headline.  This test records the numbers and holds the
-    floor they set: direction still positive, embeddings within 0.3."""
+    The fp8 forward moves the unit-norm IMAGE embedding of a trained tower by ~0.05-0.1 and the temperature (x14.3) turns that into
+    O(1) logit noise.  Round 4 asked the oracle why (tools/fp8_policy_study.py, profiles/r04_exp_fp8_policy_study.log): it is the
+    3-bit mantissa on a tower whose embedding is ONE token row — per-32-element E8M0 block scales (MXFP8), bf16 class-token rows,
+    bf16 last blocks, activation-only and weight-only quantisation all leave the image embedding 3.5-5e-2 away — while the DNA
+    tower, whose head averages 133 token rows, moves by 6-8e-3.
+
+    towers="pooled" (round 4, the default): fp8 only on the towers whose head averages its tokens, the ViT in bf16.  The oracle
+    predicts cosine 0.9999 on the training batch and 0.990 on a fresh one after 8 steps; the gate VERDICT r3 item 1 set — cosine
+    >= 0.98 against the bf16 gradient on trained weights — is what this test now holds, at both stages, on both batches."""
     from clibd_amd.data import synthetic_batch
     from clibd_amd.model import ClipLoss
     from clibd_amd.train import Trainer
@@ -348,20 +360,21 @@ def test_fp8_gradients_on_spread_embeddings(dev):
         g = _named_grads(model, loss)
         model.join_streams()
         torch.cuda.synchronize()
-        return hi.detach().float().cpu(), g
+        return hi.detach().float().cpu(), hd.detach().float().cpu(), g
 
     def compare(tag, out):
         for tw in (model.image_encoder.tower(), model.dna_encoder.tower()):
             tw.grad_sink = None     # plain autograd outputs for the comparison; the trainer's step() below re-installs its sink
         for name, bt in (("train", batch), ("fresh", fresh)):
             model.enable_fp8_forward(enabled=False)
-            e16, g16 = run(bt)
-            model.enable_fp8_forward(calibration_inputs=(bt["image"], bt["dna"], None))
-            e8, g8 = run(bt)
+            e16, d16, g16 = run(bt)
             names = sorted(g16)
             spread = float((e16 @ e16.T).fill_diagonal_(0).sum() / (B * (B - 1)))
-            out[(tag, name)] = (_cosv(torch.cat([g8[n].flatten() for n in names]), torch.cat([g16[n].flatten() for n in names])), spread,
-                                float((e8 - e16).abs().max()))
+            for towers in ("pooled", "all"):
+                model.enable_fp8_forward(calibration_inputs=(bt["image"], bt["dna"], None), towers=towers)
+                e8, d8, g8 = run(bt)
+                out[(tag, name, towers)] = (_cosv(torch.cat([g8[n].flatten() for n in names]), torch.cat([g16[n].flatten() for n in names])),
+                                            spread, float((e8 - e16).abs().max()), float((d8 - d16).abs().max()))
         model.enable_fp8_forward(enabled=False)
         sink = {id(p): p.grad for p in tr.optimizer.param_groups[0]["params"]}
         for tw in (model.image_encoder.tower(), model.dna_encoder.tower()):
@@ -371,11 +384,14 @@ def test_fp8_gradients_on_spread_embeddings(dev):
     for stage, nsteps in (("8 steps", 8), ("40 steps", 32)):
         losses += [float(tr.step(batch["image"], batch["dna"], None, batch["labels"])) for _ in range(nsteps)]
         compare(stage, out)
-    for k, (c, spread, de) in out.items():
-        print(f"[fp8 gradients on trained weights] after {k[0]}, {k[1]} batch: cosine(fp8, bf16) {c:.4f}; mean mutual cosine of image embeddings "
-              f"{spread:.3f}; max |embedding difference| {de:.2e}")
+    for k, (c, spread, de, dd) in out.items():
+        print(f"[fp8 gradients on trained weights] after {k[0]}, {k[1]} batch, towers={k[2]}: cosine(fp8, bf16) {c:.4f}; mean mutual cosine of "
+              f"image embeddings {spread:.3f}; max |embedding difference| image {de:.2e} dna {dd:.2e}")
     print(f"[fp8 gradients on trained weights] loss {losses[0]:.3f} -> {losses[7]:.3f} -> {losses[-1]:.3f}")
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
-    assert out[("40 steps", "train")][1] < 0.9                      # the embeddings did spread
-    for k, (c, _, de) in out.items():
-        assert c > 0.15 and de < 0.3, (k, c, de)                     # the floor the measurement sets
+    assert out[("40 steps", "train", "all")][1] < 0.9               # the embeddings did spread
+    for k, (c, _, de, dd) in out.items():
+        if k[2] == "pooled":
+            assert c >= 0.98 and de == 0.0 and dd < 2e-2, (k, c, de, dd)   # training-grade: VERDICT r3 item 1's gate
+        else:
+            assert c > 0.15 and de < 0.3, (k, c, de)                      # embedding-grade: the floor round 3's measurement set

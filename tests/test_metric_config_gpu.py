@@ -161,7 +161,7 @@ def test_b1024_rows_equal_chunked_and_block_loss_matches_cpu(dev, big, fp8):
     model, batch = big
     img, dna = batch["image"][:B5], batch["dna"][:B5]
     if fp8:
-        model.enable_fp8_forward(calibration_inputs=(img, dna, None))   # per-layer scales from this batch; fixed for every call below
+        model.enable_fp8_forward(calibration_inputs=(img, dna, None), towers="all")   # per-layer scales from this batch; fixed for every call below (both towers: every fp8 kernel at this size)
     try:
         with torch.no_grad():
             i_full, d_full, _, scale, _ = model(img, dna, None)

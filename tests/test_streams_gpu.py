@@ -174,7 +174,7 @@ def test_full_size_two_tower_step_is_bit_reproducible(dev):
     ri, rd, rg = step()
     for k in range(24):
         if k % 3 == 2:
-            model.enable_fp8_forward()
+            model.enable_fp8_forward(towers="all")
             step()
             model.enable_fp8_forward(enabled=False)
         i, d, g_ = step()

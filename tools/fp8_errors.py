@@ -34,7 +34,7 @@ def cos(a, b):
     return float(a @ b / (a.norm() * b.norm() + 1e-30))
 
 i16, d16, l16, g16 = run()
-model.enable_fp8_forward()
+model.enable_fp8_forward(towers="all")
 i8, d8, l8, g8 = run()
 print("loss", l16, l8)
 for nm, a, b in (("image", i8, i16), ("dna", d8, d16)):

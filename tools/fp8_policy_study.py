@@ -1,0 +1,169 @@
+"""CPU study (oracle only, no GPU): which fp8-forward POLICY keeps the contrastive gradient faithful to the bf16 path's?
+
+VERDICT r3 item 1 asks for cosine(fp8 gradient, bf16 gradient) >= 0.98 on trained weights (0.45-0.92 with the round-3 mode) and
+names the hardware's per-32-element E8M0 block scales (MXFP8) as the means.  Before a kernel is written, the oracle answers what
+each candidate buys on the full-size towers (ViT-B/16 + BERT-base, batch 16, adapters + heads trained for a few bf16 steps on the
+batch so that the embeddings are spread):
+
+  tensor    : round 3 — one power-of-two scale per layer and site for activations, one scale per weight row
+  mx32      : MXFP8 — e4m3 payload with an E8M0 (power-of-two) scale per 32 consecutive K elements, both operands
+  cls_bf16  : `tensor`, but the class-token row of every ViT block (the only row the image embedding reads) is recomputed on
+              bf16 operands in all four GEMMs (1/197 of the rows); BERT unchanged (its head averages 133 tokens)
+  mx32+cls  : both
+  lastK_bf16: `tensor` with the last K ViT blocks entirely bf16
+  dna_only  : the image tower entirely bf16, only the DNA tower (whose head averages its 133 tokens) on fp8 operands
+  act_only / w_only : diagnostics (no such MFMA exists): only the activations / only the weights quantised to e4m3
+
+Reports max |embedding - bf16 embedding| per tower, |loss difference| and the cosine of the full trainable gradient against the
+bf16 mode's, on the training batch and on a fresh batch.
+
+    python tools/fp8_policy_study.py [train_steps=8] [batch=16] > profiles/r04_exp_fp8_policy_study.log
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+from oracle import clibd_oracle as O
+
+torch.set_num_threads(8)
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+
+POLICY = dict(gran="tensor", cls_bf16=False, in_image=False, bf16_from_block=None, block_index=None, image_bf16=False)
+
+
+def e4m3(x):
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
+
+
+def mx_quant(x):
+    """MXFP8 along the last axis: per 32 elements a power-of-two scale 2^(floor(log2 amax) - 8) (e4m3's largest binade is 2^8),
+    payload e4m3(x / scale).  Returns the de-quantised values (what the block-scaled MFMA multiplies)."""
+    shp = x.shape
+    xb = x.reshape(-1, shp[-1] // 32, 32)
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax)))) - 8.0
+    s = torch.exp2(e)
+    return (e4m3(xb / s) * s).reshape(shp)
+
+
+class PolicyLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, sa):
+        ctx.save_for_backward(weight)
+        xf, wf = x.detach().float(), weight.detach().float()
+        rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        blk, frm = POLICY["block_index"], POLICY["bf16_from_block"]
+        if POLICY["in_image"] and POLICY["image_bf16"]:
+            return F.linear(rb(xf), rb(wf))
+        if POLICY["in_image"] and frm is not None and blk is not None and blk >= frm:
+            return F.linear(rb(xf), rb(wf))
+        if POLICY["gran"] == "act_only":       # diagnostic: e4m3 activations against bf16 weights (no such MFMA exists)
+            y = F.linear(e4m3(xf * sa), rb(wf)) * (1.0 / sa)
+        elif POLICY["gran"] == "w_only":       # diagnostic: bf16 activations against e4m3 weights
+            w8, sn = O.quantize_rows_e4m3(wf)
+            y = F.linear(rb(xf), w8) * (1.0 / sn).view(-1)
+        elif POLICY["gran"] == "mx32":
+            y = F.linear(mx_quant(xf), mx_quant(wf))
+        else:
+            w8, sn = O.quantize_rows_e4m3(wf)
+            y = F.linear(e4m3(xf * sa), w8) * (1.0 / (sn * sa)).view(-1)
+        if POLICY["cls_bf16"] and POLICY["in_image"] and xf.dim() == 3:
+            y = y.clone()
+            y[:, 0, :] = F.linear(rb(xf[:, 0, :]), rb(wf))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        return rb(dy) @ rb(weight.detach()), None, None
+
+
+O._Fp8Linear = PolicyLinear
+
+
+def build():
+    torch.manual_seed(11)
+    om = O.build_image_dna_model()
+    with torch.no_grad():
+        for n, p in om.named_parameters():
+            if "linear_b_" in n or ".w_b." in n:
+                p.normal_(0, 0.02)
+    # block index for the lastK policy
+    for i, blk in enumerate(om.image_encoder.base_image_encoder.blocks):
+        orig = blk.forward
+
+        def fwd(x, _orig=orig, _i=i):
+            POLICY["block_index"] = _i
+            try:
+                return _orig(x)
+            finally:
+                POLICY["block_index"] = None
+        blk.forward = fwd
+    return om
+
+
+def batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.rand(B, 3, 224, 224, generator=g)
+    dna = torch.cat([torch.zeros(B, 1, dtype=torch.long), torch.randint(3, 1027, (B, 132), generator=g)], dim=1)
+    return image, dna, torch.arange(B)
+
+
+def evaluate(om, image, dna, labels):
+    POLICY["in_image"] = True
+    img = F.normalize(om.image_encoder(image).float(), p=2, dim=-1)
+    POLICY["in_image"] = False
+    d = F.normalize(om.dna_encoder(dna).float(), p=2, dim=-1)
+    loss = O.contrastive_loss([img, d, None], labels, om.logit_scale.exp())
+    ps = [p for p in om.parameters() if p.requires_grad]
+    gs = torch.autograd.grad(loss, ps, allow_unused=True)
+    g = torch.cat([(torch.zeros_like(p) if g_ is None else g_).flatten() for p, g_ in zip(ps, gs)])
+    return img.detach(), d.detach(), float(loss.detach()), g
+
+
+def main():
+    om = build()
+    tr, fr = batch(3), batch(4)
+    opt = torch.optim.AdamW([p for p in om.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-2)
+    t0 = time.time()
+    losses = []
+    with O.precision("bf16"):
+        for _ in range(STEPS):
+            losses.append(float(O.train_step(om, opt, *tr[:2], tr[2])))
+    print(f"trained {STEPS} bf16 steps on a fixed batch of {B}: loss {losses[0]:.3f} -> {losses[-1]:.3f}  ({time.time() - t0:.0f} s)", flush=True)
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+    policies = [("tensor", dict(gran="tensor", cls_bf16=False, bf16_from_block=None)),
+                ("dna_only", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True)),
+                ("dna_only_mx32", dict(gran="mx32", cls_bf16=False, bf16_from_block=None, image_bf16=True)),
+                ("mx32", dict(gran="mx32", cls_bf16=False, bf16_from_block=None)),
+                ("act_only", dict(gran="act_only", cls_bf16=False, bf16_from_block=None)),
+                ("w_only", dict(gran="w_only", cls_bf16=False, bf16_from_block=None)),
+                ("cls_bf16", dict(gran="tensor", cls_bf16=True, bf16_from_block=None)),
+                ("mx32+cls_bf16", dict(gran="mx32", cls_bf16=True, bf16_from_block=None)),
+                ("last2_bf16", dict(gran="tensor", cls_bf16=False, bf16_from_block=10)),
+                ("last6_bf16", dict(gran="tensor", cls_bf16=False, bf16_from_block=6))]
+    for name, (image, dna, labels) in (("train batch", tr), ("fresh batch", fr)):
+        with O.precision("bf16"):
+            i16, d16, l16, g16 = evaluate(om, image, dna, labels)
+        spread = float((i16 @ i16.T).fill_diagonal_(0).sum() / (B * (B - 1)))
+        print(f"== {name}: bf16 loss {l16:.4f}, mean mutual cosine of image embeddings {spread:.3f}", flush=True)
+        for pname, pol in policies:
+            if only is not None and pname not in only:
+                continue
+            POLICY.update(image_bf16=False)
+            POLICY.update(pol)
+            with O.precision("fp8"):
+                i8, d8, l8, g8 = evaluate(om, image, dna, labels)
+            cosv = float(g8.double() @ g16.double() / (g8.double().norm() * g16.double().norm()))
+            print(f"   {pname:16s} image emb err {float((i8 - i16).abs().max()):.2e}  dna emb err {float((d8 - d16).abs().max()):.2e}  "
+                  f"|dloss| {abs(l8 - l16):.2e}  cosine(grad fp8, grad bf16) {cosv:.4f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -24,11 +24,13 @@ if has tri; then
   timeout 600 python bench.py --tri-modal --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_trimodal_b2048.json" 2> "$OUT/bench_trimodal.err"
   echo "tri exit $?"; tail -c 600 "$OUT/bench_trimodal_b2048.json"
 fi
-if has fp8; then   # BASELINE configs[4]: opt-in fp8-forward mode, at the metric's batch and at the per-GPU batch configs[4] names
-  timeout 600 python bench.py --fp8-forward --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --gemm-breakdown > "$OUT/bench_fp8_b2048.json" 2> "$OUT/bench_fp8_b2048.err"
-  echo "fp8 exit $?"; tail -c 600 "$OUT/bench_fp8_b2048.json"
-  timeout 600 python bench.py --fp8-forward --per-gpu-batch 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-h2d > "$OUT/bench_fp8_b1024.json" 2> "$OUT/bench_fp8_b1024.err"
-  echo "fp8 b1024 exit $?"; tail -c 600 "$OUT/bench_fp8_b1024.json"
+if has fp8; then   # BASELINE configs[4]: opt-in fp8-forward mode — the training-grade selection (mean-pooled towers) and the embedding-grade one (all)
+  for tw in pooled all; do
+    timeout 600 python bench.py --fp8-forward $tw --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --gemm-breakdown > "$OUT/bench_fp8_${tw}_b2048.json" 2> "$OUT/bench_fp8_${tw}_b2048.err"
+    echo "fp8 $tw exit $?"; tail -c 400 "$OUT/bench_fp8_${tw}_b2048.json"
+    timeout 600 python bench.py --fp8-forward $tw --per-gpu-batch 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-h2d > "$OUT/bench_fp8_${tw}_b1024.json" 2> "$OUT/bench_fp8_${tw}_b1024.err"
+    echo "fp8 $tw b1024 exit $?"; tail -c 400 "$OUT/bench_fp8_${tw}_b1024.json"
+  done
 fi
 if has prof; then
   export CLIBD_TOWER_STREAMS=0

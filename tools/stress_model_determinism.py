@@ -32,7 +32,7 @@ ri, rd = fwd()
 bad_i = bad_d = 0
 for k in range(iters):
     if alt:
-        model.enable_fp8_forward(); fwd(); model.enable_fp8_forward(enabled=False)
+        model.enable_fp8_forward(towers="all"); fwd(); model.enable_fp8_forward(enabled=False)
     i, d = fwd()
     if not torch.equal(i, ri):
         bad_i += 1
