@@ -62,6 +62,8 @@ SIGNATURES = {
     "clibd_layernorm_fwd_fp8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p, c_float, c_void_p]),
     "clibd_attention_fwd_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_float, c_void_p]),
     "clibd_layernorm_bwd_res16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),
+    "clibd_layernorm_bwd_any": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clibd_layernorm_bwd_pg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clibd_attention_fwd_drop": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),
     "clibd_attention_bwd_drop": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),

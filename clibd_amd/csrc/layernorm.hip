@@ -443,3 +443,11 @@ extern "C" int clibd_layernorm_bwd_res16(const void* dy_bf16, const float* dy_f3
     return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, nullptr, nullptr, dx_bf16, drop_seed, drop_thr16, drop_scale, nullptr,
                               nullptr, stream, dres_bf16, dx_res_bf16);
 }
+
+extern "C" int clibd_layernorm_bwd_any(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
+                                       int M, int H, const float* dres_f32, const void* dres_bf16, float* dx_f32, void* dx_res_bf16,
+                                       void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, float* dgamma, float* dbeta,
+                                       void* stream) {
+    return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma,
+                              dbeta, stream, dres_bf16, dx_res_bf16);
+}

@@ -499,7 +499,10 @@ class TransformerStack:
         first_lora = min((i for i, L in enumerate(self.layers) if L.lora is not None), default=len(self.layers))
         if full:
             first_lora = -1  # every layer has trainable parameters and the input gradient is needed
-        r16 = self.numerics["residual_grad"] == "bf16" and not full   # bf16 residual-gradient stream (see NUMERICS_CHOICES)
+        # bf16 residual-gradient stream (see NUMERICS_CHOICES).  Round 4: full fine-tune mode takes it too — the LayerNorm parameter
+        # gradients ride along in the same kernel (clibd_layernorm_bwd_any), and the BOTTOM layer hands an fp32 gradient to the
+        # embedding backward as before (`need32`).  409.6 ms per step at b = 2048 with the fp32 stream (profiles/r04_fullft_*_v1*).
+        r16 = self.numerics["residual_grad"] == "bf16"
         # full fine-tune: the LayerNorm backward accumulates d(gamma), d(beta) in the same pass (it holds dy and xhat anyway)
         pg = lambda w, b: (dict(dgamma=grads[id(w)].view(-1), dbeta=grads[id(b)].view(-1)) if full and id(w) in grads else {})
         wg = lambda dy, x, ws, bs: linear_wgrad(dy, x, ws, bs, grads) if full else None
@@ -531,8 +534,9 @@ class TransformerStack:
                     if r16:
                         dres16, _ = ops.scatter_rows(dx1_f32, S, bf16=True, f32=False)           # residual path: class rows only
                         ndx_bf16 = new(H, BF16)
-                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16)
-                        dx_f32, dx_bf16 = None, ndx_bf16
+                        ndx_f32 = new(H, F32) if (full and i == 0) else None
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16, dx_f32=ndx_f32, **pg(L.ln1_w, L.ln1_b))
+                        dx_f32, dx_bf16 = ndx_f32, ndx_bf16
                     else:
                         _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)        # residual path: class rows only
                         ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
@@ -545,7 +549,7 @@ class TransformerStack:
                 ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
                 if r16:
                     dx1_f32, dx1_bf16 = None, new(H, BF16)
-                    ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres_bf16=dx_bf16, dx_bf16=dx1_bf16)
+                    ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres_bf16=dx_bf16, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
                 else:
                     dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
                     ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
@@ -559,8 +563,8 @@ class TransformerStack:
                     add32 = None if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H)      # second rank slot: dt2 . A_cat2, fp32
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, residual=add32, out_bf16=dtmp)
                     if r16:
-                        ndx_f32, ndx_bf16 = None, new(H, BF16)
-                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16)
+                        ndx_f32, ndx_bf16 = (new(H, F32) if (full and i == 0) else None), new(H, BF16)
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16, dx_f32=ndx_f32, **pg(L.ln1_w, L.ln1_b))
                     else:
                         ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
                         ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
@@ -569,29 +573,38 @@ class TransformerStack:
                 # post-LN, bf16 stream: `dx_f32` holds the incoming gradient of the layer output (fp32 from the head at the top layer,
                 # bf16 below).  Each LayerNorm backward writes the un-dropped residual copy (*_res) and, under dropout, the masked
                 # copy the dense branch's dgrad consumes; the two dgrads that re-join the stream add the residual copy in their epilogue.
-                def ln_back(dy, xs, st, gam, drop_site):
+                def ln_back(dy, xs, st, gam, drop_site, pgk):
                     res = new(H, BF16)
                     if drop_site is not None and drop_site.thr16 > 0:
                         masked = new(H, BF16)
-                        ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, dx_bf16=masked, drop=drop_site)
+                        ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, dx_bf16=masked, drop=drop_site, **pgk)
                         return res, masked
-                    ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res)
+                    ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, **pgk)
                     return res, res
 
-                ds2_res, ds2_b = ln_back(dx_f32, rec["s2"], rec["st2"], c.g2, rec["d_h2"])
+                ds2_res, ds2_b = ln_back(dx_f32, rec["s2"], rec["st2"], c.g2, rec["d_h2"], pg(L.ln2_w, L.ln2_b))
+                wg(ds2_b, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 ops.gemm_nt(ds2_b, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)
+                wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                 dx1 = new(H, BF16)
                 ops.gemm_nt(dh, c.w1_t, act=ops.ACT_ADD_AUX, aux=ds2_res, out_bf16=dx1)
-                ds1_res, ds1_b = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"])
+                ds1_res, ds1_b = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"], pg(L.ln1_w, L.ln1_b))
+                wg(ds1_b, rec.get("o"), [L.proj_w], [L.proj_b])
                 ops.gemm_nt(ds1_b, c.wo_t, out_bf16=dtmp)
                 self._attention_bwd(rec, dtmp, B, S, key_mask, dqkv, drop=rec["d_att"])
                 if has_lora:
                     dt2 = self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads, rec.get("t2"))
+                wg(dqkv, rec["x_bf16"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
-                    ndx = new(H, BF16)
                     add32 = None if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H)
-                    ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
-                                act=ops.ACT_ADD_AUX, aux=ds1_res, residual=add32, out_bf16=ndx)
+                    if full and i == 0:   # the embedding backward takes an fp32 gradient (generic epilogue: one launch per tower)
+                        ndx = new(H, F32)
+                        ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
+                                    act=ops.ACT_ADD_AUX, aux=ds1_res, residual=add32, out_f32=ndx)
+                    else:
+                        ndx = new(H, BF16)
+                        ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
+                                    act=ops.ACT_ADD_AUX, aux=ds1_res, residual=add32, out_bf16=ndx)
                     dx_f32 = ndx
             else:
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)

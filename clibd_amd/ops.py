@@ -280,8 +280,8 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, 
     _chk(x, F32, "x")
     M, H = x.shape
     if dres_bf16 is not None or dx_res_bf16 is not None:
-        if dres is not None or dx_f32 is not None or dgamma is not None:
-            raise ValueError("layernorm_bwd: the bf16 residual-gradient form has no fp32 streams and no parameter gradients")
+        if dres is not None:
+            raise ValueError("layernorm_bwd: the residual gradient is either fp32 (dres) or bf16 (dres_bf16)")
         for nm, t in (("dres_bf16", dres_bf16), ("dx_res_bf16", dx_res_bf16), ("dx_bf16", dx_bf16)):
             if t is not None:
                 _chk(t, BF16, nm)
@@ -293,8 +293,24 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, 
         _chk(stats, F32, "stats")
         _chk(gamma, F32, "gamma")
         d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
-        check(_lib.load().clibd_layernorm_bwd_res16(dy.data_ptr() if dy.dtype == BF16 else None, dy.data_ptr() if dy.dtype == F32 else None,
-                                                    x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres_bf16), _p(dx_res_bf16),
+        dyb, dyf = (dy.data_ptr(), None) if dy.dtype == BF16 else (None, dy.data_ptr())
+        if dx_f32 is not None or dgamma is not None or dbeta is not None:
+            # full fine-tune on the bf16 stream: parameter gradients ride along, the bottom layer hands an fp32 gradient to the embeddings
+            if dx_f32 is not None:
+                _chk(dx_f32, F32, "dx_f32")
+                if tuple(dx_f32.shape) != (M, H):
+                    raise ValueError("layernorm_bwd: dx_f32 shape")
+            if (dgamma is None) != (dbeta is None):
+                raise ValueError("layernorm_bwd: dgamma / dbeta come together")
+            if dgamma is not None:
+                _chk(dgamma, F32, "dgamma"); _chk(dbeta, F32, "dbeta")
+                if dgamma.numel() != H or dbeta.numel() != H:
+                    raise ValueError("layernorm_bwd: dgamma / dbeta must have H elements")
+            check(_lib.load().clibd_layernorm_bwd_any(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, None, _p(dres_bf16), _p(dx_f32),
+                                                      _p(dx_res_bf16), _p(dx_bf16), d.seed, d.thr16, d.scale, _p(dgamma), _p(dbeta), _stream()),
+                  "layernorm_bwd_any")
+            return
+        check(_lib.load().clibd_layernorm_bwd_res16(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres_bf16), _p(dx_res_bf16),
                                                     _p(dx_bf16), d.seed, d.thr16, d.scale, _stream()), "layernorm_bwd_res16")
         return
     if dy.dtype == BF16:

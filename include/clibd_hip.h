@@ -159,6 +159,13 @@ int clibd_layernorm_bwd_drop(const void* dy_bf16, const float* dy_f32, const flo
 int clibd_layernorm_bwd_res16(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
                               int M, int H, const void* dres_bf16, void* dx_res_bf16, void* dx_bf16, uint32_t drop_seed,
                               int drop_thr16, float drop_scale, void* stream);
+/* The general form (round 4; full fine-tune on the bf16 residual-gradient stream): every optional operand of the three entry
+ * points above in one call — residual gradient in fp32 (dres_f32) OR bf16 (dres_bf16), outputs dx_f32 / dx_res_bf16 / dx_bf16
+ * (at least one), dropout on the dx_bf16 copy, and dgamma / dbeta (both or neither; accumulated).  Same kernel, same arithmetic. */
+int clibd_layernorm_bwd_any(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
+                            int M, int H, const float* dres_f32, const void* dres_bf16, float* dx_f32, void* dx_res_bf16,
+                            void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, float* dgamma, float* dbeta,
+                            void* stream);
 /* full fine-tune mode: the same backward that also accumulates the parameter gradients it has the operands for
  *   dgamma[c] += sum_m dy[m,c] * xhat[m,c],  dbeta[c] += sum_m dy[m,c]     (fp32 [H], caller zeroes once per step). */
 int clibd_layernorm_bwd_pg(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
