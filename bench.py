@@ -39,7 +39,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 MAX_SCLK_MHZ = 2400.0         # the shader clock that figure is quoted at
-GF_PER_PAIR_TRAIN = 117.6     # LoRA training step, I+D pair (fwd 58.78 GF + dgrad-only bwd)
+GF_PER_PAIR_TRAIN = 117.6     # LoRA training step, I+D pair (fwd 58.78 GF + dgrad-only bwd) — the reference model's FLOPs
+GF_PER_PAIR_FULLFT = 176.3    # full fine-tune (dgrad + wgrad), the authors' final configuration (`disable_lora: true`)
 
 
 def parse():
@@ -617,14 +618,17 @@ def main():
         gemm = serial if serial is not None else overlapped
         if gemm and args.gemm_breakdown:
             timer.breakdown(gemm["steps"])
-        step_frac = pairs_per_s * GF_PER_PAIR_TRAIN * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12)
+        gf_pair = GF_PER_PAIR_FULLFT if args.full_finetune else GF_PER_PAIR_TRAIN   # reference model FLOPs of the configuration being run
+        step_frac = pairs_per_s * gf_pair * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12)
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "kernel": "gemm256_bf16_nt_kernel (256x256x64 persistent tiles; gemm_bf16_nt_kernel 128x128 for small shapes)", "step_frac": step_frac,
+                "step_frac_gflop_per_pair": gf_pair,
                 "note": "achieved = sum of 2MNK over every GEMM launch / summed HIP-event durations (rank 0, events on the launch "
                         "stream), measured right after the timed region on the same step with the towers serialized on one stream; "
                         "timed_region = the same quantity with the towers overlapping on two streams exactly as in the timed region, where a "
-                        "launch's duration includes CU sharing; step_frac = pairs/s x 117.6 GF / (n_gpus x peak), the whole step "
-                        "against the MFMA roof"}
+                        "launch's duration includes CU sharing; step_frac = pairs/s x the REFERENCE model's FLOPs per pair (117.6 GF LoRA step, "
+                        "176.3 GF full fine-tune: BASELINE.md section 3; the class-row-only last ViT block executes ~4 % fewer) / (n_gpus x peak): "
+                        "the whole step against the MFMA roof"}
         traffic, traffic_src, stale = pmc_traffic(b)
         if traffic is not None:
             roof["traffic"] = traffic

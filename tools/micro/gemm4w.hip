@@ -38,6 +38,7 @@
 #include <vector>
 #include <glob.h>
 #include <unistd.h>
+#include <cctype>
 #include "../../include/clibd_hip.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -62,7 +63,14 @@ __device__ __forceinline__ unsigned pack2bf(float a, float b) {
 
 #define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-template <int STAGE>
+// DEFER = false: plain epilogue after the K loop (all 32 row stores of a wave back to back, no MFMA under them).
+// DEFER = true : NO epilogue.  Quadrants run in the order (hm0,hn0) (hm1,hn0) (hm1,hn1) (hm0,hn1), so the rows of hn0 are final after
+//   phase 1 of the last K-tile and are stored — straight from the accumulators: 8 v_accvgpr_read + 4 v_cvt_pk + one 16-byte store per
+//   row, no stash — between the MFMAs of that K-tile's phases 2 and 3; the rows of hn1 are final after phase 3 and go out under the
+//   NEXT tile's phases 0 and 1, which only write hn0 accumulators (its first K-step takes C = 0 instead of zeroed accumulators).
+//   Eight stores per phase, one after every fourth MFMA.  vmcnt retires in order and counts stores, so the LDS-DMA waits of the
+//   phases around a tile boundary carry the stores that are younger than the awaited half-tile (table at WAITS).
+template <bool DEFER>
 __global__ __launch_bounds__(256, 1) void gemm4w_kernel(P4 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(P4 p) {
     const unsigned chunk16 = (unsigned)((lane & 7) ^ prow) * 16u;
     const int nk = p.K / 64;                       // even, >= 4 (host-checked)
 
-    // staging: piece i (0..3) of a half-tile = image rows 32 w + 8 i + prow
+    // staging: piece i (0..3) of a half-tile = image rows 32 w + 8 i + prow.  Half-tile stream order j = 0 P_hm0, 1 Q_hn0, 2 P_hm1, 3 Q_hn1
     unsigned offP[4], offQ[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -82,42 +90,36 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(P4 p) {
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
     const unsigned stage_dst = (unsigned)w * 4096u;                 // this wave's 4 KiB of every half-tile
-    // fragments: tile t of a half sits 2048 bytes after tile 0; the swizzle term (row & 7) does not depend on t
     const int frow = lane & 15, fch = lane >> 4;
     const int aP0 = tile_off(64 * wm + frow, fch), aP1 = tile_off(64 * wm + frow, 4 + fch);
     const int aQ0 = tile_off(64 * wn + frow, fch), aQ1 = tile_off(64 * wn + frow, 4 + fch);
+    // output: lane (c = frow, g = fch) owns rows m0 + 128 wn + 64 hn + 16 qt + 4 g + r, columns n0 + 128 wm + 8 c + (4 hm + pt)
+    const unsigned voff_out = (unsigned)((4 * fch) * p.ldo + 128 * wm + 8 * frow) * 2u;
 
-    auto tile_xy = [&](int id, int& m0, int& n0) {   // XCD-aware: blocks b and b + 8 share an L2; give an XCD a contiguous range
+    auto tile_xy = [&](int id, int& m0_, int& n0_) {   // XCD-aware: blocks b and b + 8 share an L2; give an XCD a contiguous range
         const int per = (p.ntiles + 7) >> 3;
         const int logical = (id & 7) * per + (id >> 3);   // a bijection: ntiles % 8 == 0 (host-checked)
-        m0 = (logical / p.tiles_n) * 256;
-        n0 = (logical % p.tiles_n) * 256;
+        m0_ = (logical / p.tiles_n) * 256;
+        n0_ = (logical % p.tiles_n) * 256;
     };
 
-    // the stream of half-tiles being issued: (tile, K-tile u_is, half j)
     int tile = blockIdx.x;
-    int m0, n0;
+    int m0, n0, pm0 = 0, pn0 = 0;
     tile_xy(tile, m0, n0);
     int im0 = m0, in0 = n0;      // origin of the tile whose half-tiles are being issued
-    int u_is = 0;                // its K-tile of the NEXT issue with j = 0 (advanced after j = 3)
-    int tile_is = tile;
-
-    u32x4 stg[4][4];             // STAGE = 1: [half-tile index & 3][piece]: four half-tiles in flight in registers
-    (void)stg;
-
-    // issue half J (compile time) of K-tile u_is of the issue stream's tile -> LDS slot (u_is & 1, J) [STAGE 0] / ring RING [STAGE 1]
+    int u_is = 0, tile_is = tile;
     const char* sbase_cur = nullptr;
     unsigned dst_cur = 0;
 #define ISSUE_BEGIN(J)                                                                                            \
     do {                                                                                                          \
-        constexpr bool isP_ = ((J) == 0 || (J) == 3);                                                             \
-        sbase_cur = isP_ ? p.W + (size_t)(in0 + ((J) == 3 ? 4 : 0)) * p.ldw2 + (size_t)u_is * 128                 \
-                         : p.A + (size_t)(im0 + ((J) == 2 ? 64 : 0)) * p.lda2 + (size_t)u_is * 128;               \
+        constexpr bool isP_ = ((J) == 0 || (J) == 2);                                                             \
+        sbase_cur = isP_ ? p.W + (size_t)(in0 + ((J) == 2 ? 4 : 0)) * p.ldw2 + (size_t)u_is * 128                 \
+                         : p.A + (size_t)(im0 + ((J) == 3 ? 64 : 0)) * p.lda2 + (size_t)u_is * 128;               \
         dst_cur = lds0 + (unsigned)((u_is & 1) * STAGEB + (J) * HALF) + stage_dst;                                \
     } while (0)
 #define ISSUE_PIECE(J, I)                                                                                         \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                 \
-                 :: "v"(((J) == 0 || (J) == 3) ? offP[I] : offQ[I]), "s"(sbase_cur), "s"(dst_cur + 1024u * (I)) : "memory", "m0")
+                 :: "v"(((J) == 0 || (J) == 2) ? offP[I] : offQ[I]), "s"(sbase_cur), "s"(dst_cur + 1024u * (I)) : "memory", "m0")
 #define ISSUE_END(J)                                                                                              \
     do {                                                                                                          \
         if ((J) == 3) {                                                                                           \
@@ -129,26 +131,10 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(P4 p) {
             }                                                                                                     \
         }                                                                                                         \
     } while (0)
-#define ISSUE_HALF(J, RING)                                                                                       \
-    do {                                                                                                          \
-        ISSUE_BEGIN(J);                                                                                           \
-        if (STAGE == 0) {                                                                                         \
-            ISSUE_PIECE(J, 0); ISSUE_PIECE(J, 1); ISSUE_PIECE(J, 2); ISSUE_PIECE(J, 3);                           \
-        } else {                                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-                stg[RING][i] = *(const u32x4*)(sbase_cur + (((J) == 0 || (J) == 3) ? offP[i] : offQ[i]));         \
-        }                                                                                                         \
-        ISSUE_END(J);                                                                                             \
-    } while (0)
-    // STAGE 1: ring RING -> this wave's 4 KiB of slot (slot_stage, J)
-#define STAGE_WRITE(slot_stage, J, RING)                                                                          \
-    do {                                                                                                          \
-        char* dst_ = smem + (slot_stage) * STAGEB + (J) * HALF + stage_dst + lane * 16;                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) *(u32x4*)(dst_ + 1024 * i) = stg[RING][i];                  \
-    } while (0)
+#define ISSUE_HALF(J) do { ISSUE_BEGIN(J); ISSUE_PIECE(J, 0); ISSUE_PIECE(J, 1); ISSUE_PIECE(J, 2); ISSUE_PIECE(J, 3); ISSUE_END(J); } while (0)
 
-    f32x4 acc[2][2][4][4];       // [hm][hn][P tile][Q tile]
-    bf16x8 aFa[4][2], aFb[4][2], w0a[4][2], w0b[4][2], w1[4][2];   // [tile][kk]
+    f32x4 acc[2][2][4][4];       // [hm][hn][P tile][Q tile]: 256 AGPRs
+    bf16x8 aF0a[4][2], aF0b[4][2], aF1[4][2], w0[4][2], w1[4][2];   // [tile][kk]: P_hm0 (two sets), P_hm1, Q_hn0, Q_hn1
 
 #define LOADF(dst, half_slot, a0, a1)                                                                 \
     do {                                                                                              \
@@ -157,118 +143,120 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(P4 p) {
             dst[t][1] = *(const bf16x8*)(smem + (half_slot) + (a1) + 2048 * t);                       \
         }                                                                                             \
     } while (0)
-    // One quadrant: 32 MFMAs in program order (inline asm, accumulator tied in/out and pinned to the AGPRs: left to the builtin, hipcc
-    // gives many of them a destination different from their source accumulator and shuffles tiles between AGPRs and VGPRs), with
-    // the four LDS-DMA instructions of this phase's half-tile (STAGE 0) spread between them instead of stacked behind the barrier.
 #define MFMA_ASM(ACC, QA, PB) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(QA), "v"(PB))
-#define MMA(hm, hn, PF, QF, J)                                                                        \
+#define MFMA_ASM0(ACC, QA, PB) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(QA), "v"(PB))
+    // one output row of this lane (16 bytes), straight from the accumulators
+#define STORE_ROW(HN, QT, R, TM0, TN0)                                                                \
+    do {                                                                                              \
+        const char* rb_ = (const char*)p.out + ((size_t)((TM0) + 128 * wn + 64 * (HN) + 16 * (QT) + (R)) * p.ldo + (TN0)) * 2; \
+        u32x4 d_;                                                                                     \
+        d_[0] = pack2bf(acc[0][HN][0][QT][R], acc[0][HN][1][QT][R]);                                  \
+        d_[1] = pack2bf(acc[0][HN][2][QT][R], acc[0][HN][3][QT][R]);                                  \
+        d_[2] = pack2bf(acc[1][HN][0][QT][R], acc[1][HN][1][QT][R]);                                  \
+        d_[3] = pack2bf(acc[1][HN][2][QT][R], acc[1][HN][3][QT][R]);                                  \
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff_out), "v"(d_), "s"(rb_) : "memory"); \
+    } while (0)
+    // One quadrant = 32 MFMAs in program order; after every fourth: an LDS-DMA piece of half-tile J (groups 0, 2, 4, 6) and, where the
+    // phase carries stores (SP: 0 none, 1 = rows (SHN, SQB + (g >> 2), g & 3) of the tile at (SM0, SN0), under the run-time condition SC)
+#define MMA(hm, hn, PF, QF, J, ZC, SP, SHN, SQB, SM0, SN0, SC)                                        \
     do {                                                                                              \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
             _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) {                                        \
-                _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) MFMA_ASM(acc[hm][hn][pt][qt], QF[qt][kk], PF[pt][kk]); \
-                if (STAGE == 0 && (pt & 1) == 0) ISSUE_PIECE(J, 2 * kk + (pt >> 1));                  \
+                _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) {                                    \
+                    if ((ZC) && kk == 0) MFMA_ASM0(acc[hm][hn][pt][qt], QF[qt][kk], PF[pt][kk]);      \
+                    else MFMA_ASM(acc[hm][hn][pt][qt], QF[qt][kk], PF[pt][kk]);                       \
+                }                                                                                     \
+                if ((pt & 1) == 0) ISSUE_PIECE(J, 2 * kk + (pt >> 1));                                \
+                if (SP) {                                                                             \
+                    if (SC) STORE_ROW(SHN, (SQB) + ((4 * kk + pt) >> 2), (4 * kk + pt) & 3, SM0, SN0); \
+                    __builtin_amdgcn_sched_barrier(0);                                                \
+                }                                                                                     \
             }                                                                                         \
     } while (0)
-    // phase head (phase p = 4 u + Q, stage S = u & 1): wait for L_{<= p+3}, barrier, [STAGE 1: write L_{p+4}], issue L_{p+7}
-    // STAGE 0: 4 LDS-DMA per half-tile and wave; in flight at the start of phase p: L_{p+4..p+6} = 12 (+ the 32 epilogue stores while
-    //          they are younger than the awaited half-tile: phases 0-3 of a tile that follows an epilogue)
-    // STAGE 1: the compiler counts its own loads.  L_{p+4} (= half Q of K-tile u + 1: slot (S ^ 1, Q)), loaded in phase p - 3 into ring
-    //          Q, is written now and published by the NEXT barrier — the start of phase p + 1, its earliest read phase; L_{p+7} is
-    //          loaded into ring (Q + 3) & 3, the ring L_{p+3} left in phase p - 1
-#define HEAD(Q, S, AFTER_EPI)                                                                         \
-    do {                                                                                              \
-        if (STAGE == 0) {                                                                             \
-            if (AFTER_EPI) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");                          \
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                    \
-        } else {                                                                                      \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
-        }                                                                                             \
-        BARRIER();                                                                                    \
-        if (STAGE == 1) { STAGE_WRITE((S) ^ 1, (Q), (Q)); ISSUE_HALF(((Q) + 3) & 3, ((Q) + 3) & 3); } \
-        else ISSUE_BEGIN(((Q) + 3) & 3);      /* its four pieces go out between this phase's MFMAs (MMA) */ \
-    } while (0)
-#define TAIL(Q) do { if (STAGE == 0) ISSUE_END(((Q) + 3) & 3); } while (0)
+#define WAITSEL(COND, NA, NB) do { if (COND) asm volatile("s_waitcnt vmcnt(" #NA ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #NB ")" ::: "memory"); } while (0)
+    // phase head (phase p = 4 u + Q): wait for L_{<= p+3} — in flight behind it: L_{p+4..p+6} = 12 LDS-DMA plus the stores issued in
+    // the last three phases —, barrier, start L_{p+7} (its pieces go out between this phase's MFMAs)
+#define HEAD(Q, COND, NA, NB) do { WAITSEL(COND, NA, NB); BARRIER(); ISSUE_BEGIN(((Q) + 3) & 3); } while (0)
+#define TAIL(Q) ISSUE_END(((Q) + 3) & 3)
 
-    // ---- prologue: L_0 .. L_6
-    if (STAGE == 0) {
-        ISSUE_HALF(0, 0); ISSUE_HALF(1, 0); ISSUE_HALF(2, 0); ISSUE_HALF(3, 0); ISSUE_HALF(0, 0); ISSUE_HALF(1, 0); ISSUE_HALF(2, 0);
-    } else {
-        // L_0 .. L_3 (K-tile 0, stage 0) go through ring 0 synchronously; L_4, L_5, L_6 stay in rings 0, 1, 2 (phase 0 writes ring 0
-        // and loads L_7 into ring 3)
-        ISSUE_HALF(0, 0); STAGE_WRITE(0, 0, 0);
-        ISSUE_HALF(1, 0); STAGE_WRITE(0, 1, 0);
-        ISSUE_HALF(2, 0); STAGE_WRITE(0, 2, 0);
-        ISSUE_HALF(3, 0); STAGE_WRITE(0, 3, 0);
-        ISSUE_HALF(0, 0); ISSUE_HALF(1, 1); ISSUE_HALF(2, 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    if (STAGE == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // L_0 .. L_3 landed
+    // ---- prologue: L_0 .. L_6; first fragments: P_hm0, Q_hn0 of K-tile 0 (stage 0)
+    ISSUE_HALF(0); ISSUE_HALF(1); ISSUE_HALF(2); ISSUE_HALF(3); ISSUE_HALF(0); ISSUE_HALF(1); ISSUE_HALF(2);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // L_0 .. L_3 landed
     BARRIER();
-    // first fragments of the first tile: Q_hn0, P_hm0 of K-tile 0 (stage 0)
-    LOADF(w0a, 1 * HALF, aQ0, aQ1);
-    LOADF(aFa, 0 * HALF, aP0, aP1);
+    LOADF(aF0a, 0 * HALF, aP0, aP1);
+    LOADF(w0, 1 * HALF, aQ0, aQ1);
 
-    bool after_epi = false;
-    while (true) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // K-tile pair 0 (its first four phases may follow an epilogue: the stores are then younger than the awaited half-tiles),
-        // then the steady loop; the same eight phases either way
-#define PAIR(AE)                                                                                                         \
-    do {                                                                                                                 \
-        HEAD(0, 0, AE); LOADF(w1, 0 * STAGEB + 2 * HALF, aQ0, aQ1);  MMA(0, 0, aFa, w0a, 3); TAIL(0);                    \
-        HEAD(1, 0, AE); LOADF(aFb, 0 * STAGEB + 3 * HALF, aP0, aP1); MMA(0, 1, aFa, w1, 0);  TAIL(1);                    \
-        HEAD(2, 0, AE); LOADF(w0b, 1 * STAGEB + 1 * HALF, aQ0, aQ1); MMA(1, 1, aFb, w1, 1);  TAIL(2);                    \
-        HEAD(3, 0, AE); LOADF(aFa, 1 * STAGEB + 0 * HALF, aP0, aP1); MMA(1, 0, aFb, w0a, 2); TAIL(3);                    \
-        HEAD(0, 1, false); LOADF(w1, 1 * STAGEB + 2 * HALF, aQ0, aQ1);  MMA(0, 0, aFa, w0b, 3); TAIL(0);                 \
-        HEAD(1, 1, false); LOADF(aFb, 1 * STAGEB + 3 * HALF, aP0, aP1); MMA(0, 1, aFa, w1, 0);  TAIL(1);                 \
-        HEAD(2, 1, false); LOADF(w0a, 0 * STAGEB + 1 * HALF, aQ0, aQ1); MMA(1, 1, aFb, w1, 1);  TAIL(2);                 \
-        HEAD(3, 1, false); LOADF(aFa, 0 * STAGEB + 0 * HALF, aP0, aP1); MMA(1, 0, aFb, w0b, 2); TAIL(3);                 \
+    bool has_prev = false;
+    // WAITS.  DEFER: stores sit in phases L2, L3 (last K-tile) and N0, N1 (first K-tile of the next tile), 8 each:
+    //   L3: 12 + 8 = 20 | N0: 12 + 16 = 28 | N1: 36 | N2: 36 | N3: 28 | N4: 20 | else 12   (first tile of a workgroup: no N-phase stores)
+    // plain epilogue (32 stores between L3 and N0): N0 .. N3: 12 + 32 = 44, else 12
+    // K-tile of stage S with P_hm0 in ACUR, the next K-tile's P_hm0 going to ANEXT; ZC: first K-tile of a tile; WN0..WN3 / SPx: see callers
+#define KTILE(S, ACUR, ANEXT, ZC, W0A, W0B, W1A, W1B, W2A, W2B, W3A, W3B, SP0, SP1, SP2, SP3)                                    \
+    do {                                                                                                                         \
+        HEAD(0, has_prev, W0A, W0B); LOADF(aF1, (S) * STAGEB + 2 * HALF, aP0, aP1);                                              \
+        MMA(0, 0, ACUR, w0, 3, ZC, SP0, 1, 0, pm0, pn0, has_prev); TAIL(0);                                                      \
+        HEAD(1, has_prev, W1A, W1B); LOADF(w1, (S) * STAGEB + 3 * HALF, aQ0, aQ1);                                               \
+        MMA(1, 0, aF1, w0, 0, ZC, SP1, 1, 2, pm0, pn0, has_prev); TAIL(1);                                                       \
+        HEAD(2, has_prev, W2A, W2B); LOADF(w0, ((S) ^ 1) * STAGEB + 1 * HALF, aQ0, aQ1);                                         \
+        MMA(1, 1, aF1, w1, 1, ZC, SP2, 0, 0, m0, n0, true); TAIL(2);                                                             \
+        HEAD(3, has_prev, W3A, W3B); LOADF(ANEXT, ((S) ^ 1) * STAGEB + 0 * HALF, aP0, aP1);                                      \
+        MMA(0, 1, ACUR, w1, 2, ZC, SP3, 0, 2, m0, n0, true); TAIL(3);                                                            \
     } while (0)
-        PAIR(after_epi);
+    while (true) {
+        // ---- first K-tile pair of the tile
+        if constexpr (DEFER) {
+            KTILE(0, aF0a, aF0b, true, 28, 12, 36, 12, 36, 12, 28, 12, 1, 1, 0, 0);
+            KTILE(1, aF0b, aF0a, false, 20, 12, 12, 12, 12, 12, 12, 12, 0, 0, 0, 0);
+        } else {
+            KTILE(0, aF0a, aF0b, true, 44, 12, 44, 12, 44, 12, 44, 12, 0, 0, 0, 0);
+            KTILE(1, aF0b, aF0a, false, 12, 12, 12, 12, 12, 12, 12, 12, 0, 0, 0, 0);
+        }
+        // ---- steady K-tile pairs
 #pragma unroll 1
-        for (int u = 2; u < nk; u += 2) PAIR(false);
-#undef PAIR
-        // ---- epilogue: lane (c = frow, g = fch) owns rows m0 + 128 wn + 64 hn + 16 qt + 4 g + r, columns n0 + 128 wm + 8 c + (4 hm + pt)
-        {
-            unsigned short* obase = p.out + (size_t)(m0 + 128 * wn + 4 * fch) * p.ldo + n0 + 128 * wm + 8 * frow;
+        for (int u = 2; u < nk - 2; u += 2) {
+            KTILE(0, aF0a, aF0b, false, 12, 12, 12, 12, 12, 12, 12, 12, 0, 0, 0, 0);
+            KTILE(1, aF0b, aF0a, false, 12, 12, 12, 12, 12, 12, 12, 12, 0, 0, 0, 0);
+        }
+        // ---- last K-tile pair: DEFER stores the hn0 rows of this tile under phases 2 and 3 of the last K-tile
+        KTILE(0, aF0a, aF0b, false, 12, 12, 12, 12, 12, 12, 12, 12, 0, 0, 0, 0);
+        if constexpr (DEFER) {
+            KTILE(1, aF0b, aF0a, false, 12, 12, 12, 12, 12, 12, 20, 20, 0, 0, 1, 1);
+        } else {
+            KTILE(1, aF0b, aF0a, false, 12, 12, 12, 12, 12, 12, 12, 12, 0, 0, 0, 0);
 #pragma unroll
             for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
                 for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        u32x4 v;
-                        v[0] = pack2bf(acc[0][hn][0][qt][r], acc[0][hn][1][qt][r]);
-                        v[1] = pack2bf(acc[0][hn][2][qt][r], acc[0][hn][3][qt][r]);
-                        v[2] = pack2bf(acc[1][hn][0][qt][r], acc[1][hn][1][qt][r]);
-                        v[3] = pack2bf(acc[1][hn][2][qt][r], acc[1][hn][3][qt][r]);
-                        *(u32x4*)(obase + (size_t)(64 * hn + 16 * qt + r) * p.ldo) = v;
-                    }
+                    for (int r = 0; r < 4; ++r) { STORE_ROW(hn, qt, r, m0, n0); __builtin_amdgcn_sched_barrier(0); }
         }
         const int nxt = tile + (int)gridDim.x;
         if (nxt >= p.ntiles) break;
+        pm0 = m0; pn0 = n0;
         tile = nxt;
         tile_xy(tile, m0, n0);
-        after_epi = true;
+        has_prev = true;
+    }
+    if constexpr (DEFER) {   // the hn1 rows of this workgroup's last tile have no next tile to hide under
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { STORE_ROW(1, qt, r, m0, n0); __builtin_amdgcn_sched_barrier(0); }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the stream ran 7 half-tiles ahead: drain before the LDS is released
+#undef KTILE
 #undef HEAD
+#undef TAIL
+#undef WAITSEL
 #undef MMA
+#undef STORE_ROW
+#undef MFMA_ASM
+#undef MFMA_ASM0
 #undef LOADF
 #undef ISSUE_HALF
 #undef ISSUE_BEGIN
 #undef ISSUE_PIECE
 #undef ISSUE_END
-#undef TAIL
-#undef MFMA_ASM
-#undef STAGE_WRITE
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
@@ -278,17 +266,32 @@ static double now() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec + 1e
 
 static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-struct Board {   // sysfs hwmon of the card that draws the most (one GPU per box here): power1_input / power1_average (uW), freq1_input (Hz)
+struct Board {   // sysfs hwmon of THIS process's device (matched by PCI bus id): power1_input / power1_average (uW), freq1_input (Hz)
     std::string dir, pn;
     Board() {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), 0) != hipSuccess) return;      // "0000:dc:00.0": this process's device
+        for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
         glob_t g;
-        double best = -1;
-        if (glob("/sys/class/drm/card*/device/hwmon/hwmon*", 0, nullptr, &g) == 0) {
-            for (size_t i = 0; i < g.gl_pathc; ++i)
-                for (const char* n : {"power1_input", "power1_average"}) {
-                    double v = rd(std::string(g.gl_pathv[i]) + "/" + n);
-                    if (v > best) { best = v; dir = g.gl_pathv[i]; pn = n; }
+        if (glob("/sys/class/drm/card*/device", 0, nullptr, &g) == 0) {
+            for (size_t i = 0; i < g.gl_pathc && dir.empty(); ++i) {
+                FILE* f = fopen((std::string(g.gl_pathv[i]) + "/uevent").c_str(), "r");
+                if (!f) continue;
+                char line[256]; bool mine = false;
+                while (fgets(line, sizeof(line), f)) {
+                    for (char* c = line; *c; ++c) *c = (char)tolower(*c);
+                    if (!strncmp(line, "pci_slot_name=", 14) && !strncmp(line + 14, bus, strlen(bus))) mine = true;
                 }
+                fclose(f);
+                if (!mine) continue;
+                glob_t h;
+                if (glob((std::string(g.gl_pathv[i]) + "/hwmon/hwmon*").c_str(), 0, nullptr, &h) == 0) {
+                    for (size_t k = 0; k < h.gl_pathc && dir.empty(); ++k)
+                        for (const char* n : {"power1_input", "power1_average"})
+                            if (rd(std::string(h.gl_pathv[k]) + "/" + n) > 0) { dir = h.gl_pathv[k]; pn = n; break; }
+                    globfree(&h);
+                }
+            }
             globfree(&g);
         }
     }
@@ -318,8 +321,8 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     int ncu = 256;
     { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); ncu = pr.multiProcessorCount; }
-    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     const int M = 403456;
     const int shapes[2][2] = {{768, 3072}, {3072, 768}};   // (N, K)
     for (int si = 0; si < 2; ++si) {
@@ -341,8 +344,8 @@ int main(int argc, char** argv) {
         ep.split_k = 1; ep.ld_out_bf16 = N;
         auto run = [&](int arm) {
             if (arm == 0) { ep.out_bf16 = dO[0]; if (ref(dA, K, dW, K, M, N, K, &ep, st) != 0) { fprintf(stderr, "reference gemm failed\n"); exit(1); } }
-            else if (arm == 1) { p.out = dO[1]; hipLaunchKernelGGL(gemm4w_kernel<0>, dim3(ncu), dim3(256), LDS_BYTES, st, p); }
-            else { p.out = dO[2]; hipLaunchKernelGGL(gemm4w_kernel<1>, dim3(ncu), dim3(256), LDS_BYTES, st, p); }
+            else if (arm == 1) { p.out = dO[1]; hipLaunchKernelGGL(gemm4w_kernel<false>, dim3(ncu), dim3(256), LDS_BYTES, st, p); }
+            else { p.out = dO[2]; hipLaunchKernelGGL(gemm4w_kernel<true>, dim3(ncu), dim3(256), LDS_BYTES, st, p); }
         };
         // ---- correctness: each arm against a host fp64 dot product on sampled entries, and arm against arm on everything
         for (int arm = 0; arm < 3; ++arm) run(arm);
@@ -364,7 +367,7 @@ int main(int argc, char** argv) {
                "elements differing from the 8-wave kernel: %zu / %zu of %zu\n", M, N, K, worst[0], worst[1], worst[2], diff1, diff2, hO[0].size());
         fflush(stdout);
         // ---- timing: interleaved arms, `secs` of back-to-back launches each, three rounds; board power / clock sampled at 20 Hz
-        const char* names[3] = {"8-wave product kernel (kind 1)", "4-wave x 512 regs, LDS-DMA", "4-wave x 512 regs, register-staged"};
+        const char* names[3] = {"8-wave product kernel (kind 1)", "4-wave x 512 regs, plain epilogue", "4-wave x 512 regs, stores under MFMAs"};
         for (int round = 0; round < 3; ++round)
             for (int arm = 0; arm < 3; ++arm) {
                 hipEvent_t e0, e1;
