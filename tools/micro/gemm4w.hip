@@ -363,7 +363,7 @@ int main(int argc, char** argv) {
         }
         size_t diff1 = 0, diff2 = 0;
         for (size_t i = 0; i < hO[0].size(); ++i) { diff1 += hO[1][i] != hO[0][i]; diff2 += hO[2][i] != hO[0][i]; }
-        printf("shape M=%d N=%d K=%d: max rel error vs fp64 on 4000 entries: 8-wave %.2e, 4-wave LDS-DMA %.2e, 4-wave register-staged %.2e; "
+        printf("shape M=%d N=%d K=%d: max rel error vs fp64 on 4000 entries: 8-wave %.2e, 4-wave plain epilogue %.2e, 4-wave stores under MFMAs %.2e; "
                "elements differing from the 8-wave kernel: %zu / %zu of %zu\n", M, N, K, worst[0], worst[1], worst[2], diff1, diff2, hO[0].size());
         fflush(stdout);
         // ---- timing: interleaved arms, `secs` of back-to-back launches each, three rounds; board power / clock sampled at 20 Hz
