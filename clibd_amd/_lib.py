@@ -92,6 +92,9 @@ SIGNATURES = {
     "clibd_softce_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_softce_rows_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_topk_ip_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "clibd_topk_prepare_keys": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "clibd_topk_ip_fast_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "clibd_topk_ip_fast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_topk_ip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_kmer_tokenize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "clibd_layernorm_param_grads": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),

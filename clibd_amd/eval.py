@@ -77,11 +77,34 @@ def get_feature_and_label(dataloader, model, device, for_open_clip=False, multi_
     return file_name_list, out[0], out[1], out[2], label_list
 
 
-def topk_search(query_feature: torch.Tensor, keys_feature: torch.Tensor, max_k: int = 5):
-    """(similarities, indices) of IndexFlatIP.search on L2-normalised features."""
-    q, _ = ops.l2norm_fwd(query_feature.detach().to(torch.float32).contiguous())
+def prepare_key_bank(keys_feature: torch.Tensor) -> "ops.KeyBank":
+    """L2-normalise a key set and prepare it ONCE for the pre-filtered search (what the reference's faiss.IndexFlatIP(dim) +
+    index.add(keys) does once per key set, util/util.py:521-526)."""
     kf, _ = ops.l2norm_fwd(keys_feature.detach().to(torch.float32).contiguous())
-    return ops.topk_ip(q, kf, max_k)
+    return ops.KeyBank(kf)
+
+
+def topk_search(query_feature: torch.Tensor, keys_feature, max_k: int = 5, exact: bool = False):
+    """(similarities, indices) of IndexFlatIP.search on L2-normalised features.  `keys_feature`: a tensor, or a bank from
+    `prepare_key_bank` (re-used across query batches).  Large banks take the pre-filtered search (bf16 approximate scores, exact
+    fp32 re-score of every key inside the rigorous error band: indices and similarities identical to the exact kernel's); queries
+    it flags — candidate lists full inside the band, e.g. many duplicate keys — are re-run through the exact kernel.  exact=True
+    forces the exact kernel for everything."""
+    q, _ = ops.l2norm_fwd(query_feature.detach().to(torch.float32).contiguous())
+    bank = keys_feature if isinstance(keys_feature, ops.KeyBank) else None
+    if bank is None:
+        kf, _ = ops.l2norm_fwd(keys_feature.detach().to(torch.float32).contiguous())
+        if exact or kf.shape[1] % 64 != 0 or not (4096 <= kf.shape[0] < (1 << 24)):
+            return ops.topk_ip(q, kf, max_k)
+        bank = ops.KeyBank(kf)
+    if exact:
+        return ops.topk_ip(q, bank.keys, max_k)
+    sim, idx, ovf = ops.topk_ip_fast(q, bank, max_k)
+    bad = torch.nonzero(ovf).flatten()          # (host sync: the eval path hands numpy arrays back anyway)
+    if bad.numel():
+        s2, i2 = ops.topk_ip(q[bad].contiguous(), bank.keys, max_k)
+        sim[bad], idx[bad] = s2, i2
+    return sim, idx
 
 
 def make_prediction(query_feature, keys_feature, keys_label: List[dict], with_similarity=False, with_indices=False, max_k=5, device=None):
@@ -89,7 +112,8 @@ def make_prediction(query_feature, keys_feature, keys_label: List[dict], with_si
     optionally followed by the similarity and index arrays (numpy, like faiss)."""
     dev = device or (query_feature.device if torch.is_tensor(query_feature) else torch.device("cuda"))
     qf = torch.as_tensor(np.asarray(query_feature) if not torch.is_tensor(query_feature) else query_feature).to(dev)
-    kf = torch.as_tensor(np.asarray(keys_feature) if not torch.is_tensor(keys_feature) else keys_feature).to(dev)
+    kf = keys_feature if isinstance(keys_feature, ops.KeyBank) else \
+        torch.as_tensor(np.asarray(keys_feature) if not torch.is_tensor(keys_feature) else keys_feature).to(dev)
     sim, idx = topk_search(qf, kf, max_k)
     idx_h, sim_h = idx.cpu().numpy(), sim.cpu().numpy()
     pred_list = [{level: [keys_label[i][level] for i in row] for level in LEVELS} for row in idx_h]

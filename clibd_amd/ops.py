@@ -668,6 +668,42 @@ def topk_ip(q: torch.Tensor, keys: torch.Tensor, k: int = 5):
     return sim, idx
 
 
+class KeyBank:
+    """A key bank prepared once for the pre-filtered search: the fp32 keys, their bf16 image and max ||key|| (clibd_topk_prepare_keys).
+    The reference builds one faiss.IndexFlatIP per key set and searches it with every query batch (util/util.py:521-528)."""
+
+    def __init__(self, keys: torch.Tensor):
+        _chk(keys, F32, "keys")
+        Nk, D = keys.shape
+        if D % 64 != 0 or Nk >= 1 << 24:
+            raise ValueError("KeyBank: the pre-filtered search needs D % 64 == 0 and fewer than 2^24 keys (use topk_ip)")
+        self.keys = keys
+        self.keys_bf16 = torch.empty((Nk, D), dtype=BF16, device=keys.device)
+        self.max_norm = torch.empty((1,), dtype=F32, device=keys.device)
+        check(_lib.load().clibd_topk_prepare_keys(keys.data_ptr(), Nk, D, self.keys_bf16.data_ptr(), self.max_norm.data_ptr(), _stream()),
+              "topk_prepare_keys")
+
+
+def topk_ip_fast(q: torch.Tensor, bank: "KeyBank", k: int = 5):
+    """clibd_topk_ip_fast: the top-k of `topk_ip` — same indices, same similarities, bit for bit — from bf16 approximate scores
+    followed by an exact re-score of every key within the rigorous error band of the k-th best.  Returns (sim, idx, overflow):
+    overflow int32 [Q] flags the queries whose candidate lists were full inside the band (their rows are unspecified; `topk_search`
+    re-runs them through the exact kernel)."""
+    _chk(q, F32, "q")
+    Q, D = q.shape
+    Nk = bank.keys.shape[0]
+    if bank.keys.shape[1] != D:
+        raise ValueError("topk_ip_fast: dimension mismatch")
+    idx = torch.empty((Q, k), dtype=I64, device=q.device)
+    sim = torch.empty((Q, k), dtype=F32, device=q.device)
+    ovf = torch.empty((Q,), dtype=I32, device=q.device)
+    lib = _lib.load()
+    ws = torch.empty((int(lib.clibd_topk_ip_fast_workspace_bytes(Q, Nk, D)),), dtype=torch.uint8, device=q.device)
+    check(lib.clibd_topk_ip_fast(q.data_ptr(), bank.keys.data_ptr(), bank.keys_bf16.data_ptr(), bank.max_norm.data_ptr(), Q, Nk, D, k, idx.data_ptr(),
+                                 sim.data_ptr(), ovf.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "topk_ip_fast")
+    return sim, idx, ovf
+
+
 def kmer_tokenize(seq_u8: torch.Tensor, k: int = 5) -> torch.Tensor:
     """uint8 [B,L] ('N'-padded ASCII) -> int64 [B, 1 + L/k] token ids."""
     _chk(seq_u8, torch.uint8, "seq_u8")

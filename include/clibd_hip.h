@@ -314,6 +314,19 @@ size_t clibd_topk_ip_workspace_bytes(int Q, int Nk);
 int clibd_topk_ip(const float* q, const float* keys, int Q, int Nk, int D, int k, int64_t* out_idx, float* out_sim,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same search, pre-filtered (round 4): indices and similarities BIT-IDENTICAL to clibd_topk_ip at the bf16 MFMA rate.
+ * clibd_topk_prepare_keys: once per key bank: keys_bf16 [Nk, D] (the bf16 image) and max_norm[0] = max_n ||key_n||.
+ * clibd_topk_ip_fast: approximate scores bf16(q) . bf16(key) streamed into running top-8 lists (no score matrix), then every listed key
+ * whose approximate score lies within 2 eps of the k-th largest one — eps = 0.0045 ||q|| max ||key|| bounds |approximate - exact| —
+ * is re-scored with the exact kernel's arithmetic (k-ordered fp32 fmaf chain) and the top k of those are returned (ties -> lower
+ * index).  The true top k are provably among the re-scored keys unless a list was full above that line: such queries are flagged
+ * overflow[q] = 1 (their outputs are then unspecified) and the caller re-runs them through clibd_topk_ip.  D % 64 == 0, Nk < 2^24.
+ * Replaces the same faiss.IndexFlatIP(...).search call (reference util/util.py:521-528). */
+int clibd_topk_prepare_keys(const float* keys, int Nk, int D, void* keys_bf16, float* max_norm, void* stream);
+size_t clibd_topk_ip_fast_workspace_bytes(int Q, int Nk, int D);
+int clibd_topk_ip_fast(const float* q, const float* keys, const void* keys_bf16, const float* max_norm, int Q, int Nk, int D, int k,
+                       int64_t* out_idx, float* out_sim, int32_t* overflow, void* workspace, size_t workspace_bytes, void* stream);
+
 /* f1 batch contract: k-mer tokenisation (model/dna_encoder.py:53-63 get_sequence_pipeline, util/util.py:77-98).
  * seq_u8 [B,L] ASCII, already truncated / 'N'-padded to L (660); out int64 [B, 1 + L/k]: leading 0, then 3 + base-4 value
  * (A0 C1 G2 T3, product('ACGT', repeat=k) order) or 2 (<UNK>) for a k-mer with any other character. */

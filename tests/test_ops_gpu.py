@@ -888,6 +888,54 @@ def test_topk_ties_prefer_lower_index(ops, dev):
     assert sim.cpu().tolist() == [[1.0, 1.0] + [0.5] * 6] * 70
 
 
+@pytest.mark.parametrize("Q,Nk,D,k", [(37, 5000, 768, 5), (130, 21000, 768, 5), (1024, 409600, 768, 5), (300, 70000, 128, 8), (3, 4096, 64, 1)])
+def test_topk_prefiltered_search_equals_the_exact_kernel(ops, dev, Q, Nk, D, k):
+    """clibd_topk_ip_fast (bf16 approximate scores, exact fp32 re-score of every key inside the rigorous error band of the k-th best)
+    returns the exact kernel's indices AND similarities bit for bit — the similarities because the re-score is the same k-ordered
+    fmaf chain the fp32 MFMA evaluates.  Random unit vectors: no query overflows its candidate lists."""
+    g = torch.Generator().manual_seed(Q + Nk)
+    keys = torch.nn.functional.normalize(torch.randn(Nk, D, generator=g), dim=1).to(dev)
+    q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g), dim=1)
+    q[0] = keys[Nk // 2].cpu()              # an exact match
+    q = q.to(dev)
+    bank = ops.KeyBank(keys)
+    assert abs(float(bank.max_norm) - 1.0) < 1e-4
+    assert torch.equal(bank.keys_bf16, keys.to(torch.bfloat16))
+    sim, idx, ovf = ops.topk_ip_fast(q, bank, k)
+    esim, eidx = ops.topk_ip(q, keys, k)
+    torch.cuda.synchronize()
+    assert int(ovf.sum()) == 0
+    assert torch.equal(idx, eidx)
+    assert torch.equal(sim, esim)
+
+
+def test_topk_prefiltered_search_flags_what_it_cannot_guarantee(ops, dev):
+    """Exactness never depends on the data: a bank with 3000 copies of one vector puts thousands of keys inside the error band, the
+    candidate lists fill up, the queries are flagged — and `eval.topk_search` re-runs exactly those through the exact kernel
+    (ties -> lower index, as faiss).  Unscaled (non-unit) vectors: the band scales with ||q|| max ||key||."""
+    from clibd_amd.eval import topk_search
+
+    g = torch.Generator().manual_seed(9)
+    Nk, D = 8192, 128
+    keys = torch.randn(Nk, D, generator=g)
+    keys[2000:5000] = keys[1999]                   # 3001 identical keys
+    q = torch.randn(40, D, generator=g)
+    q[:8] = keys[1999] + 0.01 * torch.randn(8, D, generator=g)    # these queries' best keys are the duplicates
+    keys, q = keys.to(dev), q.to(dev)
+    sim, idx, ovf = ops.topk_ip_fast(q, ops.KeyBank(keys), 5)
+    esim, eidx = ops.topk_ip(q, keys, 5)
+    torch.cuda.synchronize()
+    assert ovf[:8].all()                            # lists full inside the band
+    ok = ovf == 0
+    assert torch.equal(idx[ok], eidx[ok]) and torch.equal(sim[ok], esim[ok])     # everything not flagged is exact
+    assert eidx[:8, :5].cpu().tolist() == [[1999, 2000, 2001, 2002, 2003]] * 8
+    # the eval wrapper (L2-normalises, pre-filters, repairs the flagged rows): equal to the exact path everywhere
+    s1, i1 = topk_search(q, keys, 5)
+    s2, i2 = topk_search(q, keys, 5, exact=True)
+    torch.cuda.synchronize()
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+
+
 def test_kmer_tokenizer_matches_oracle(dev):
     from clibd_amd.eval import tokenize_barcodes
     from oracle import clibd_oracle as O
