@@ -128,13 +128,12 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 def _rank_slots(lp: "LoraParams"):
     """The kernels carry the adapters as rank 4 + 4 (q and v in one MFMA k-slot of 8).  The reference accepts any r > 0
     (image_encoder.py:53; every shipped config uses 4): ranks 1-3 run zero-padded — A gets zero rows, B zero columns, the same
-    product — and ranks 5-8 as TWO such slots, rows / columns 0-3 and 4-7 of every adapter matrix (B A x = B1 A1 x + B2 A2 x):
-    the second slot's down-projection, rank update and gradients take a pass of their own (TransformerStack._slot2_*).
+    product — and ranks above 4 as ceil(r / 4) such slots, rows / columns 4j .. 4j+3 of every adapter matrix
+    (B A x = sum_j B_j A_j x): every slot after the first takes a pass of its own for its down-projection, rank update and gradients
+    (TransformerStack._slot2_*; round 4: any r > 0, as the reference accepts — round 3 stopped at two slots, r <= 8).
     Returns [(a_q, a_v, b_q, b_v)] per slot, each [4,H] / [H,4] fp32."""
     a_q, a_v, b_q, b_v = _f32c(lp.a_q), _f32c(lp.a_v), _f32c(lp.b_q), _f32c(lp.b_v)
     r, H = a_q.shape
-    if r > 8:
-        raise NotSupportedYet("LoRA rank > 8 (two rank-4 slots per adapter)")
 
     def slot(lo):
         hi = min(lo + 4, r)
@@ -143,7 +142,7 @@ def _rank_slots(lp: "LoraParams"):
         pb = lambda b: (b[:, lo:hi] if k == 4 else torch.cat([b[:, lo:hi], b.new_zeros((H, 4 - k))], dim=1)).contiguous()
         return pa(a_q), pa(a_v), pb(b_q), pb(b_v)
 
-    return [slot(0)] + ([slot(4)] if r > 4 else [])
+    return [slot(lo) for lo in range(0, r, 4)]
 
 
 class TransformerStack:
@@ -265,16 +264,17 @@ class TransformerStack:
                 c.v_fwd, c.v_bwd, c.a_cat, c.w_dt = im["v_fwd"], im["v_bwd"], im["a_cat"], im["w_dt"]
             slots = _rank_slots(L.lora)
             ops.lora_pack(*slots[0], c.v_fwd, c.v_bwd, c.a_cat, c.w_dt)
-            if len(slots) > 1:      # ranks 5-8: the second rank-(4+4) slot
+            if len(slots) > 1:      # ranks above 4: one more rank-(4+4) slot per four ranks (c.slot2: the list of their operand images)
                 if self.fp8 is not None:
                     raise NotSupportedYet("fp8 forward with LoRA rank > 4")
-                if c.slot2 is None:
-                    c.slot2 = images()
-                ops.lora_pack(*slots[1], c.slot2["v_fwd"], c.slot2["v_bwd"], c.slot2["a_cat"], c.slot2["w_dt"])
+                if c.slot2 is None or len(c.slot2) != len(slots) - 1:
+                    c.slot2 = [images() for _ in slots[1:]]
+                for sl, im in zip(slots[1:], c.slot2):
+                    ops.lora_pack(*sl, im["v_fwd"], im["v_bwd"], im["a_cat"], im["w_dt"])
             else:
                 c.slot2 = None
 
-    # ---- second rank slot (4 < r <= 8): a pass built from the existing kernels — a zero-operand GEMM whose rank-8 MFMA step
+    # ---- further rank slots (r > 4): a pass each, built from the existing kernels — a zero-operand GEMM whose rank-8 MFMA step
     # carries u . V^T into an fp32 addend, which the layer's real GEMM then takes as its fp32 residual: ONE rounding of the sum,
     # as in the reference's B(A x) over all r columns
     def _slot2_addend(self, u, v, N, residual=None):
@@ -285,9 +285,21 @@ class TransformerStack:
         return out
 
     def _slot2_fwd(self, c, x_bf16):
-        """(fp32 [M,3H] addend (x A2^T) B2^T on the q and v columns, t2) of the second rank slot."""
-        t2 = ops.lora_down_proj(x_bf16, c.slot2["a_cat"])
-        return self._slot2_addend(t2, c.slot2["v_fwd"], 3 * self.H), t2
+        """(fp32 [M,3H] addend sum_j (x A_j^T) B_j^T over the slots j >= 1 on the q and v columns, [t_j]): the slots chain through the
+        addend (each zero-operand GEMM takes the previous sum as its fp32 residual), so the layer's GEMM still rounds the whole sum once."""
+        add32, ts = None, []
+        for im in c.slot2:
+            tj = ops.lora_down_proj(x_bf16, im["a_cat"])
+            add32 = self._slot2_addend(tj, im["v_fwd"], 3 * self.H, residual=add32)
+            ts.append(tj)
+        return add32, ts
+
+    def _slot2_bwd_addend(self, c, dt2, residual=None):
+        """fp32 [M,H] sum_j dt_j . A_cat_j over the slots j >= 1 (+ residual): joins the QKV dgrad as its fp32 addend."""
+        add32 = residual
+        for im, dtj in zip(c.slot2, dt2):
+            add32 = self._slot2_addend(dtj, im["v_bwd"], self.H, residual=add32)
+        return add32
 
     def lora_a(self, i: int):
         if i >= len(self.layers) or self.layers[i].lora is None:
@@ -331,7 +343,7 @@ class TransformerStack:
             has_lora = L.lora is not None
             rec = {}
             att_sv = None
-            t2 = None   # second rank slot's down-projection (LoRA ranks 5-8)
+            t2 = None   # further rank slots' down-projections (LoRA ranks above 4): a list
             f8 = f8s[i] if f8s is not None else None
             crec = {} if cal is not None else None
             if keep:
@@ -509,7 +521,7 @@ class TransformerStack:
         for i in range(len(self.layers) - 1, -1, -1):
             L, c, rec = self.layers[i], self._cache[i], saved[i]
             has_lora = L.lora is not None
-            dt2 = None   # second rank slot's dt (LoRA ranks 5-8), set by _lora_grads
+            dt2 = None   # further rank slots' dt (LoRA ranks above 4): a list, set by _lora_grads
             if i < first_lora:
                 break  # nothing trainable at or below this layer
             if self.pre_ln and rec.get("cls_only"):
@@ -529,7 +541,7 @@ class TransformerStack:
                     dt2 = self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads, rec.get("t2"))
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
-                    add32 = None if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H)      # second rank slot: dt2 . A_cat2, fp32
+                    add32 = None if dt2 is None else self._slot2_bwd_addend(c, dt2)      # further rank slots: sum_j dt_j . A_cat_j, fp32
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, residual=add32, out_bf16=dtmp)
                     if r16:
                         dres16, _ = ops.scatter_rows(dx1_f32, S, bf16=True, f32=False)           # residual path: class rows only
@@ -560,7 +572,7 @@ class TransformerStack:
                     dt2 = self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads, rec.get("t2"))
                 wg(dqkv, rec["xn"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
-                    add32 = None if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H)      # second rank slot: dt2 . A_cat2, fp32
+                    add32 = None if dt2 is None else self._slot2_bwd_addend(c, dt2)      # further rank slots: sum_j dt_j . A_cat_j, fp32
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, residual=add32, out_bf16=dtmp)
                     if r16:
                         ndx_f32, ndx_bf16 = (new(H, F32) if (full and i == 0) else None), new(H, BF16)
@@ -596,7 +608,7 @@ class TransformerStack:
                     dt2 = self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads, rec.get("t2"))
                 wg(dqkv, rec["x_bf16"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
-                    add32 = None if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H)
+                    add32 = None if dt2 is None else self._slot2_bwd_addend(c, dt2)
                     if full and i == 0:   # the embedding backward takes an fp32 gradient (generic epilogue: one launch per tower)
                         ndx = new(H, F32)
                         ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
@@ -624,7 +636,7 @@ class TransformerStack:
                 wg(dqkv, rec["x_bf16"], L.qkv_w, L.qkv_b)
                 if i > first_lora:
                     ndx = new(H, F32)
-                    res32 = ds1_f32 if dt2 is None else self._slot2_addend(dt2, c.slot2["v_bwd"], H, residual=ds1_f32)
+                    res32 = ds1_f32 if dt2 is None else self._slot2_bwd_addend(c, dt2, residual=ds1_f32)
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None,
                                 residual=res32, out_f32=ndx)
                     dx_f32 = ndx
@@ -641,8 +653,8 @@ class TransformerStack:
     def _lora_grads(self, L, c, dqkv, x_bf16, t, dt, grads, t2=None):
         """dt[:, 0:4] = dq·B_q, dt[:, 4:8] = dv·B_v (the rank-8 operand of the QKV dgrad that follows) and the four adapter gradients
         in one call: dq and dv are streamed once for dt and dB together (clibd_lora_backward); the k segment of dqkv is never read.
-        Ranks other than 4 run on rank-4 slots (_rank_slots): scratch gradients, sliced back; ranks 5-8 take a second call with the
-        second slot's images and down-projection t2, whose dt (returned) joins the QKV dgrad as an fp32 addend (_slot2_addend)."""
+        Ranks other than 4 run on rank-4 slots (_rank_slots): scratch gradients, sliced back; ranks above 4 take one more call per slot
+        with that slot's images and down-projection t2[j], whose dt (returned as a list) join the QKV dgrad as an fp32 addend (_slot2_bwd_addend)."""
         H = self.H
         lp = L.lora
         r = lp.a_q.shape[0]
@@ -650,19 +662,22 @@ class TransformerStack:
             ops.lora_backward(dqkv, x_bf16, t, c.w_dt, dt, grads[id(lp.a_q)], grads[id(lp.a_v)], grads[id(lp.b_q)], grads[id(lp.b_v)])
             return None
         dev = dqkv.device
-        dt2 = None
-        for k, (tk, w_dt, dtk) in enumerate(((t, c.w_dt, dt), (t2, None if c.slot2 is None else c.slot2["w_dt"], None))):
+        dt2 = []
+        nslots = (r + 3) // 4
+        for k in range(nslots):
             lo = 4 * k
-            if lo >= r:
-                break
-            if k == 1:
-                dtk = dt2 = torch.empty_like(dt)
+            if k == 0:
+                tk, w_dt, dtk = t, c.w_dt, dt
+            else:
+                tk, w_dt, dtk = t2[k - 1], c.slot2[k - 1]["w_dt"], torch.empty_like(dt)
+                dt2.append(dtk)
             ga_q, ga_v = torch.zeros((4, H), dtype=F32, device=dev), torch.zeros((4, H), dtype=F32, device=dev)
             gb_q, gb_v = torch.zeros((H, 4), dtype=F32, device=dev), torch.zeros((H, 4), dtype=F32, device=dev)
             ops.lora_backward(dqkv, x_bf16, tk, w_dt, dtk, ga_q, ga_v, gb_q, gb_v)
             n = min(4, r - lo)   # the padded rows / columns receive exact zeros' worth of signal
             grads[id(lp.a_q)][lo:lo + n].add_(ga_q[:n]); grads[id(lp.a_v)][lo:lo + n].add_(ga_v[:n])
             grads[id(lp.b_q)][:, lo:lo + n].add_(gb_q[:, :n]); grads[id(lp.b_v)][:, lo:lo + n].add_(gb_v[:, :n])
+        dt2 = dt2 or None
         return dt2
 
 

@@ -213,8 +213,6 @@ class CLIBDDNAEncoder(nn.Module):
     def __init__(self, model, r: int, num_classes: int = 0, lora_layer=None):
         super().__init__()
         assert r > 0
-        if r > 8:
-            raise NotImplementedError("the HIP LoRA path carries ranks 1-8 (one or two rank-(4+4) MFMA k-slots for q + v; every reference config uses r=4)")
         # reference: `is not None` — an empty list really disables LoRA here (dna_encoder.py:85-88)
         self.lora_layer = lora_layer if lora_layer is not None else list(range(len(model.bert.encoder.layer)))
         self.w_As, self.w_Bs = [], []

@@ -121,8 +121,6 @@ class CLIBDImageEncoder(nn.Module):
     def __init__(self, vit_model, r: int, num_classes: int = 0, lora_layer=None):
         super().__init__()
         assert r > 0
-        if r > 8:
-            raise NotImplementedError("the HIP LoRA path carries ranks 1-8 (one or two rank-(4+4) MFMA k-slots for q + v; every reference config uses r=4)")
         # reference quirk (image_encoder.py:54-57): `if lora_layer:` — an empty list still wraps every block
         self.lora_layer = lora_layer if lora_layer else list(range(len(vit_model.blocks)))
         self.w_As, self.w_Bs = [], []

@@ -38,8 +38,6 @@ class CLIBDLanguageEncoder(nn.Module):
     def __init__(self, model, r: int, num_classes: int = 0, lora_layer=None):
         super().__init__()
         assert r > 0
-        if r > 8:
-            raise NotImplementedError("the HIP LoRA path carries ranks 1-8 (one or two rank-(4+4) MFMA k-slots for q + v; every reference config uses r=4)")
         self.lora_layer = lora_layer if lora_layer is not None else list(range(len(model.encoder.layer)))
         self.w_As, self.w_Bs = [], []
         for p in model.parameters():

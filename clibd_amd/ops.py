@@ -436,7 +436,7 @@ def lora_pack(a_q, a_v, b_q, b_v, v_fwd, v_bwd, a_cat, w_dt) -> None:
 
 
 def lora_down_proj(x: torch.Tensor, a_cat: torch.Tensor) -> torch.Tensor:
-    """t [M,8] = bf16(x [M,H] . a_cat [8,H]^T): the adapters' down-projection as its own kernel (second rank slot, 4 < r <= 8)."""
+    """t [M,8] = bf16(x [M,H] . a_cat [8,H]^T): the adapters' down-projection as its own kernel (rank slots after the first, r > 4)."""
     _chk(x, BF16, "x", contiguous=False)
     _chk(a_cat, BF16, "a_cat")
     M, H = x.shape
