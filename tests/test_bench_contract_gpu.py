@@ -34,5 +34,12 @@ def test_bench_prints_exactly_one_json_line(forced):
     assert roof["bound"] == "mfma" and roof["peak"] == 2500.0 and 0 < roof["frac"] < 1
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert "workload" in d["config"] and "model" not in d["config"]
+    # round 4: what arithmetic produced the line, and what the host paid to enqueue it
+    assert d["config"]["train_mode"] is True                      # the reference steps in model.train() (train_epoch.py:19)
+    num = d["config"]["numerics"]
+    assert set(num) == {"image_encoder", "dna_encoder"} and all(v["forward"] == "bf16" and v["residual_grad"] in ("bf16", "fp32") for v in num.values())
+    he = d["host_enqueue_ms"]
+    assert all(k in he for k in ("mean", "median", "p95", "cpu_mean", "cpu_median")) and 0 < he["cpu_median"] <= he["p95"] * 1.5 + 1.0
+    assert roof["step_frac_gflop_per_pair"] == 117.6
     if forced == "1":
         assert "collectives" in d
