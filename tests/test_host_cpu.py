@@ -317,3 +317,40 @@ def test_fused_adamw_follows_the_references_lr_schedulers(monkeypatch, sched):
     assert len(set(lrs)) > 1                      # the schedule moved, and the fused step saw it
     for a, b in zip(mine, ref):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (sched, (a - b).abs().max())
+
+
+def test_numerics_switches_are_explicit_settings(monkeypatch, tmp_path):
+    """the backward's arithmetic switches are per-stack settings.  The CLIBD_* environment variables only give the default
+    a tower is CONSTRUCTED with; `SimpleCLIP.set_numerics` / `Trainer(numerics=...)` change them per model; unknown names or values
+    raise; `save_training_state` records what produced a checkpoint; the fp8 tower selection validates its names."""
+    from clibd_amd import engine
+    from clibd_amd.checkpoint import save_training_state
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder, CLIBDImageEncoder, SimpleCLIP, VisionTransformer
+
+    def build():
+        ie = CLIBDImageEncoder(VisionTransformer(embed_dim=64, depth=1, num_heads=1, num_classes=0), 4, 32)
+        de = CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, hidden_size=64, num_hidden_layers=1, num_attention_heads=1,
+                                                            intermediate_size=128)), 4, 32)
+        return SimpleCLIP(ie, de, None)
+
+    monkeypatch.delenv("CLIBD_GELU_GRAD", raising=False)
+    monkeypatch.delenv("CLIBD_RESIDUAL_GRAD", raising=False)
+    a = build()
+    assert a.numerics()["image_encoder"] == dict(residual_grad="bf16", gelu_grad="bf16", attn_bwd="2phase", forward="bf16")
+    monkeypatch.setenv("CLIBD_GELU_GRAD", "u8")
+    b = build()                                    # the variable is read at construction ...
+    assert b.numerics()["dna_encoder"]["gelu_grad"] == "u8" and a.numerics()["dna_encoder"]["gelu_grad"] == "bf16"   # ... not by `a`
+    a.set_numerics(residual_grad="fp32")           # two models of one process differ
+    assert a.numerics()["image_encoder"]["residual_grad"] == "fp32" and b.numerics()["image_encoder"]["residual_grad"] == "bf16"
+    with pytest.raises(ValueError):
+        a.set_numerics(residual_grad="fp16")
+    with pytest.raises(ValueError):
+        a.set_numerics(no_such_switch="x")
+    assert engine.check_numerics(dict(attn_bwd="sp")) == dict(attn_bwd="sp")
+    path = tmp_path / "state.pth"
+    save_training_state(str(path), a, epoch=3)
+    st = torch.load(str(path), map_location="cpu", weights_only=False)
+    assert st["numerics"]["image_encoder"]["residual_grad"] == "fp32" and st["epoch"] == 3
+    with pytest.raises(ValueError):
+        a.enable_fp8_forward(towers=("vision_tower",))
+    assert SimpleCLIP.FP8_TOWER_SETS["pooled"] == ("dna_encoder", "language_encoder")

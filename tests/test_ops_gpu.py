@@ -1145,3 +1145,36 @@ def test_layernorm_bwd_bf16_residual_stream(ops, dev, M, H, f32dy, drop):
         assert torch.equal(nores.cpu(), res.cpu())
     with pytest.raises(ValueError):
         ops.layernorm_bwd(dyd, x.to(dev), st, gam.to(dev), dres=dres16.float(), dres_bf16=dres16, dx_bf16=nores)
+
+
+@pytest.mark.parametrize("M,H,f32dy,drop", [(777, 768, False, True), (5000, 768, True, False), (64, 512, False, False)])
+def test_layernorm_bwd_any_bf16_stream_with_param_grads(ops, dev, M, H, f32dy, drop):
+    """clibd_layernorm_bwd_any (round 4: full fine-tune on the bf16 residual-gradient stream): the bf16-stream backward with
+    d(gamma), d(beta) accumulated in the same pass and, for the bottom layer, an fp32 dx beside the bf16 copies — every output equal
+    to what the separate entry points give (res16 for dx, pg for the parameter gradients), bit for bit."""
+    g = torch.Generator().manual_seed(M * 3 + H)
+    x = (torch.randn(M, H, generator=g) * 2 + 0.3).to(dev)
+    gam, bet = torch.randn(H, generator=g).to(dev), torch.randn(H, generator=g).to(dev)
+    dy = torch.randn(M, H, generator=g)
+    dyd = dy.to(dev) if f32dy else dy.to(dev, BF16)
+    st = torch.empty((M, 2), device=dev)
+    y = torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_fwd(x, gam, bet, 1e-6, y_bf16=y, stats=st)
+    d = ops.Drop(0.1, 99) if drop else None
+    dres16 = torch.randn(M, H, generator=g).to(dev, BF16)
+    # references: the two existing entry points
+    res_r, msk_r = torch.empty((M, H), dtype=BF16, device=dev), torch.empty((M, H), dtype=BF16, device=dev)
+    ops.layernorm_bwd(dyd, x, st, gam, dres_bf16=dres16, dx_res_bf16=res_r, dx_bf16=msk_r, drop=d)
+    dxf_r, dxb_r = torch.empty((M, H), device=dev), torch.empty((M, H), dtype=BF16, device=dev)
+    dg_r, db_r = torch.zeros((H,), device=dev), torch.zeros((H,), device=dev)
+    ops.layernorm_bwd(dyd, x, st, gam, dres=dres16.float(), dx_f32=dxf_r, dx_bf16=dxb_r, drop=d, dgamma=dg_r, dbeta=db_r)
+    # the general entry: bf16 residual in, all three outputs, parameter gradients
+    res, msk, dxf = torch.empty((M, H), dtype=BF16, device=dev), torch.empty((M, H), dtype=BF16, device=dev), torch.empty((M, H), device=dev)
+    dg, db = torch.zeros((H,), device=dev), torch.zeros((H,), device=dev)
+    ops.layernorm_bwd(dyd, x, st, gam, dres_bf16=dres16, dx_res_bf16=res, dx_bf16=msk, dx_f32=dxf, drop=d, dgamma=dg, dbeta=db)
+    torch.cuda.synchronize()
+    assert torch.equal(res, res_r) and torch.equal(msk, msk_r) and torch.equal(dxf, dxf_r)
+    # float atomics over blocks: equal up to summation order
+    assert rel_err(dg.cpu(), dg_r.cpu().double()) < 1e-5 and rel_err(db.cpu(), db_r.cpu().double()) < 1e-5
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(dyd, x, st, gam, dres_bf16=dres16, dx_res_bf16=res, dgamma=dg)       # d(gamma) and d(beta) come together
