@@ -139,7 +139,9 @@ __device__ long long* g_att_stamps = nullptr;   // [workgroup][8]
 // NW: waves per workgroup (4; 3 for nine query tiles — S in (128, 144], the DNA tower — where four waves would take 3 + 2 + 2 + 2 tiles
 // one by one or, two at a time, 2 + 1 + 1 + 1 pairs of which the last is half padding: three waves take 3 + 3 + 3 single tiles, capped at
 // three waves per SIMD so that four such workgroups share a CU).
-template <int NKT, bool PAIR, bool MASK, bool DROP, int NW = ATT_WAVES>  // NKT: number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32); PAIR: two query tiles per sweep
+// IMG: rows per LDS image (S_pad; 144 in the three-wave form: the all-padding tile 9 is never read from the K image, and rows 144 .. 159 of the
+// V image, read by the last k-slot against probabilities that are exactly 0, are a zeroed 2-KiB pad: 38 912 B per workgroup, four per CU)
+template <int NKT, bool PAIR, bool MASK, bool DROP, int NW = ATT_WAVES, int IMG = 16 * NKT>  // NKT: number of 16-key tiles, even (S_pad = 16*NKT, multiple of 32); PAIR: two query tiles per sweep
 __global__ __launch_bounds__(64 * NW, (NW == 3 ? 3 : 2)) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ out, float scale,
@@ -151,8 +153,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 3 ? 3 : 2)) void attention_fwd_kern
     // scores, [B * nheads, S] fp32, and the bf16 residual of the output rounding (store_rows16_lo), laid out like `out`
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S_pad = 16 * NKT;
+    static_assert(IMG == S_pad || (IMG == S_pad - 16 && !PAIR), "a short image drops exactly the all-padding last tile (one query tile per sweep only)");
     char* kt_lds = smem;
-    char* vt_lds = smem + S_pad * 128;
+    char* vt_lds = smem + IMG * 128;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / nheads, h = blockIdx.x % nheads;
@@ -172,8 +175,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 3 ? 3 : 2)) void attention_fwd_kern
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (size_t)qc0 * ld + 32 * ks + 8 * g);
     }
-    stage_head_tile(kt_lds, qbase + H, ld, S, S_pad, wave, lane, NW);
-    stage_head_tile(vt_lds, qbase + 2 * H, ld, S, S_pad, wave, lane, NW);
+    stage_head_tile(kt_lds, qbase + H, ld, S, IMG, wave, lane, NW);
+    stage_head_tile(vt_lds, qbase + 2 * H, ld, S, IMG, wave, lane, NW);
+    if constexpr (IMG < S_pad) {
+        for (int r = threadIdx.x; r < (S_pad - IMG) * 8; r += 64 * NW) *(uint4*)(vt_lds + IMG * 128 + 16 * r) = make_uint4(0u, 0u, 0u, 0u);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -1198,6 +1204,7 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
     const int total = B * nheads;
     const size_t ldsp = (size_t)2 * lds;
     static const bool three_waves = [] { const char* e = getenv("CLIBD_ATTN_FWD_WAVES"); return !(e && e[0] == '4'); }();
+    const size_t lds3 = (size_t)2 * 144 * 128 + 16 * 128;   // three-wave form: two 144-row images + the zeroed pad
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
         if (N >= 12 && total >= 2 * num_cus) {   /* S > 160: at S = 133 only 9 of the 16 waves have a tile and the per-head kernel wins */ \
@@ -1207,8 +1214,8 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
                                (const unsigned short*)qkv, S, nheads, total, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
                                drop_seed, drop_thr16, drop_scale, out_fp8_scale, lse, (unsigned short*)o_lo);      \
         } else if (N == 10 && S <= 144 && S > 128 && nq > 128 && three_waves) {   /* nine query tiles: 3 + 3 + 3 on three waves */ \
-            hipFuncSetAttribute((const void*)attention_fwd_kernel<10, false, MSK, DRP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((attention_fwd_kernel<10, false, MSK, DRP, 3>), dim3(B * nheads), dim3(192), lds, st,   \
+            hipFuncSetAttribute((const void*)attention_fwd_kernel<10, false, MSK, DRP, 3, 144>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
+            hipLaunchKernelGGL((attention_fwd_kernel<10, false, MSK, DRP, 3, 144>), dim3(B * nheads), dim3(192), lds3, st,   \
                                (const unsigned short*)qkv, S, nheads, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
                                drop_seed, drop_thr16, drop_scale, out_fp8_scale, lse, (unsigned short*)o_lo);      \
         } else {                                                                                                  \
