@@ -205,7 +205,8 @@ def _attn_ref(qkv, B, S, nh, mask):
 @pytest.mark.parametrize("B,S,nh,masked", [(2, 197, 2, False), (3, 133, 3, False), (4, 20, 2, True), (1, 32, 1, False), (2, 64, 1, True),
                                            (1, 256, 1, False), (2, 7, 1, False),
                                            # nine-tile sequences (S in (128, 144]) take the three-wave workgroups; 129 and 144 are its edges, 150 / 160 stay on four
-                                           (2, 129, 2, False), (5, 144, 3, False), (2, 150, 2, False), (1, 160, 1, False), (40, 133, 12, False)])
+                                           (2, 129, 2, False), (5, 144, 3, False), (2, 150, 2, False), (1, 160, 1, False), (40, 133, 12, False),
+                                           (3, 140, 2, True)])   # a key mask on a nine-tile sequence: three-wave forward, four-wave (masked) backward
 def test_attention_fwd_bwd(ops, dev, B, S, nh, masked):
     g = torch.Generator().manual_seed(S * 3 + nh)
     H = nh * 64
