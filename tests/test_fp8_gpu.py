@@ -395,3 +395,46 @@ def test_fp8_gradients_on_spread_embeddings(dev):
             assert c >= 0.98 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # training-grade: VERDICT r3 item 1's gate (measured 0.9846 - 0.9993; DNA rows move by 5e-3 - 3e-2)
         else:
             assert c > 0.15 and de < 0.3, (k, c, de)                      # embedding-grade: the floor round 3's measurement set
+
+
+def test_fp8_pooled_selection_covers_the_text_tower(dev):
+    """Tri-modal model (BASELINE configs[3] + configs[4]): the default fp8 selection puts BarcodeBERT AND BERT-small (H = 512, key
+    mask, mean over 20 positions: the other token-averaging head) on fp8 operands and leaves the ViT alone.  Embeddings stay within the
+    mode's distance of the bf16 path on the pooled towers, the image rows are bit-identical, a training step runs and learns."""
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import (CLIBDDNAEncoder, CLIBDImageEncoder, CLIBDLanguageEncoder, SimpleCLIP, create_vit, load_pre_trained_bert,
+                                 load_pre_trained_bioscan_bert)
+    from clibd_amd.train import Trainer
+
+    torch.manual_seed(17)
+    model = SimpleCLIP(CLIBDImageEncoder(create_vit("vit_base_patch16_224"), r=4, num_classes=768),
+                       CLIBDDNAEncoder(load_pre_trained_bioscan_bert(None), r=4, num_classes=768),
+                       CLIBDLanguageEncoder(load_pre_trained_bert()[1], r=4, num_classes=768))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "linear_b_" in n or ".w_b." in n:
+                p.normal_(0, 0.02)
+    model = model.to(dev).eval()
+    B = 32
+    batch = synthetic_batch(B, dev, seed=3, rank=0, with_text=True)
+
+    def emb():
+        with torch.no_grad():
+            out = model(batch["image"], batch["dna"], batch["text"])
+        model.join_streams()
+        torch.cuda.synchronize()
+        return [o.float().cpu() for o in out[:3]]
+
+    i16, d16, t16 = emb()
+    model.enable_fp8_forward(calibration_inputs=(batch["image"], batch["dna"], batch["text"]))     # towers="pooled"
+    assert model.image_encoder.tower().stack.fp8 is None
+    assert model.dna_encoder.tower().stack.fp8 is not None and len(model.language_encoder.tower().stack.fp8) == 4
+    i8, d8, t8 = emb()
+    cosr = lambda a, b: ((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).min().item()
+    assert torch.equal(i8, i16)
+    assert cosr(d8, d16) > 0.999 and cosr(t8, t16) > 0.99, (cosr(d8, d16), cosr(t8, t16))
+    assert (d8 - d16).abs().max() < 2e-2 and (t8 - t16).abs().max() < 5e-2
+    tr = Trainer(model.train(), lr=1e-3, world_size=1, rank=0, all_gather=True, fp8_recalibrate_every=2)
+    losses = [float(tr.step(batch["image"], batch["dna"], batch["text"], batch["labels"])) for _ in range(4)]
+    assert all(l == l and l < 1e4 for l in losses) and losses[-1] < losses[0], losses
+    assert model.image_encoder.tower().stack.fp8 is None and model.language_encoder.tower().stack.fp8 is not None   # the selection survives re-calibration
