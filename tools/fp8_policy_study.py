@@ -6,7 +6,8 @@ each candidate buys on the full-size towers (ViT-B/16 + BERT-base, batch 16, ada
 batch so that the embeddings are spread):
 
   tensor    : round 3 — one power-of-two scale per layer and site for activations, one scale per weight row
-  mx32      : MXFP8 — e4m3 payload with an E8M0 (power-of-two) scale per 32 consecutive K elements, both operands
+  mx32      : MXFP8 — e4m3 payload with an E8M0 (power-of-two) scale per 32 consecutive K elements, both operands (scale per the OCP
+              MX rule); mx32_noclip: the smallest power-of-two scale that does not saturate the block maximum
   cls_bf16  : `tensor`, but the class-token row of every ViT block (the only row the image embedding reads) is recomputed on
               bf16 operands in all four GEMMs (1/197 of the rows); BERT unchanged (its head averages 133 tokens)
   mx32+cls  : both
@@ -40,13 +41,19 @@ def e4m3(x):
     return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
 
 
+MX_NOCLIP = False
+
+
 def mx_quant(x):
-    """MXFP8 along the last axis: per 32 elements a power-of-two scale 2^(floor(log2 amax) - 8) (e4m3's largest binade is 2^8),
-    payload e4m3(x / scale).  Returns the de-quantised values (what the block-scaled MFMA multiplies)."""
+    """MXFP8 along the last axis: per 32 elements a power-of-two (E8M0) scale, payload e4m3(x / scale).  Scale as the OCP MX
+    specification derives it, 2^(floor(log2 amax) - 8) (e4m3's largest binade is 2^8; a block maximum with a mantissa above 1.75
+    then saturates at 448), or — MX_NOCLIP — the smallest power of two that keeps the block maximum representable,
+    2^ceil(log2(amax / 448)).  Returns the de-quantised values (what the block-scaled MFMA multiplies)."""
     shp = x.shape
     xb = x.reshape(-1, shp[-1] // 32, 32)
     amax = xb.abs().amax(dim=-1, keepdim=True)
-    e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax)))) - 8.0
+    safe = torch.where(amax > 0, amax, torch.ones_like(amax))
+    e = torch.ceil(torch.log2(safe / 448.0)) if MX_NOCLIP else torch.floor(torch.log2(safe)) - 8.0
     s = torch.exp2(e)
     return (e4m3(xb / s) * s).reshape(shp)
 
@@ -62,12 +69,14 @@ class PolicyLinear(torch.autograd.Function):
             return F.linear(rb(xf), rb(wf))
         if POLICY["in_image"] and frm is not None and blk is not None and blk >= frm:
             return F.linear(rb(xf), rb(wf))
+        global MX_NOCLIP
+        MX_NOCLIP = POLICY["gran"] == "mx32_noclip"
         if POLICY["gran"] == "act_only":       # diagnostic: e4m3 activations against bf16 weights (no such MFMA exists)
             y = F.linear(e4m3(xf * sa), rb(wf)) * (1.0 / sa)
         elif POLICY["gran"] == "w_only":       # diagnostic: bf16 activations against e4m3 weights
             w8, sn = O.quantize_rows_e4m3(wf)
             y = F.linear(rb(xf), w8) * (1.0 / sn).view(-1)
-        elif POLICY["gran"] == "mx32":
+        elif POLICY["gran"] in ("mx32", "mx32_noclip"):
             y = F.linear(mx_quant(xf), mx_quant(wf))
         else:
             w8, sn = O.quantize_rows_e4m3(wf)
@@ -142,6 +151,7 @@ def main():
                 ("dna_only", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True)),
                 ("dna_only_mx32", dict(gran="mx32", cls_bf16=False, bf16_from_block=None, image_bf16=True)),
                 ("mx32", dict(gran="mx32", cls_bf16=False, bf16_from_block=None)),
+                ("mx32_noclip", dict(gran="mx32_noclip", cls_bf16=False, bf16_from_block=None)),
                 ("act_only", dict(gran="act_only", cls_bf16=False, bf16_from_block=None)),
                 ("w_only", dict(gran="w_only", cls_bf16=False, bf16_from_block=None)),
                 ("cls_bf16", dict(gran="tensor", cls_bf16=True, bf16_from_block=None)),
