@@ -13,6 +13,8 @@ batch so that the embeddings are spread):
   mx32+cls  : both
   lastK_bf16: `tensor` with the last K ViT blocks entirely bf16
   dna_only  : the image tower entirely bf16, only the DNA tower (whose head averages its 133 tokens) on fp8 operands
+  tensor_cal: per-tensor activation scales as a calibration pass sets them (2^floor(log2(448 / (2 amax))) of the tensor itself)
+  STUDY_OUTLIER_GAIN=g (environment): four channels of every LayerNorm weight multiplied by g before anything else (outlier channels)
   act_only / w_only : diagnostics (no such MFMA exists): only the activations / only the weights quantised to e4m3
 
 Reports max |embedding - bf16 embedding| per tower, |loss difference| and the cosine of the full trainable gradient against the
@@ -80,6 +82,8 @@ class PolicyLinear(torch.autograd.Function):
             y = F.linear(mx_quant(xf), mx_quant(wf))
         else:
             w8, sn = O.quantize_rows_e4m3(wf)
+            if POLICY["gran"] == "tensor_cal":      # the scale a calibration pass would set for this very tensor: 2^floor(log2(448 / (2 amax)))
+                sa = float(2.0 ** torch.floor(torch.log2(448.0 / (2.0 * xf.abs().amax().clamp_min(1e-30)))))
             y = F.linear(e4m3(xf * sa), w8) * (1.0 / (sn * sa)).view(-1)
         if POLICY["cls_bf16"] and POLICY["in_image"] and xf.dim() == 3:
             y = y.clone()
@@ -96,6 +100,9 @@ class PolicyLinear(torch.autograd.Function):
 O._Fp8Linear = PolicyLinear
 
 
+OUTLIERS = float(os.environ.get("STUDY_OUTLIER_GAIN", "0"))   # > 0: four channels of every LayerNorm weight are multiplied by this
+
+
 def build():
     torch.manual_seed(11)
     om = O.build_image_dna_model()
@@ -103,6 +110,12 @@ def build():
         for n, p in om.named_parameters():
             if "linear_b_" in n or ".w_b." in n:
                 p.normal_(0, 0.02)
+        if OUTLIERS > 0:    # outlier channels as trained checkpoints have them: the activations feeding every GEMM get a 30-50x dynamic range
+            g = torch.Generator().manual_seed(77)
+            for n, p in om.named_parameters():
+                if p.dim() == 1 and ("norm" in n.lower()) and n.endswith("weight"):
+                    idx = torch.randperm(p.numel(), generator=g)[:4]
+                    p[idx] *= OUTLIERS
     # block index for the lastK policy
     for i, blk in enumerate(om.image_encoder.base_image_encoder.blocks):
         orig = blk.forward
@@ -152,6 +165,9 @@ def main():
                 ("dna_only_mx32", dict(gran="mx32", cls_bf16=False, bf16_from_block=None, image_bf16=True)),
                 ("mx32", dict(gran="mx32", cls_bf16=False, bf16_from_block=None)),
                 ("mx32_noclip", dict(gran="mx32_noclip", cls_bf16=False, bf16_from_block=None)),
+                ("tensor_cal", dict(gran="tensor_cal", cls_bf16=False, bf16_from_block=None)),
+                ("dna_only_cal", dict(gran="tensor_cal", cls_bf16=False, bf16_from_block=None, image_bf16=True)),
+                ("dna_only_mx32_noclip", dict(gran="mx32_noclip", cls_bf16=False, bf16_from_block=None, image_bf16=True)),
                 ("act_only", dict(gran="act_only", cls_bf16=False, bf16_from_block=None)),
                 ("w_only", dict(gran="w_only", cls_bf16=False, bf16_from_block=None)),
                 ("cls_bf16", dict(gran="tensor", cls_bf16=True, bf16_from_block=None)),
