@@ -76,6 +76,7 @@ SIGNATURES = {
     "clibd_lora_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_lora_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_patchify": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "clibd_patchify_u8": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "clibd_vit_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "clibd_gelu_bwd_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "clibd_bert_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -109,7 +110,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 2   # what this binding was written against (clibd_abi_version(), csrc/capi.hip); load() refuses any other library
+ABI_VERSION = 3   # what this binding was written against (clibd_abi_version(), csrc/capi.hip); load() refuses any other library
 
 
 class ClibdHipError(RuntimeError):

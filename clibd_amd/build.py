@@ -53,14 +53,38 @@ def _stale(target: Path, srcs: list[Path]) -> bool:
     return any(s.stat().st_mtime > t for s in srcs)
 
 
+def _flags(name: str) -> list[str]:
+    """Every flag that changes the generated code of unit `name` (hashed into its stamp: ADVICE r4 — a changed --offload-arch or
+    optimisation flag must not leave old objects 'current')."""
+    f = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    if name == "capi":
+        f.append(f'-DCLIBD_CSRC_HASH="{csrc_hash()}"')   # clibd_build_hash(): checked by _lib.load() against the sources
+    if os.environ.get("CLIBD_GEMM_DIAG") == "1":
+        f.append("-DCLIBD_GEMM_DIAG")  # tools/gemm_stamps.py: s_memtime stamps + start-up skew knob (never in the product build)
+    return f
+
+
+_HIPCC_VERSION = None
+
+
+def _hipcc_version() -> str:
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            _HIPCC_VERSION = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout.strip()
+        except Exception:
+            _HIPCC_VERSION = "unknown"
+    return _HIPCC_VERSION
+
+
+def _link_stamp() -> str:
+    return f"{csrc_hash()} {ARCH}"
+
+
 def _compile_one(name: str, report: bool) -> tuple[str, str]:
     src = CSRC / f"{name}.hip"
     obj = OBJ / f"{name}.o"
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", str(src), "-o", str(obj)]
-    if name == "capi":
-        cmd.append(f'-DCLIBD_CSRC_HASH="{csrc_hash()}"')   # clibd_build_hash(): checked by _lib.load() against the sources
-    if os.environ.get("CLIBD_GEMM_DIAG") == "1":
-        cmd.append("-DCLIBD_GEMM_DIAG")  # tools/gemm_stamps.py: s_memtime stamps + start-up skew knob (never in the product build)
+    cmd = [_hipcc()] + _flags(name) + ["-c", str(src), "-o", str(obj)]
     if report:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -101,9 +125,8 @@ def _unit_hash(name: str) -> str:
     for f in [CSRC / f"{name}.hip"] + sorted(_deps()):
         h.update(f.name.encode())
         h.update(f.read_bytes())
-    h.update(os.environ.get("CLIBD_GEMM_DIAG", "0").encode())
-    if name == "capi":
-        h.update(csrc_hash().encode())
+    h.update("\0".join(_flags(name)).encode())   # arch, optimisation level, -D switches (capi: the csrc hash it embeds)
+    h.update(_hipcc_version().encode())
     return h.hexdigest()[:16]
 
 
@@ -138,13 +161,13 @@ def build(force: bool = False, report: bool = False, verbose: bool = True) -> Pa
                     print(f"== {name}")
                     print("\n".join(_summarise(err)))
     objs = [OBJ / f"{n}.o" for n in SOURCES]
-    linked_ok = LIB.exists() and stamp.exists() and stamp.read_text().strip() == csrc_hash()
+    linked_ok = LIB.exists() and stamp.exists() and stamp.read_text().strip() == _link_stamp()
     if force or todo or not linked_ok or _stale(LIB, objs):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
-        stamp.write_text(csrc_hash())
+        stamp.write_text(_link_stamp())
         if verbose:
             print(f"[clibd_amd.build] linked {LIB}", flush=True)
     return LIB

@@ -26,6 +26,36 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     }
 }
 
+// The same gather from the image bytes the dataset holds (uint8 [B,3,224,224]; the reference's ToTensor turns them into fp32
+// u8 / 255 on the host and copies 4 bytes per value across PCIe, util/dataset.py:185-195, train_epoch.py:26-32): the division is
+// the same IEEE fp32 division, so the bf16 patch matrix equals patchify_kernel(image_u8.float() / 255) bit for bit.
+// one thread = 8 consecutive px (8 B read, 16 B write).
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* __restrict__ img, int B, unsigned short* __restrict__ out) {
+    const size_t total = (size_t)B * 196 * 96;   // octets
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) {
+        const int ko = (int)(q % 96);
+        const size_t pr = q / 96;                // b*196 + p
+        const int p = (int)(pr % 196);
+        const int b = (int)(pr / 196);
+        const int k = ko * 8;
+        const int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
+        const int gy = (p / 14) * 16 + py, gx = (p % 14) * 16 + px;
+        const uint2 v = *(const uint2*)(img + (((size_t)b * 3 + c) * 224 + gy) * 224 + gx);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = __fdiv_rn((float)((v.x >> (8 * e)) & 255u), 255.0f);
+            f[4 + e] = __fdiv_rn((float)((v.y >> (8 * e)) & 255u), 255.0f);
+        }
+        uint4 o;
+        o.x = pack2bf(f[0], f[1]);
+        o.y = pack2bf(f[2], f[3]);
+        o.z = pack2bf(f[4], f[5]);
+        o.w = pack2bf(f[6], f[7]);
+        *(uint4*)(out + pr * 768 + k) = o;
+    }
+}
+
 // tok[b,0,:] = cls + pos[0,:];  tok[b,1+p,:] = proj[b*P+p,:] + pos[1+p,:]   (timm VisionTransformer._pos_embed)
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ proj, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, int B, int S, int H,
@@ -371,6 +401,14 @@ extern "C" int clibd_patchify(const float* image, int B, void* patches_bf16, voi
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((size_t)B * 196 * 192)), dim3(256), 0, (hipStream_t)stream, image, B,
                        (unsigned short*)patches_bf16);
     return check_launch("patchify");
+}
+
+extern "C" int clibd_patchify_u8(const unsigned char* image, int B, void* patches_bf16, void* stream) {
+    if (!image || !patches_bf16 || B <= 0) return set_error(CLIBD_EINVAL, "patchify_u8: bad args");
+    if (((uintptr_t)image & 7) || !aligned16(patches_bf16)) return set_error(CLIBD_EINVAL, "patchify_u8: alignment");
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for((size_t)B * 196 * 96)), dim3(256), 0, (hipStream_t)stream, image, B,
+                       (unsigned short*)patches_bf16);
+    return check_launch("patchify_u8");
 }
 
 extern "C" int clibd_vit_assemble_tokens(const float* proj, const float* cls, const float* pos, int B, int S, int H, float* tok,

@@ -248,6 +248,8 @@ __device__ __forceinline__ void tk_wave_best(float& v, int& id) {
 }
 
 constexpr float TK_C = 0.0045f;
+constexpr int TK_FAST_MAX_KEYS = 1 << 24;   // candidate lists carry key indices as floats: exact below 2^24
+constexpr int TK_FAST_MAX_D = 2048;          // 2 D 2^-23 <= 4.9e-4 < the 5.9e-4 of headroom TK_C leaves for fp32 accumulation
 constexpr int TB_Q = 128, TB_K = 64, TB_BK = 64;      // queries / keys per workgroup step, k per LDS chunk
 constexpr int TB_LD = TB_BK * 2 + 16;                  // LDS row stride in bytes (144: conflict-free ds_read_b128 over 16 rows)
 
@@ -515,6 +517,7 @@ extern "C" int clibd_topk_ip(const float* q, const float* keys, int Q, int Nk, i
 extern "C" int clibd_topk_prepare_keys(const float* keys, int Nk, int D, void* keys_bf16, float* max_norm, void* stream) {
     if (!keys || !keys_bf16 || !max_norm) return set_error(CLIBD_EINVAL, "topk_prepare_keys: null pointer");
     if (Nk <= 0 || D <= 0 || D % 64 != 0) return set_error(CLIBD_EINVAL, "topk_prepare_keys: D must be a positive multiple of 64");
+    if (Nk >= TK_FAST_MAX_KEYS || D > TK_FAST_MAX_D) return set_error(CLIBD_EINVAL, "topk_prepare_keys: the pre-filtered search takes Nk < 2^24 keys and D <= 2048 (use clibd_topk_ip)");
     if (!aligned16(keys) || !aligned16(keys_bf16)) return set_error(CLIBD_EINVAL, "topk_prepare_keys: alignment");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(max_norm, 0, sizeof(float), st) != hipSuccess) return set_error(CLIBD_ELAUNCH, "topk_prepare_keys: memset");
@@ -538,6 +541,9 @@ extern "C" int clibd_topk_ip_fast(const float* q, const float* keys, const void*
     if (!q || !keys || !keys_bf16 || !max_norm || !out_idx || !out_sim || !overflow || !workspace) return set_error(CLIBD_EINVAL, "topk_ip_fast: null pointer");
     if (Q <= 0 || Nk <= 0 || D <= 0 || D % 64 != 0) return set_error(CLIBD_EINVAL, "topk_ip_fast: D must be a positive multiple of 64");
     if (k < 1 || k > TK_KMAX || k > Nk) return set_error(CLIBD_EINVAL, "topk_ip_fast: need 1 <= k <= min(8, Nk)");
+    // The bit-identity with clibd_topk_ip rests on two bounds: the candidate lists carry key indices as floats (exact
+    // below 2^24), and the band TK_C leaves 5.9e-4 of headroom for the two fp32 accumulations, whose worst case grows as 2 D 2^-23.
+    if (Nk >= TK_FAST_MAX_KEYS || D > TK_FAST_MAX_D) return set_error(CLIBD_EINVAL, "topk_ip_fast: needs Nk < 2^24 and D <= 2048 (use clibd_topk_ip)");
     if (!aligned16(q) || !aligned16(keys) || !aligned16(keys_bf16) || !aligned16(workspace)) return set_error(CLIBD_EINVAL, "topk_ip_fast: alignment");
     if (workspace_bytes < clibd_topk_ip_fast_workspace_bytes(Q, Nk, D)) return set_error(CLIBD_EINVAL, "topk_ip_fast: workspace too small");
     const int nsplit = topk_fast_splits(Q, Nk);

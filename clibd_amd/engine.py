@@ -39,7 +39,9 @@ class NotSupportedYet(NotImplementedError):
 #   travels between blocks as bf16 instead of fp32 — the LayerNorm backward then moves 10 instead of 16 bytes per element and the
 #   BERT dgrad GEMMs join the stream with a bf16 add (CLIBD_ACT_ADD_AUX) instead of an fp32 read + write.  The reference's autograd
 #   keeps this stream in fp32 (also under autocast); the extra rounding (one bf16 rounding per block-half: ~0.1 % rms each,
-#   independent) is budgeted in DESIGN.md §4.  Full fine-tune mode always keeps fp32.
+#   independent) is budgeted in DESIGN.md §4.  Full fine-tune mode (disable_lora) follows the same switch since round 4 — its bottom
+#   layer still hands an fp32 gradient to the embedding backward; tests/test_model_gpu.py::test_full_finetune_residual_grad_streams_agree
+#   gates the bf16 stream against the fp32 one on the same model.
 # gelu_grad ("bf16" default | "u8"; env CLIBD_GELU_GRAD).  gelu'(fc1 out) is all the MLP's backward needs (frozen fc1 / fc2 carry no
 #   weight gradient that would want the activation), and it lies in [-0.129, 1.129].  "u8" keeps it as ONE BYTE per element
 #   (CLIBD_ACT_GELU_SAVE_GRAD_U8, |error| <= 2.5e-3 everywhere; bf16's half-spacing is 2.0e-3 in [0.5, 1), 3.9e-3 in [1, 2), finer

@@ -3,6 +3,7 @@
 (reference bioscanclip/util/util.py:521-553: sklearn L2-normalise -> faiss.IndexFlatIP -> search(query, max_k) -> label lookup)."""
 from __future__ import annotations
 
+import weakref
 from typing import List, Sequence
 
 import numpy as np
@@ -84,6 +85,24 @@ def prepare_key_bank(keys_feature: torch.Tensor) -> "ops.KeyBank":
     return ops.KeyBank(kf)
 
 
+# One prepared bank per key TENSOR: `make_prediction` is called with the same keys for every query set of an evaluation
+# (inference_epoch.py / util.py:521-553 build ONE faiss index per key set), and a bank costs a normalisation, a bf16 image of the
+# keys (630 MB at 410 k x 768) and a conversion kernel.  The key is the tensor's storage, shape, strides and version counter, so an
+# in-place update of the keys invalidates the entry; only the most recent bank is kept.
+_bank_cache: dict = {}
+
+
+def _cached_key_bank(keys_feature: torch.Tensor) -> "ops.KeyBank":
+    key = (keys_feature.data_ptr(), tuple(keys_feature.shape), tuple(keys_feature.stride()), keys_feature.dtype, keys_feature._version,
+           str(keys_feature.device))
+    hit = _bank_cache.get("entry")
+    if hit is not None and hit[0] == key and hit[1]() is keys_feature:
+        return hit[2]
+    bank = prepare_key_bank(keys_feature)
+    _bank_cache["entry"] = (key, weakref.ref(keys_feature), bank)
+    return bank
+
+
 def topk_search(query_feature: torch.Tensor, keys_feature, max_k: int = 5, exact: bool = False):
     """(similarities, indices) of IndexFlatIP.search on L2-normalised features.  `keys_feature`: a tensor, or a bank from
     `prepare_key_bank` (re-used across query batches).  Large banks take the pre-filtered search (bf16 approximate scores, exact
@@ -93,10 +112,11 @@ def topk_search(query_feature: torch.Tensor, keys_feature, max_k: int = 5, exact
     q, _ = ops.l2norm_fwd(query_feature.detach().to(torch.float32).contiguous())
     bank = keys_feature if isinstance(keys_feature, ops.KeyBank) else None
     if bank is None:
-        kf, _ = ops.l2norm_fwd(keys_feature.detach().to(torch.float32).contiguous())
-        if exact or kf.shape[1] % 64 != 0 or not (4096 <= kf.shape[0] < (1 << 24)):
+        Nk, D = keys_feature.shape
+        if exact or D % 64 != 0 or D > ops.KeyBank.MAX_D or not (4096 <= Nk < ops.KeyBank.MAX_KEYS):
+            kf, _ = ops.l2norm_fwd(keys_feature.detach().to(torch.float32).contiguous())
             return ops.topk_ip(q, kf, max_k)
-        bank = ops.KeyBank(kf)
+        bank = _cached_key_bank(keys_feature)
     if exact:
         return ops.topk_ip(q, bank.keys, max_k)
     sim, idx, ovf = ops.topk_ip_fast(q, bank, max_k)

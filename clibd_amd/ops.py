@@ -482,12 +482,17 @@ def lora_backward(dqkv, x, t, w_dt, dt, dA_q, dA_v, dB_q, dB_v) -> None:
 
 
 def patchify(image: torch.Tensor) -> torch.Tensor:
-    _chk(image, F32, "image")
+    """fp32 [B,3,224,224] in [0,1] — or the dataset's uint8 bytes, read as u8 / 255 (bit-identical to the fp32 form of the same
+    image: clibd_patchify_u8) — -> bf16 patch matrix [B*196, 768]."""
+    _chk(image, torch.uint8 if image.dtype == torch.uint8 else F32, "image")
     if image.dim() != 4 or tuple(image.shape[1:]) != (3, 224, 224):
         raise ValueError("patchify: image must be [B,3,224,224]")
     B = image.shape[0]
     out = torch.empty((B * 196, 768), dtype=BF16, device=image.device)
-    check(_lib.load().clibd_patchify(image.data_ptr(), B, out.data_ptr(), _stream()), "patchify")
+    if image.dtype == torch.uint8:
+        check(_lib.load().clibd_patchify_u8(image.data_ptr(), B, out.data_ptr(), _stream()), "patchify_u8")
+    else:
+        check(_lib.load().clibd_patchify(image.data_ptr(), B, out.data_ptr(), _stream()), "patchify")
     return out
 
 
@@ -672,11 +677,13 @@ class KeyBank:
     """A key bank prepared once for the pre-filtered search: the fp32 keys, their bf16 image and max ||key|| (clibd_topk_prepare_keys).
     The reference builds one faiss.IndexFlatIP per key set and searches it with every query batch (util/util.py:521-528)."""
 
+    MAX_KEYS, MAX_D = 1 << 24, 2048   # the C entry points refuse beyond these too (topk.hip: TK_FAST_MAX_KEYS / TK_FAST_MAX_D)
+
     def __init__(self, keys: torch.Tensor):
         _chk(keys, F32, "keys")
         Nk, D = keys.shape
-        if D % 64 != 0 or Nk >= 1 << 24:
-            raise ValueError("KeyBank: the pre-filtered search needs D % 64 == 0 and fewer than 2^24 keys (use topk_ip)")
+        if D % 64 != 0 or D > self.MAX_D or Nk >= self.MAX_KEYS:
+            raise ValueError("KeyBank: the pre-filtered search needs D % 64 == 0, D <= 2048 and fewer than 2^24 keys (use topk_ip)")
         self.keys = keys
         self.keys_bf16 = torch.empty((Nk, D), dtype=BF16, device=keys.device)
         self.max_norm = torch.empty((1,), dtype=F32, device=keys.device)

@@ -251,6 +251,10 @@ int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_bf16, const
  * BERT embeddings: word[id] + position[s] + token_type[tt] (HF BertEmbeddings) -> fp32 [B*S,H] (pre-LN sum).
  * ------------------------------------------------------------------------------------------------ */
 int clibd_patchify(const float* image, int B, void* patches_bf16, void* stream);
+/* The same from the dataset's image BYTES (uint8 [B,3,224,224], 8-byte aligned): value = fp32(u8) / 255 (IEEE division, what the
+ * reference's ToTensor computes on the host, util/dataset.py:185-195), so the result equals clibd_patchify(u8.float() / 255) bit
+ * for bit while a quarter of the bytes cross PCIe (train_epoch.py:26-32 copies the fp32 tensor every step).  ABI version 3. */
+int clibd_patchify_u8(const unsigned char* image, int B, void* patches_bf16, void* stream);
 int clibd_vit_assemble_tokens(const float* proj, const float* cls, const float* pos, int B, int S, int H, float* tok,
                               void* stream);
 int clibd_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int S, int H, int vocab,

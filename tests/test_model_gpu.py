@@ -772,6 +772,24 @@ def test_device_prefetcher_delivers_the_batches_in_order(dev):
     assert seen == 5
 
 
+def test_image_tower_takes_the_datasets_image_bytes(dev):
+    """uint8 images through CLIBDImageEncoder.forward (what DevicePrefetcher hands over when the loader yields the HDF5 bytes):
+    embeddings AND adapter / head gradients equal those of the fp32 u8 / 255 tensor the reference's ToTensor would have produced,
+    bit for bit — only the patch gather differs, and it reads the same values."""
+    gi = load("image_tiny_golden.pt")
+    hm = hip_image(gi, dev)
+    img8 = gi["image_u8"]
+    assert img8.dtype == torch.uint8
+    cot = torch.randn(img8.shape[0], hm(img8.to(dev)).shape[1], generator=torch.Generator().manual_seed(2)).to(dev)
+    y8 = hm(img8.to(dev))
+    g8 = grads_named(hm, (y8 * cot).sum())
+    y32 = hm((img8.float() / 255.0).to(dev))
+    g32 = grads_named(hm, (y32 * cot).sum())
+    assert torch.equal(y8, y32) and len(g8) == len(g32) > 4
+    for n in g32:
+        assert rel(g8[n], g32[n]) < 2e-5, n   # float-atomic order of the adapter sums only
+
+
 @pytest.mark.parametrize("name,dim,depth,heads", [("vit_large_patch16_224", 1024, 24, 16), ("vit_small_patch16_224", 384, 12, 6)])
 def test_other_vit_sizes_match_oracle(dev, name, dim, depth, heads):
     """The reference also ships configs on other timm ViTs (`pre_train_model`, simple_clip.py:148-153; e.g.
@@ -995,3 +1013,45 @@ def test_gelu_grad_kept_as_one_byte_in_the_towers(dev, monkeypatch):
             go = dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
         # (the most sensitive tensor of the tiny ViT, the block-0 q adapter, sits at 1.7-2.5 % with either form depending on the other knobs)
         assert_grads(res["u8"][1], go, rel_tol=3e-2, cos_tol=0.999, what="u8 gelu' vs oracle")
+
+
+@pytest.mark.parametrize("name", ["image", "dna"])
+def test_full_finetune_residual_grad_streams_agree(dev, name):
+    """since round 4 the full fine-tune walk (model_config.disable_lora) follows the residual_grad switch too, i.e. by
+    default the gradient of the residual stream travels between block halves in bf16 where the reference's autograd keeps fp32.
+    Both settings on the SAME model and cotangent: identical forward, every base-weight / bias / LayerNorm / embedding gradient of
+    the bf16 stream within 2e-2 (cosine 0.9995) of the fp32 stream's — and the fp32 stream, the reference's semantics, still
+    within the oracle gate."""
+    from oracle import clibd_oracle as O
+    from tests.test_oracle import build_dna, build_image
+
+    if name == "image":
+        gi = load("image_tiny_golden.pt")
+        hm, om, x = hip_image(gi, dev), build_image(gi), gi["image_u8"].float() / 255.0
+    else:
+        gd = load("dna_tiny_golden.pt")
+        hm, om, x = hip_dna(gd, dev), build_dna(gd), gd["ids"]
+    for p in hm.parameters():
+        p.requires_grad_(True)
+    for p in om.parameters():
+        p.requires_grad_(True)
+    g = torch.Generator().manual_seed(11)
+    res, cot = {}, None
+    for mode in ("fp32", "bf16"):
+        hm.tower().stack.set_numerics(residual_grad=mode)
+        y = hm(x.to(dev))
+        if cot is None:
+            cot = torch.randn(y.shape, generator=g)
+        res[mode] = (y.detach().cpu(), grads_named(hm, (y * cot.to(dev)).sum()))
+    hm.tower().stack.set_numerics(residual_grad="bf16")
+    assert torch.equal(res["fp32"][0], res["bf16"][0])
+    assert len(res["bf16"][1]) > 30
+    assert any(not torch.equal(res["bf16"][1][n], res["fp32"][1][n]) for n in res["fp32"][1]), "the switch did not reach the full fine-tune walk"
+    assert_grads(res["bf16"][1], res["fp32"][1], rel_tol=2e-2, cos_tol=0.9995, what=f"{name} full fine-tune: bf16 vs fp32 residual-gradient stream",
+                 zero_tol=2e-6, zero_rel=1e-4)
+    with O.precision("bf16"):
+        yo = om(x)
+        ps = [(n, p) for n, p in om.named_parameters()]
+        gs = torch.autograd.grad((yo * cot).sum(), [p for _, p in ps], allow_unused=True)
+        go = {n: (torch.zeros_like(p) if g_ is None else g_) for (n, p), g_ in zip(ps, gs)}
+    assert_grads(res["fp32"][1], go, rel_tol=3e-2, cos_tol=0.999, what=f"{name} full fine-tune, fp32 stream vs oracle", zero_tol=2e-6, zero_rel=1e-4)

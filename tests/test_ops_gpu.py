@@ -463,6 +463,24 @@ def test_patchify_matches_conv_unfold(ops, dev):
     assert torch.equal(got.cpu().float(), bfr(ref))
 
 
+def test_patchify_from_image_bytes_equals_the_host_side_totensor(ops, dev):
+    """clibd_patchify_u8: the dataset's uint8 images, divided by 255 on the device, give the patch matrix of the reference's host-side
+    ToTensor (u8.float() / 255, util/dataset.py:185-195) bit for bit — every one of the 256 byte values occurs."""
+    g = torch.Generator().manual_seed(14)
+    B = 3
+    img8 = torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8)
+    img8.view(-1)[:256] = torch.arange(256, dtype=torch.uint8)
+    f32 = img8.float() / 255.0
+    got8 = ops.patchify(img8.to(dev))
+    got32 = ops.patchify(f32.to(dev))
+    ref = torch.nn.functional.unfold(f32, kernel_size=16, stride=16).transpose(1, 2).reshape(B * 196, 768)
+    torch.cuda.synchronize()
+    assert torch.equal(got8.cpu().view(torch.int16), got32.cpu().view(torch.int16))
+    assert torch.equal(got8.cpu().float(), bfr(ref))
+    with pytest.raises(TypeError):
+        ops.patchify(img8.to(dev).to(torch.int32))
+
+
 def test_vit_assemble_gelu_bwd_and_bert_embed(ops, dev):
     g = torch.Generator().manual_seed(13)
     B, S, H = 3, 5, 64
