@@ -143,7 +143,6 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
     const unsigned wB10 = wB00 + STAGE_BYTES, wB11 = wB01 + STAGE_BYTES;
 
     f32x4 acc[2][4][2][2];  // [hm][mt][hn][nt]
-    const int unit_scale = 0;  // E8M0 1.0 in every byte (FP8 only)
     bf16x8 aF[4][2], w0F[2][2], w1F[2][2];  // [tile][kk]
     i32x8 aF8[4], w0F8[2], w1F8[2];         // FP8: [tile], both 16-byte k-chunks of the lane as ONE 8-VGPR MFMA operand
     // (w0F / w0F8 etc. are selected by token pasting in the macros below: the unused set never materialises)
@@ -182,8 +181,11 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         if constexpr (FP8) {                                                                                 \
             _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                    \
                 _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                \
-                    acc[hm][t][hn][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                    \
-                        wF##8[n], aF8[t], acc[hm][t][hn][n], 0, 0, 0, unit_scale, 0, unit_scale); \
+                    /* inline asm with the accumulator TIED in and out: left to the builtin, hipcc gave the MFMAs of the peeled */ \
+                    /* tail phases a destination different from their source accumulator and spilled 13-28 registers around   */ \
+                    /* them, each reload behind a vmcnt(0) that also drains the LDS-DMA ring.  Unscaled form */ \
+                    /* = unit block scales, e4m3 x e4m3 (cbsz = blgp = 0).  Invisible to the hazard recognizer: FP8_MFMA_DRAIN.  */ \
+                    asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(acc[hm][t][hn][n]) : "v"(wF##8[n]), "v"(aF8[t])); \
         } else {                                                                                             \
             _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                 \
                 _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                \
@@ -360,6 +362,9 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         if (has_next) set_sources(next);  // no more issues for this tile: the source registers now describe the next one
         PHASE_TAIL(2, 6); PHASE_TAIL(3, 4); PHASE_TAIL(4, 2); PHASE_TAIL(5, 0); PHASE_TAIL(6, 0); PHASE_TAIL(7, 0);
         if (wm == 0) BARRIER();  // group 0 matches group 1's extra barrier; every LDS read of this tile is complete
+        // FP8_MFMA_DRAIN: the fp8 MFMAs are inline asm, so hipcc inserts no wait states between the last of them (8 passes) and the
+        // first VALU read of an accumulator below (dequantisation): 18 are required, give 32
+        if constexpr (FP8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         STAMP(4);
         // lane coordinates made opaque per tile: everything the epilogue derives from them (16 row offsets x several
         // leading dimensions) is rebuilt here instead of being hoisted out of the persistent loop into spilled registers

@@ -171,7 +171,7 @@ class TransformerStack:
     FP8_SITES = ("qkv_in", "proj_in", "fc1_in", "fc2_in")
     FP8_SCALES = dict(qkv_in=8.0, proj_in=32.0, fc1_in=8.0, fc2_in=4.0)
 
-    def enable_fp8(self, scales: Optional[dict] = None, amax: Optional[list] = None, margin: float = 2.0):
+    def enable_fp8(self, scales: Optional[dict] = None, amax: Optional[list] = None, margin: float = 2.0, sites: Optional[Sequence[str]] = None):
         """The four forward GEMMs of every layer run on the fp8 MFMA (ops.gemm_fp8_nt): frozen weights are quantised per
         output channel once; activations per tensor, inside the kernels that produce them (LayerNorm, attention, fc1
         epilogue), as e4m3(value * scale) saturating at +-448.  Scales are powers of two, per layer and site:
@@ -180,17 +180,31 @@ class TransformerStack:
           * otherwise the static `scales` / FP8_SCALES for every layer (fits unit-variance LayerNorm outputs, random-init or
             lightly trained towers; pretrained checkpoints with outlier channels want the calibration).
         The backward is unchanged bf16 (it needs gelu', qkv, statistics and — for the adapters — the bf16 LayerNorm output
-        only): gradients are those of the bf16 network evaluated at the fp8 forward's activations.  LoRA / frozen-base mode only."""
+        only): gradients are those of the bf16 network evaluated at the fp8 forward's activations.  LoRA / frozen-base mode only.
+        sites (round 5; pre-LN stacks only): a subset of FP8_SITES — ("fc1_in", "fc2_in") runs the MLP of every block on the fp8 MFMA
+        and leaves QKV, attention and the projection on bf16 operands (the per-layer dicts then hold those sites only, which is also
+        how the oracle is told: a site without a scale is a bf16 site).  The oracle study behind it: profiles/r05_exp_fp8_vit_sites.log."""
+        if sites is not None:
+            sites = tuple(sites)
+            if any(s not in self.FP8_SITES for s in sites):
+                raise ValueError(f"enable_fp8: sites must come from {self.FP8_SITES}")
+            if set(sites) != set(self.FP8_SITES):
+                if not self.pre_ln or set(sites) != {"fc1_in", "fc2_in"}:
+                    raise NotSupportedYet("fp8 site selection: only the MLP pair (fc1_in, fc2_in) of a pre-LN stack is built")
         if self.full_mode():
             raise NotSupportedYet("fp8 forward needs frozen base weights (their gradients would need the bf16 GEMM inputs)")
         if self.H % 256 or self.H < 512 or self.FF % 256:
             raise NotSupportedYet("fp8 forward needs hidden % 256 == 0, hidden >= 512, intermediate % 256 == 0")
         base = dict(self.FP8_SCALES, **(scales or {}))
+        if sites is not None:
+            base = {k: v for k, v in base.items() if k in sites}
         per_layer = []
         for i in range(len(self.layers)):
             d = dict(base)
             if amax is not None:
                 for site, v in amax[i].items():
+                    if site not in d:
+                        continue
                     v = float(v)
                     if v > 0.0 and math.isfinite(v):
                         d[site] = 2.0 ** math.floor(math.log2(448.0 / (margin * v)))
@@ -244,8 +258,9 @@ class TransformerStack:
                 c.g1, c.be1, c.g2, c.be2 = _f32c(L.ln1_w), _f32c(L.ln1_b), _f32c(L.ln2_w), _f32c(L.ln2_b)
                 if self.fp8 is not None:
                     f8 = self.fp8[len(self._cache)]
-                    c.wqkv8, c.cs_qkv = ops.quantize_rows_fp8(wqkv.contiguous(), f8["qkv_in"])
-                    c.wo8, c.cs_o = ops.quantize_rows_fp8(_f32c(L.proj_w), f8["proj_in"])
+                    if "qkv_in" in f8:   # (a site selection leaves the other sites' images unbuilt)
+                        c.wqkv8, c.cs_qkv = ops.quantize_rows_fp8(wqkv.contiguous(), f8["qkv_in"])
+                        c.wo8, c.cs_o = ops.quantize_rows_fp8(_f32c(L.proj_w), f8["proj_in"])
                     c.w18, c.cs_1 = ops.quantize_rows_fp8(_f32c(L.fc1_w), f8["fc1_in"])
                     c.w28, c.cs_2 = ops.quantize_rows_fp8(_f32c(L.fc2_w), f8["fc2_in"])
                 c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = c.slot2 = None
@@ -332,10 +347,11 @@ class TransformerStack:
         amax = lambda t_: t_.abs().amax().float()
         f8 = None
         AT = ops.FP8 if f8s is not None else BF16    # dtype of the GEMM-operand temporaries
-        o = None if keep else new(H, AT)            # attention output (temporary, reused by every layer)
+        mlp_only = f8s is not None and "qkv_in" not in f8s[0]   # fp8 site selection: QKV / attention / projection stay bf16
+        o = None if keep else new(H, BF16 if mlp_only else AT)   # attention output (temporary, reused by every layer)
         a = None if keep else new(FF, AT)           # post-GELU activation (temporary)
         xn2 = new(H, AT) if (self.pre_ln and not keep) else None
-        xn8 = new(H, ops.FP8) if f8s is not None else None   # fp8 image of the first LayerNorm's output (temporary)
+        xn8 = new(H, ops.FP8) if (f8s is not None and not mlp_only) else None   # fp8 image of the first LayerNorm's output (temporary)
         GG = torch.uint8 if (self.numerics["gelu_grad"] == "u8" and f8s is None) else BF16            # storage of gelu'(fc1 out)
         act_save = ops.ACT_GELU_SAVE_GRAD_U8 if GG == torch.uint8 else ops.ACT_GELU_SAVE_GRAD
         h_tmp = new(FF, BF16) if (f8s is not None and not save) else None       # the fp8 fc1 form always writes gelu'
@@ -356,7 +372,7 @@ class TransformerStack:
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
                 t = torch.empty((M, 8), dtype=BF16, device=dev) if has_lora else None
                 qkv = new(3 * H, BF16)
-                if f8 is not None:   # the full-size GEMM of this block; its class-row remainder stays bf16
+                if f8 is not None and not mlp_only:   # the full-size GEMM of this block; its class-row remainder stays bf16
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t,
                                       y_fp8=xn8, fp8_scale=f8["qkv_in"])
                     ops.gemm_fp8_nt(xn8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)
@@ -395,7 +411,16 @@ class TransformerStack:
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
                 h = new(FF, GG) if save else None        # holds gelu'(fc1 out): all the backward needs
                 x2 = new(H, F32)
-                if f8 is not None:
+                if f8 is not None and mlp_only:   # fp8 on the MLP pair only: the attention half of the block is the bf16 path's
+                    ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
+                    add32, t2 = self._slot2_fwd(c, xn) if c.slot2 is not None else (None, None)
+                    ops.gemm_nt(xn, c.wqkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, residual=add32, out_bf16=qkv)
+                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
+                    ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
+                    ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, stats=st2, y_fp8=xn2, fp8_scale=f8["fc1_in"])
+                    ops.gemm_fp8_nt(xn2, c.w18, c.cs_1, bias=c.b1, gelu_out_fp8=a, gelu_out_scale=f8["fc2_in"], out_pre=h if save else h_tmp)
+                    ops.gemm_fp8_nt(a, c.w28, c.cs_2, bias=c.b2, residual=x1, out_f32=x2)
+                elif f8 is not None:
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t,
                                       y_fp8=xn8, fp8_scale=f8["qkv_in"])
                     ops.gemm_fp8_nt(xn8, c.wqkv8, c.cs_qkv, bias=c.bqkv, rank_u=t, rank_v=c.v_fwd if has_lora else None, out_bf16=qkv)

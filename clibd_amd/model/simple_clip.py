@@ -116,7 +116,12 @@ class SimpleCLIP(nn.Module):
     # token, whose embedding moves by 4-5e-2 under e4m3 — x14.3 in the logits — whatever the scale granularity (per tensor, per row,
     # MXFP8 per 32) and whichever rows / blocks are kept in bf16 (tools/fp8_policy_study.py, profiles/r04_exp_fp8_policy_study.log):
     # "all" adds it for an embedding-grade mode that is 6 % faster still and not gradient-faithful.
-    FP8_TOWER_SETS = {"pooled": ("dna_encoder", "language_encoder"), "all": ("image_encoder", "dna_encoder", "language_encoder")}
+    # Round 5: "pooled_mlp" = "pooled" plus the MLP pair (fc1, fc2) of every ViT block — the oracle study of SITE selections
+    # (profiles/r05_exp_fp8_vit_sites.log) found the class row's sensitivity to sit in the attention half (fp8 on QKV + projection alone:
+    # cosine 0.954; on fc1 + fc2 alone 0.985; on everything 0.937, training batch).
+    FP8_TOWER_SETS = {"pooled": ("dna_encoder", "language_encoder"), "all": ("image_encoder", "dna_encoder", "language_encoder"),
+                      "pooled_mlp": ("image_encoder", "dna_encoder", "language_encoder")}
+    FP8_TOWER_SITES = {"pooled_mlp": {"image_encoder": ("fc1_in", "fc2_in")}}   # towers of a set that take a site selection
 
     def enable_fp8_forward(self, scales: Optional[dict] = None, enabled: bool = True, calibration_inputs=None, margin: float = 2.0,
                            towers=None):
@@ -136,7 +141,10 @@ class SimpleCLIP(nn.Module):
         self.__dict__["_fp8_towers"] = towers if isinstance(towers, str) else names
         every = [getattr(self, n).tower().stack for n in self.FP8_TOWER_SETS["all"]
                  if getattr(self, n) is not None and hasattr(getattr(self, n), "tower")]
-        stacks = [getattr(self, n).tower().stack for n in names if getattr(self, n) is not None and hasattr(getattr(self, n), "tower")]
+        live = [n for n in names if getattr(self, n) is not None and hasattr(getattr(self, n), "tower")]
+        stacks = [getattr(self, n).tower().stack for n in live]
+        site_sel = self.FP8_TOWER_SITES.get(towers, {}) if isinstance(towers, str) else {}
+        sites = [site_sel.get(n) for n in live]
         for st in every:
             st.disable_fp8()
         if not enabled:
@@ -155,8 +163,8 @@ class SimpleCLIP(nn.Module):
                 torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.MAX)
                 it = iter(flat.tolist())
                 amax = [[{k: next(it) for k, _ in sorted(d.items())} for d in am] for am in amax]
-        for st, am in zip(stacks, amax):
-            st.enable_fp8(scales, amax=am if am else None, margin=margin)
+        for st, am, ss in zip(stacks, amax, sites):
+            st.enable_fp8(scales, amax=am if am else None, margin=margin, sites=ss)
         return self
 
     def _stacks(self):

@@ -175,7 +175,7 @@ def set_fp8_scales(layers, per_layer=None, last_block_qkv_only: bool = False):
     for i, layer in enumerate(layers):
         d = dict(FP8_SCALES if per_layer is None else per_layer[i])
         if last_block_qkv_only and i == n - 1:
-            d = {"qkv_in": d["qkv_in"]}
+            d = {k: v for k, v in d.items() if k == "qkv_in"}   # (a site selection may not carry qkv_in at all)
         for m in layer.modules():
             m._fp8 = d
 

@@ -269,7 +269,7 @@ def _named_grads(module, loss):
     return {n: (torch.zeros_like(p) if g is None else g).detach().float().cpu() for (n, p), g in zip(ps.items(), gs)}
 
 
-@pytest.mark.parametrize("calibrated,towers", [(False, "all"), (True, "all"), (True, "pooled")])
+@pytest.mark.parametrize("calibrated,towers", [(False, "all"), (True, "all"), (True, "pooled"), (True, "pooled_mlp")])
 def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated, towers):
     """configs[4]'s mode against a CPU statement of the SAME arithmetic (oracle precision("fp8"): e4m3 operands with the towers'
     scales, fp32 accumulation, bf16 backward), ViT-B/16 + BERT-base at batch 16 — no longer HIP against HIP.
@@ -283,7 +283,9 @@ def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated, towers):
     embedding-grade, not gradient-faithful.  Gates: embeddings 1e-2, loss 3e-3, cosines 0.8 / 0.85.
     Round 4, towers="pooled" (the default selection: fp8 only where the head averages its tokens, the ViT in bf16): the image side is
     the bf16 path, the DNA side's quantisation noise is averaged by its head, and HIP and oracle agree on the gradient like two bf16
-    implementations do: gate cosine >= 0.97 over all trainable tensors."""
+    implementations do: gate cosine >= 0.97 over all trainable tensors.
+    Round 5, towers="pooled_mlp": "pooled" plus fp8 on the MLP pair (fc1, fc2) of every ViT block, the attention half of the block on
+    bf16 operands — the oracle is told through the same per-layer dicts (a site without a scale is a bf16 site); gates as for "all"."""
     from oracle import clibd_oracle as O
     from clibd_amd.data import synthetic_batch
     from clibd_amd.model import ClipLoss
@@ -370,7 +372,7 @@ def test_fp8_gradients_on_spread_embeddings(dev):
             e16, d16, g16 = run(bt)
             names = sorted(g16)
             spread = float((e16 @ e16.T).fill_diagonal_(0).sum() / (B * (B - 1)))
-            for towers in ("pooled", "all"):
+            for towers in ("pooled", "pooled_mlp", "all"):
                 model.enable_fp8_forward(calibration_inputs=(bt["image"], bt["dna"], None), towers=towers)
                 e8, d8, g8 = run(bt)
                 out[(tag, name, towers)] = (_cosv(torch.cat([g8[n].flatten() for n in names]), torch.cat([g16[n].flatten() for n in names])),
@@ -394,7 +396,13 @@ def test_fp8_gradients_on_spread_embeddings(dev):
         if k[2] == "pooled":
             assert c >= 0.98 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # training-grade: VERDICT r3 item 1's gate (measured 0.9846 - 0.9993; DNA rows move by 5e-3 - 3e-2)
         else:
-            assert c > 0.15 and de < 0.3, (k, c, de)                      # embedding-grade: the floor round 3's measurement set
+            # embedding-grade: the floor round 3's measurement set.  "pooled_mlp" (round 5: + the ViT's MLP pair) sits between the two —
+            # the oracle study (profiles/r05_exp_fp8_vit_sites.log) has it at 0.985 on the training batch and 0.82 on a fresh one after
+            # 8 steps: it does NOT pass the 0.98 gate on both batches, so it is not the default and not called training-grade
+            assert c > 0.15 and de < 0.3, (k, c, de)
+    for stage in ("8 steps", "40 steps"):
+        for name in ("train", "fresh"):
+            assert out[(stage, name, "pooled_mlp")][0] >= out[(stage, name, "all")][0] - 0.05, (stage, name, out[(stage, name, "pooled_mlp")][0], out[(stage, name, "all")][0])
 
 
 def test_fp8_pooled_selection_covers_the_text_tower(dev):

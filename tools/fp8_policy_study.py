@@ -36,7 +36,20 @@ torch.set_num_threads(8)
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 
-POLICY = dict(gran="tensor", cls_bf16=False, in_image=False, bf16_from_block=None, block_index=None, image_bf16=False)
+POLICY = dict(gran="tensor", cls_bf16=False, in_image=False, bf16_from_block=None, block_index=None, image_bf16=False, image_sites=None,
+              fp8_until_block=None)
+
+
+def vit_site(weight):
+    """Which of a ViT block's four GEMMs a weight belongs to, from its shape ([out, in]; ViT-B/16: H = 768)."""
+    o, i = weight.shape
+    if o == 3 * i:
+        return "qkv"
+    if o == 4 * i:
+        return "fc1"
+    if i == 4 * o:
+        return "fc2"
+    return "proj"
 
 
 def e4m3(x):
@@ -70,6 +83,11 @@ class PolicyLinear(torch.autograd.Function):
         if POLICY["in_image"] and POLICY["image_bf16"]:
             return F.linear(rb(xf), rb(wf))
         if POLICY["in_image"] and frm is not None and blk is not None and blk >= frm:
+            return F.linear(rb(xf), rb(wf))
+        # round 5: fp8 only on SOME of the ViT's GEMM sites / only in its first blocks, the rest of the tower bf16
+        if POLICY["in_image"] and POLICY["image_sites"] is not None and vit_site(weight) not in POLICY["image_sites"]:
+            return F.linear(rb(xf), rb(wf))
+        if POLICY["in_image"] and POLICY["fp8_until_block"] is not None and blk is not None and blk >= POLICY["fp8_until_block"]:
             return F.linear(rb(xf), rb(wf))
         global MX_NOCLIP
         MX_NOCLIP = POLICY["gran"] == "mx32_noclip"
@@ -173,7 +191,16 @@ def main():
                 ("cls_bf16", dict(gran="tensor", cls_bf16=True, bf16_from_block=None)),
                 ("mx32+cls_bf16", dict(gran="mx32", cls_bf16=True, bf16_from_block=None)),
                 ("last2_bf16", dict(gran="tensor", cls_bf16=False, bf16_from_block=10)),
-                ("last6_bf16", dict(gran="tensor", cls_bf16=False, bf16_from_block=6))]
+                ("last6_bf16", dict(gran="tensor", cls_bf16=False, bf16_from_block=6)),
+                # round 5: site selections inside the ViT (the DNA tower on fp8 throughout)
+                ("vit_mlp", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc1", "fc2"))),
+                ("vit_fc1", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc1",))),
+                ("vit_fc2", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc2",))),
+                ("vit_qkv_proj", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("qkv", "proj"))),
+                ("vit_mlp_cal", dict(gran="tensor_cal", cls_bf16=False, bf16_from_block=None, image_sites=("fc1", "fc2"))),
+                ("vit_mlp_first6", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc1", "fc2"), fp8_until_block=6)),
+                ("vit_mlp_first3", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc1", "fc2"), fp8_until_block=3)),
+                ("vit_fc2_first6", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc2",), fp8_until_block=6))]
     for name, (image, dna, labels) in (("train batch", tr), ("fresh batch", fr)):
         with O.precision("bf16"):
             i16, d16, l16, g16 = evaluate(om, image, dna, labels)
@@ -182,7 +209,7 @@ def main():
         for pname, pol in policies:
             if only is not None and pname not in only:
                 continue
-            POLICY.update(image_bf16=False)
+            POLICY.update(image_bf16=False, image_sites=None, fp8_until_block=None)
             POLICY.update(pol)
             with O.precision("fp8"):
                 i8, d8, l8, g8 = evaluate(om, image, dna, labels)
