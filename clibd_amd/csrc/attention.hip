@@ -845,6 +845,16 @@ __global__ __launch_bounds__(64 * NW, (NKT <= 10 ? 3 : 2)) void attention_bwd_ke
     } else {
     // ---------------- phase 2: per 16-key tile: dV, dK (query on the MFMA row, key on the lane) ----------------
     bf16x8 kf[2], vf[2], kfn[2], vfn[2];
+#ifdef CLIBD_ATT_NO_REFETCH
+    // TIMING-ONLY variant (tools/build_variant.sh, wrong results): the upper bound of removing this kernel's SECOND fetch of q, k, v and
+    // dO — phase 2 takes its K / V fragments from the LDS images and sweeps the K / V images as if they were Q / dO (no re-staging)
+    {
+        const int kc0 = min(wave * 16 + i, IMG - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { kf[ks] = lds_row_frag(t0, kc0, ks, g); vf[ks] = lds_row_frag(t1, kc0, ks, g); }
+    }
+    __syncthreads();
+#else
     {
         const int kc0 = min(wave * 16 + i, S - 1);
 #pragma unroll
@@ -857,6 +867,7 @@ __global__ __launch_bounds__(64 * NW, (NKT <= 10 ? 3 : 2)) void attention_bwd_ke
     stage_head_tile(t1, dobase, (size_t)H, nq, IMG, wave, lane, NW);  // rows >= nq are clamped copies, masked below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
 
     const int nkt = (S + 15) >> 4;
     for (int kt = wave; kt < nkt; kt += NW) {
@@ -864,12 +875,18 @@ __global__ __launch_bounds__(64 * NW, (NKT <= 10 ? 3 : 2)) void attention_bwd_ke
         bool key_ok = key < S;
         if (MASK) key_ok = key_ok && key_mask[(size_t)b * S + min(key, S - 1)] != 0;
         {   // next key tile's K / V fragments fly during this tile's sweep over the queries
+#ifdef CLIBD_ATT_NO_REFETCH
+            const int kn = min((kt + NW) * 16 + i, IMG - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { kfn[ks] = lds_row_frag(t0, kn, ks, g); vfn[ks] = lds_row_frag(t1, kn, ks, g); }
+#else
             const int kn = min((kt + NW) * 16 + i, S - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 kfn[ks] = *(const bf16x8*)(qbase + H + (size_t)kn * ld + 32 * ks + 8 * g);
                 vfn[ks] = *(const bf16x8*)(qbase + 2 * H + (size_t)kn * ld + 32 * ks + 8 * g);
             }
+#endif
         }
         f32x4 dv[4], dk[4];
 #pragma unroll
