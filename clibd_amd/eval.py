@@ -129,7 +129,10 @@ def topk_search(query_feature: torch.Tensor, keys_feature, max_k: int = 5, exact
 
 def make_prediction(query_feature, keys_feature, keys_label: List[dict], with_similarity=False, with_indices=False, max_k=5, device=None):
     """Same return convention as the reference `make_prediction`: a list of {level: [k predicted labels]} per query,
-    optionally followed by the similarity and index arrays (numpy, like faiss)."""
+    optionally followed by the similarity and index arrays (numpy, like faiss).
+    `keys_feature`: a device tensor (its prepared bank is cached per tensor and re-used by later calls), a `KeyBank` from
+    `prepare_key_bank` (evaluating several query sets against one key set: prepare it once, as the reference builds one faiss index),
+    or host data (numpy / CPU tensor: copied and prepared on every call — there is no cheap way to know a host array is unchanged)."""
     dev = device or (query_feature.device if torch.is_tensor(query_feature) else torch.device("cuda"))
     qf = torch.as_tensor(np.asarray(query_feature) if not torch.is_tensor(query_feature) else query_feature).to(dev)
     kf = keys_feature if isinstance(keys_feature, ops.KeyBank) else \
