@@ -99,7 +99,7 @@ constexpr int SPIN_LIMIT = 1 << 16;  // a flag wait gives up after this many pol
 //         wave polls the four counters one phase ahead (the ds_read rides behind the phase's fragment reads; its result is tested two
 //         MFMAs into the next phase, before that phase's fragment reads) and publishes consumed[wn] = g once the reads of the phases
 //         before g have returned; a DMA wave refills L_h's slot (with L_{h+8}) only when all four consumed counters are >= h - 1.
-template <int MODE, int SYNC, int DK = 0, int OPT = 0>   // OPT bit 0: compute waves at s_setprio 3; bit 1: fragment reads start after the phase's FIRST MFMA (not the third).  // DK: how the memory waves move operands: 0 LDS-DMA, 1 registers (global_load_dwordx4 -> ds_write_b128), 2 not at all (timing only)
+template <int MODE, int SYNC, int DK = 0, int OPT = 0>   // DK 4 (timing only): every LDS-DMA piece reads 1 KiB CONTIGUOUS (operands as if stored in [rows / 8][K / 64][8][64] tiles).  // OPT bit 0: compute waves at s_setprio 3; bit 1: fragment reads start after the phase's FIRST MFMA (not the third).  // DK: how the memory waves move operands: 0 LDS-DMA, 1 registers (global_load_dwordx4 -> ds_write_b128), 2 not at all (timing only)
 __global__ __launch_bounds__(512, 1) void gemmsr_kernel(PS p, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = 8;
@@ -135,6 +135,17 @@ __global__ __launch_bounds__(512, 1) void gemmsr_kernel(PS p, long long* stamps)
         auto set_src = [&]() {
             tile_xy(p, tile_is, im0, in0);
             if constexpr (DK == 3) { im0 = 256 * (int)(blockIdx.x & 7); in0 = 0; }   // timing only: every workgroup re-reads ONE L2-resident A panel per XCD and one W panel
+            if constexpr (DK == 4) {   // timing only: 1-KiB-tiled operands — piece q of a half = row group (8 rows) x K-tile, contiguous
+                const unsigned sw16 = (unsigned)prow * 128u + chunk16;
+#pragma unroll
+                for (int i = 0; i < PP; ++i) offP[i] = (unsigned)(in0 / 8 + PP * mw + i) * (unsigned)nk * 1024u + sw16;
+#pragma unroll
+                for (int i = 0; i < QP; ++i) {
+                    const int q = QP * mw + i;
+                    offQ[i] = (unsigned)(im0 / 8 + 8 * (q >> 2) + (q & 3)) * (unsigned)nk * 1024u + sw16;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < PP; ++i) {   // P piece q = PP mw + i: LDS rows 8 q + prow = 16 t + c
                 const int row = 8 * (PP * mw + i) + prow;
@@ -148,16 +159,18 @@ __global__ __launch_bounds__(512, 1) void gemmsr_kernel(PS p, long long* stamps)
         };
         set_src();
 #define PIECE(voff, sbase, dst)                                                                                   \
-    do { if constexpr (DK == 0 || DK == 3) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0"); } while (0)
+    do { if constexpr (DK == 0 || DK == 3 || DK == 4) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0"); } while (0)
 #define ISSUE(J)                                                                                                  \
     do {                                                                                                          \
         const unsigned st_ = lds0 + (unsigned)((u_is & 1) * STG_B);                                               \
         if ((J) == 0 || (J) == 3) {                                                                               \
-            const char* sb_ = p.W + (size_t)u_is * 128 + ((J) == 3 ? (size_t)p.ldw2 * 4 : 0);                     \
+            const char* sb_ = (DK == 4) ? p.W + (size_t)u_is * 1024 + ((J) == 3 ? (size_t)8 * nk * 1024 : 0)      \
+                                        : p.W + (size_t)u_is * 128 + ((J) == 3 ? (size_t)p.ldw2 * 4 : 0);          \
             const unsigned d_ = st_ + (unsigned)((J) == 3 ? OFF_P1 : OFF_P0) + (unsigned)(mw * PP) * 1024u;       \
             _Pragma("unroll") for (int i = 0; i < PP; ++i) PIECE(offP[i], sb_, d_ + 1024u * i);                   \
         } else {                                                                                                  \
-            const char* sb_ = p.A + (size_t)u_is * 128 + ((J) == 2 ? (size_t)p.lda2 * 32 : 0);                    \
+            const char* sb_ = (DK == 4) ? p.A + (size_t)u_is * 1024 + ((J) == 2 ? (size_t)4 * nk * 1024 : 0)      \
+                                        : p.A + (size_t)u_is * 128 + ((J) == 2 ? (size_t)p.lda2 * 32 : 0);         \
             const unsigned d_ = st_ + (unsigned)((J) == 2 ? OFF_Q1 : OFF_Q0) + (unsigned)(mw * QP) * 1024u;       \
             _Pragma("unroll") for (int i = 0; i < QP; ++i) PIECE(offQ[i], sb_, d_ + 1024u * i);                   \
         }                                                                                                         \
@@ -201,10 +214,12 @@ __global__ __launch_bounds__(512, 1) void gemmsr_kernel(PS p, long long* stamps)
 #define GLOAD(J, SLOT)                                                                                            \
     do {                                                                                                          \
         if ((J) == 0 || (J) == 3) {                                                                               \
-            const char* sb_ = p.W + (size_t)u_is * 128 + ((J) == 3 ? (size_t)p.ldw2 * 4 : 0);                     \
+            const char* sb_ = (DK == 4) ? p.W + (size_t)u_is * 1024 + ((J) == 3 ? (size_t)8 * nk * 1024 : 0)      \
+                                        : p.W + (size_t)u_is * 128 + ((J) == 3 ? (size_t)p.ldw2 * 4 : 0);          \
             _Pragma("unroll") for (int i = 0; i < PP; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(buf[SLOT][i]) : "v"(offP[i]), "s"(sb_) : "memory"); \
         } else {                                                                                                  \
-            const char* sb_ = p.A + (size_t)u_is * 128 + ((J) == 2 ? (size_t)p.lda2 * 32 : 0);                    \
+            const char* sb_ = (DK == 4) ? p.A + (size_t)u_is * 1024 + ((J) == 2 ? (size_t)4 * nk * 1024 : 0)      \
+                                        : p.A + (size_t)u_is * 128 + ((J) == 2 ? (size_t)p.lda2 * 32 : 0);         \
             _Pragma("unroll") for (int i = 0; i < QP; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(buf[SLOT][i]) : "v"(offQ[i]), "s"(sb_) : "memory"); \
         }                                                                                                         \
         if ((J) == 3) {                                                                                           \
@@ -567,6 +582,7 @@ int main(int argc, char** argv) {
         {"split-role, plain, barrier per phase, REGISTER staging", gemmsr_kernel<0, 0, 1>, LDS_PLAIN},
         {"split-role, plain, barrier per phase, NO operand traffic (timing only)", gemmsr_kernel<0, 0, 2>, LDS_PLAIN},
         {"split-role, plain, barrier per phase, operands from ONE L2-hot tile (timing only)", gemmsr_kernel<0, 0, 3>, LDS_PLAIN},
+        {"split-role, plain, barrier per phase, 1-KiB-TILED operand layout (timing only)", gemmsr_kernel<0, 0, 4>, LDS_PLAIN},
         {"split-role, stash + store waves, barrier per phase", gemmsr_kernel<2, 0>, LDS_STASH},
         {"split-role, stash + store waves, barrier per 2", gemmsr_kernel<2, 1>, LDS_STASH},
     };
