@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("forced", ["0", "1"])
 def test_bench_prints_exactly_one_json_line(forced):
     env = dict(os.environ, CLIBD_FORCE_COLLECTIVES=forced)
+    # (the forced-collectives run skips the host-batch legs; the plain run keeps them: round 5's steady-state / uint8 legs are part of the line)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--per-gpu-batch", "32", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-h2d"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--no-cpu-baseline"] + (["--no-h2d"] if forced == "1" else []), capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     if forced == "1" and r.returncode != 0 and "init_process_group" in r.stderr:
         pytest.skip("one-rank RCCL process group unavailable on this box")
     assert r.returncode == 0, r.stderr[-3000:]
@@ -41,5 +42,12 @@ def test_bench_prints_exactly_one_json_line(forced):
     he = d["host_enqueue_ms"]
     assert all(k in he for k in ("mean", "median", "p95", "cpu_mean", "cpu_median")) and 0 < he["cpu_median"] <= he["p95"] * 1.5 + 1.0
     assert roof["step_frac_gflop_per_pair"] == 117.6
+    # round 5: the step at the reference's backward numerics rides in the same line; the host-fed legs are steady state + uint8 images
+    rn = d["reference_numerics"]
+    assert rn["value"] > 0 and rn["numerics"] == {"residual_grad": "fp32", "gelu_grad": "bf16", "attn_bwd": "2phase"}
     if forced == "1":
         assert "collectives" in d
+    else:
+        h = d["h2d_inclusive"]
+        assert h["value"] > 0 and h["copy_at_top_of_step"]["value"] > 0 and h["uint8_images"]["value"] > 0
+        assert h["uint8_images"]["host_bytes_per_step_per_gpu"] < h["host_bytes_per_step_per_gpu"] / 3
