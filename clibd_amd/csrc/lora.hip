@@ -185,7 +185,12 @@ __global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ t,
                                                               const unsigned short* __restrict__ dt, int ld_dt, int M, int H,
                                                               float* __restrict__ dA_q, float* __restrict__ dA_v,
-                                                              float* __restrict__ dB_q, float* __restrict__ dB_v, int which0) {
+                                                              float* __restrict__ dB_q, float* __restrict__ dB_v, int which0,
+                                                              float* __restrict__ ws) {
+    // ws (round 5): per-workgroup partials instead of float atomics — copy blockIdx.x of [dB_q | dB_v | dA_q | dA_v] (16 H floats);
+    // this workgroup writes its own column segment of its own matrix there (plain stores: every element of a copy has one writer), and
+    // lora_reduce_kernel adds the copies in a fixed order: no 256-way contended atomics (38-54 us of a 286-377 us backward at b = 2048:
+    // profiles/r05_exp_lora_atomics_bound.log) and a gradient that is bit-reproducible.  nullptr: the float atomics of rounds 1-4.
     // which0: first matrix of the launch (0: dq, dv and x segments, grid.y = 6;  2: the x segments only, grid.y = 2 — dB then
     // comes from lora_dt_db_kernel)
     extern __shared__ __attribute__((aligned(16))) char lsm[];
@@ -263,11 +268,19 @@ __global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const unsigned sho
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int col = col0 + 64 * tl + 16 * d + 4 * g + r;
-                        float* dst = (which == 0) ? dB_q + (size_t)col * 4 + c
-                                   : (which == 1) ? dB_v + (size_t)col * 4 + (c - 4)
-                                   : (c < 12)     ? dA_q + (size_t)(c - 8) * H + col
-                                                  : dA_v + (size_t)(c - 12) * H + col;
-                        atomicAdd(dst, acc[a][d][r]);
+                        if (ws != nullptr) {
+                            const size_t idx = (which == 0) ? (size_t)col * 4 + c
+                                             : (which == 1) ? (size_t)4 * H + (size_t)col * 4 + (c - 4)
+                                             : (c < 12)     ? (size_t)8 * H + (size_t)(c - 8) * H + col
+                                                            : (size_t)12 * H + (size_t)(c - 12) * H + col;
+                            ws[(size_t)blockIdx.x * 16 * H + idx] = acc[a][d][r];
+                        } else {
+                            float* dst = (which == 0) ? dB_q + (size_t)col * 4 + c
+                                       : (which == 1) ? dB_v + (size_t)col * 4 + (c - 4)
+                                       : (c < 12)     ? dA_q + (size_t)(c - 8) * H + col
+                                                      : dA_v + (size_t)(c - 12) * H + col;
+                            atomicAdd(dst, acc[a][d][r]);
+                        }
                     }
             }
         }
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(256) void lora_dt_db_kernel(const unsigned short* _
                                                          const unsigned short* __restrict__ t,
                                                          const unsigned short* __restrict__ w_dt,   // [16, 3H]
                                                          unsigned short* __restrict__ dt, int ld_dt, int M, int H,
-                                                         float* __restrict__ dB_q, float* __restrict__ dB_v) {
+                                                         float* __restrict__ dB_q, float* __restrict__ dB_v, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     constexpr int IMG = 4 * 4096;                 // one chunk: four [32][64] tiles
     char* img = lsm;                              // 2 x IMG
@@ -397,10 +410,33 @@ __global__ __launch_bounds__(256) void lora_dt_db_kernel(const unsigned short* _
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int col = 256 * c - (isv ? H : 0) + 64 * wave + 16 * d + 4 * g + r;
-                    atomicAdd((isv ? dB_v : dB_q) + (size_t)col * 4 + (isv ? cc - 4 : cc), accB[c][d][r]);
+                    if (ws != nullptr) ws[(size_t)blockIdx.x * 16 * H + (isv ? (size_t)4 * H : 0) + (size_t)col * 4 + (isv ? cc - 4 : cc)] = accB[c][d][r];   // (see lora_wgrad_mfma_kernel)
+                    else atomicAdd((isv ? dB_v : dB_q) + (size_t)col * 4 + (isv ? cc - 4 : cc), accB[c][d][r]);
                 }
         }
     }
+}
+
+// dst[i] += sum over copies x < G of ws[x][i], copies added in index order (deterministic).  Element i of the copy layout
+// [dB_q (4H) | dB_v (4H) | dA_q (4H) | dA_v (4H)]; the dB half was written by g_b workgroups, the dA half by g_a (0: that half is skipped).
+__global__ __launch_bounds__(256) void lora_reduce_kernel(const float* __restrict__ ws, int H, int g_b, int g_a, float* __restrict__ dB_q,
+                                                          float* __restrict__ dB_v, float* __restrict__ dA_q, float* __restrict__ dA_v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 16 * H) return;
+    const int part = i / (4 * H);
+    const int G = part < 2 ? g_b : g_a;
+    if (G <= 0) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four chains, recombined in a fixed order
+    int x = 0;
+    for (; x + 4 <= G; x += 4) {
+        s0 += ws[(size_t)x * 16 * H + i];
+        s1 += ws[(size_t)(x + 1) * 16 * H + i];
+        s2 += ws[(size_t)(x + 2) * 16 * H + i];
+        s3 += ws[(size_t)(x + 3) * 16 * H + i];
+    }
+    for (; x < G; ++x) s0 += ws[(size_t)x * 16 * H + i];
+    float* dst = part == 0 ? dB_q : part == 1 ? dB_v : part == 2 ? dA_q : dA_v;
+    dst[i - part * 4 * H] += (s0 + s1) + (s2 + s3);
 }
 
 // Standalone down-projection t[m, 0:8] = bf16(x[m, :] . a_cat[0:8, :]^T) (bf16 operands, fp32 accumulation) — the arithmetic the
@@ -446,8 +482,32 @@ extern "C" int clibd_lora_pack(const float* a_q, const float* a_v, const float* 
     return check_launch("lora_pack");
 }
 
+static int lora_num_cus() {
+    static const int n = [] {
+        int dev = 0, c = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c = prop.multiProcessorCount;
+        return c;
+    }();
+    return n;
+}
+
+// Partials workspace of the adapters' gradient kernels (ABI 3): one copy of [dB_q | dB_v | dA_q | dA_v] (16 H floats) per workgroup
+// column of the MFMA forms; 0 for shapes that take the VALU kernel (ragged M), which keeps its per-block float atomics.
+extern "C" size_t clibd_lora_workspace_bytes(int M, int H) {
+    if (M <= 0 || H <= 0 || M % 32 != 0 || H % 128 != 0) return 0;
+    const int g = lora_num_cus() < M / 32 ? lora_num_cus() : M / 32;
+    return (size_t)g * 16 * (size_t)H * sizeof(float);
+}
+
+static int lora_reduce_launch(const float* ws, int H, int g_b, int g_a, float* dA_q, float* dA_v, float* dB_q, float* dB_v, hipStream_t st) {
+    hipLaunchKernelGGL(lora_reduce_kernel, dim3((unsigned)((16 * H + 255) / 256)), dim3(256), 0, st, ws, H, g_b, g_a, dB_q, dB_v, dA_q, dA_v);
+    return check_launch("lora_reduce");
+}
+
 extern "C" int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* dt_bf16,
-                                int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v, void* stream) {
+                                int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v,
+                                void* workspace, size_t workspace_bytes, void* stream) {
     if (!dqkv || !x_bf16 || !t_bf16 || !dt_bf16 || !dA_q || !dA_v || !dB_q || !dB_v)
         return set_error(CLIBD_EINVAL, "lora_wgrad: null pointer");
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "lora_wgrad: H must be a multiple of 64, <= 1024");
@@ -456,29 +516,32 @@ extern "C" int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf1
         return set_error(CLIBD_EINVAL, "lora_wgrad: alignment");
     // large M: the MFMA form (needs whole 32-token slabs, 128-column segments and the dt rows at 16-byte pitch)
     if (M % LWM_ROWS == 0 && M >= 8192 && H % 128 == 0 && (H / 128 == 3 || H / 128 == 4 || H / 128 == 6 || H / 128 == 8) && ld_dt % 8 == 0) {
-        static const int num_cus = [] {
-            int dev = 0, n = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-            return n;
-        }();
+        const int num_cus = lora_num_cus();
         const int tiles = H / 128;
         const int want = (2 * num_cus + 5) / 6;   // x 6 segments: two workgroups (2 x 56 KiB of LDS at H = 768) per CU
         const int groups = want < M / LWM_ROWS ? want : M / LWM_ROWS;
         const size_t ldsm = (size_t)2 * (tiles + 1) * 4096;
+        // partials instead of float atomics when the caller brought the workspace (nullptr: the atomics of rounds 1-4)
+        float* ws = nullptr;
+        if (workspace != nullptr) {
+            if (!aligned16(workspace) || workspace_bytes < (size_t)groups * 16 * (size_t)H * sizeof(float))
+                return set_error(CLIBD_EINVAL, "lora_wgrad: workspace too small or misaligned (clibd_lora_workspace_bytes)");
+            ws = (float*)workspace;
+        }
 #define LWM_LAUNCH(T)                                                                                                 \
     do {                                                                                                              \
         hipFuncSetAttribute((const void*)lora_wgrad_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);   \
         hipLaunchKernelGGL((lora_wgrad_mfma_kernel<T>), dim3(groups, 6), dim3(256), ldsm, (hipStream_t)stream,        \
                            (const unsigned short*)dqkv, ld_dqkv, (const unsigned short*)x_bf16, (const unsigned short*)t_bf16, \
-                           (const unsigned short*)dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, 0);                   \
+                           (const unsigned short*)dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, 0, ws);               \
     } while (0)
         if (tiles == 3) LWM_LAUNCH(3);
         else if (tiles == 4) LWM_LAUNCH(4);
         else if (tiles == 6) LWM_LAUNCH(6);
         else LWM_LAUNCH(8);
 #undef LWM_LAUNCH
-        return check_launch("lora_wgrad");
+        if (int e = check_launch("lora_wgrad")) return e;
+        return ws ? lora_reduce_launch(ws, H, groups, groups, dA_q, dA_v, dB_q, dB_v, (hipStream_t)stream) : CLIBD_OK;
     }
     const int blocks = (M + LW_ROWS - 1) / LW_ROWS;
     const size_t lds = ((size_t)3 * (H / 4) * 16 + (size_t)4 * H + (size_t)(4 * H) / 32 + 32) * sizeof(float);
@@ -493,7 +556,7 @@ extern "C" int clibd_gemm_bf16_nt_khole(const void* A, int lda, const void* W, i
 
 extern "C" int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* w_dt_bf16,
                                    void* dt_bf16, int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v,
-                                   void* stream) {
+                                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!dqkv || !x_bf16 || !t_bf16 || !w_dt_bf16 || !dt_bf16 || !dA_q || !dA_v || !dB_q || !dB_v)
         return set_error(CLIBD_EINVAL, "lora_backward: null pointer");
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "lora_backward: H must be a multiple of 64, <= 1024");
@@ -511,24 +574,27 @@ extern "C" int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_
         ep.ld_out_bf16 = ld_dt;
         ep.split_k = 1;
         if (int e = clibd_gemm_bf16_nt_khole(dqkv, ld_dqkv, w_dt_bf16, 3 * H, M, 16, 3 * H, H, H, &ep, stream)) return e;
-        return clibd_lora_wgrad(dqkv, ld_dqkv, x_bf16, t_bf16, dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, stream);
+        return clibd_lora_wgrad(dqkv, ld_dqkv, x_bf16, t_bf16, dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, workspace, workspace_bytes, stream);
     }
-    static const int num_cus = [] {
-        int dev = 0, n = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-        return n;
-    }();
+    const int num_cus = lora_num_cus();
     const int nslab = M / LWM_ROWS;
+    float* ws = nullptr;
+    if (workspace != nullptr) {
+        if (!aligned16(workspace) || workspace_bytes < clibd_lora_workspace_bytes(M, H))
+            return set_error(CLIBD_EINVAL, "lora_backward: workspace too small or misaligned (clibd_lora_workspace_bytes)");
+        ws = (float*)workspace;
+    }
+    int g_b = 0, g_a = 0;
     {   // dt and dB: one workgroup per CU
         const int groups = num_cus < nslab ? num_cus : nslab;
+        g_b = groups;
         const size_t lds1 = (size_t)2 * 4 * 4096 + 2 * 4096 + (size_t)4 * nch * 2048 + 4 * 2 * 64 * 16;
 #define LDB_LAUNCH(N_)                                                                                                \
     do {                                                                                                              \
         hipFuncSetAttribute((const void*)lora_dt_db_kernel<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);       \
         hipLaunchKernelGGL((lora_dt_db_kernel<N_>), dim3(groups), dim3(256), lds1, (hipStream_t)stream,              \
                            (const unsigned short*)dqkv, ld_dqkv, (const unsigned short*)t_bf16, (const unsigned short*)w_dt_bf16, \
-                           (unsigned short*)dt_bf16, ld_dt, M, H, dB_q, dB_v);                                        \
+                           (unsigned short*)dt_bf16, ld_dt, M, H, dB_q, dB_v, ws);                                    \
     } while (0)
         if (nch == 4) LDB_LAUNCH(4);
         else if (nch == 6) LDB_LAUNCH(6);
@@ -540,13 +606,14 @@ extern "C" int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_
         const int tiles = H / 128;
         const int want = (2 * num_cus + 1) / 2;
         const int groups = want < nslab ? want : nslab;
+        g_a = groups;
         const size_t ldsm = (size_t)2 * (tiles + 1) * 4096;
 #define LWM_LAUNCH2(T)                                                                                                \
     do {                                                                                                              \
         hipFuncSetAttribute((const void*)lora_wgrad_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);   \
         hipLaunchKernelGGL((lora_wgrad_mfma_kernel<T>), dim3(groups, 2), dim3(256), ldsm, (hipStream_t)stream,        \
                            (const unsigned short*)dqkv, ld_dqkv, (const unsigned short*)x_bf16, (const unsigned short*)t_bf16, \
-                           (const unsigned short*)dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, 2);                   \
+                           (const unsigned short*)dt_bf16, ld_dt, M, H, dA_q, dA_v, dB_q, dB_v, 2, ws);               \
     } while (0)
         if (tiles == 3) LWM_LAUNCH2(3);
         else if (tiles == 4) LWM_LAUNCH2(4);
@@ -554,7 +621,8 @@ extern "C" int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_
         else LWM_LAUNCH2(8);
 #undef LWM_LAUNCH2
     }
-    return check_launch("lora_backward (dA)");
+    if (int e = check_launch("lora_backward (dA)")) return e;
+    return ws ? lora_reduce_launch(ws, H, g_b, g_a, dA_q, dA_v, dB_q, dB_v, (hipStream_t)stream) : CLIBD_OK;
 }
 
 extern "C" int clibd_lora_down_proj(const void* x_bf16, int ld_x, const void* a_cat_bf16, int M, int H, void* t_bf16, void* stream) {

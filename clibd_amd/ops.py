@@ -447,7 +447,22 @@ def lora_down_proj(x: torch.Tensor, a_cat: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v) -> None:
+def _lora_workspace(M: int, H: int, device, workspace):
+    """(pointer, bytes) of the adapters' partials workspace: the caller's buffer, a fresh one (deterministic sums, no contended
+    float atomics), or (None, 0) when `workspace` is False (the float atomics of rounds 1-4) / the shape takes the VALU kernel."""
+    if workspace is False:
+        return None, 0
+    need = int(_lib.load().clibd_lora_workspace_bytes(M, H))
+    if need == 0:
+        return None, 0
+    if workspace is None or workspace is True:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=device)
+    if workspace.numel() * workspace.element_size() < need:
+        raise ValueError("lora workspace too small (clibd_lora_workspace_bytes)")
+    return workspace, need
+
+
+def lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v, workspace=None) -> None:
     _chk(dqkv, BF16, "dqkv")
     _chk(x, BF16, "x")
     _chk(t, BF16, "t")
@@ -459,12 +474,15 @@ def lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v) -> None:
         _chk(g, F32, nm)
         if tuple(g.shape) != shape:
             raise ValueError(f"lora_wgrad: {nm} must be {shape}")
+    ws, nb = _lora_workspace(M, H, x.device, workspace)
     check(_lib.load().clibd_lora_wgrad(dqkv.data_ptr(), 3 * H, x.data_ptr(), t.data_ptr(), dt.data_ptr(), dt.shape[1], M, H,
-                                       dA_q.data_ptr(), dA_v.data_ptr(), dB_q.data_ptr(), dB_v.data_ptr(), _stream()), "lora_wgrad")
+                                       dA_q.data_ptr(), dA_v.data_ptr(), dB_q.data_ptr(), dB_v.data_ptr(),
+                                       ws.data_ptr() if ws is not None else None, nb, _stream()), "lora_wgrad")
 
 
-def lora_backward(dqkv, x, t, w_dt, dt, dA_q, dA_v, dB_q, dB_v) -> None:
-    """dt = dqkv . w_dt^T (written, bf16 [M,16]) and the adapters' four parameter gradients (accumulated); see clibd_lora_backward."""
+def lora_backward(dqkv, x, t, w_dt, dt, dA_q, dA_v, dB_q, dB_v, workspace=None) -> None:
+    """dt = dqkv . w_dt^T (written, bf16 [M,16]) and the adapters' four parameter gradients (accumulated); see clibd_lora_backward.
+    workspace: None = a partials buffer is allocated (deterministic, atomics-free sums), a uint8 tensor = the caller's, False = float atomics."""
     _chk(dqkv, BF16, "dqkv")
     _chk(x, BF16, "x")
     _chk(t, BF16, "t")
@@ -477,8 +495,10 @@ def lora_backward(dqkv, x, t, w_dt, dt, dA_q, dA_v, dB_q, dB_v) -> None:
         _chk(g, F32, nm)
         if tuple(g.shape) != shape:
             raise ValueError(f"lora_backward: {nm} must be {shape}")
+    ws, nb = _lora_workspace(M, H, x.device, workspace)
     check(_lib.load().clibd_lora_backward(dqkv.data_ptr(), 3 * H, x.data_ptr(), t.data_ptr(), w_dt.data_ptr(), dt.data_ptr(), 16, M, H,
-                                          dA_q.data_ptr(), dA_v.data_ptr(), dB_q.data_ptr(), dB_v.data_ptr(), _stream()), "lora_backward")
+                                          dA_q.data_ptr(), dA_v.data_ptr(), dB_q.data_ptr(), dB_v.data_ptr(),
+                                          ws.data_ptr() if ws is not None else None, nb, _stream()), "lora_backward")
 
 
 def patchify(image: torch.Tensor) -> torch.Tensor:

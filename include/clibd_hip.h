@@ -232,15 +232,21 @@ int clibd_lora_pack(const float* a_q, const float* a_v, const float* b_q, const 
  * rank-(4+4) slot; adapters with 4 < r <= 8 — the reference accepts any r > 0, image_encoder.py:50-53, dna_encoder.py:80-88 —
  * carry ranks 5..8 in a second slot whose t comes from here).  x bf16 row stride ld_x (% 8), H % 8 == 0. */
 int clibd_lora_down_proj(const void* x_bf16, int ld_x, const void* a_cat_bf16, int M, int H, void* t_bf16, void* stream);
+/* workspace (ABI 3; may be NULL): clibd_lora_workspace_bytes(M, H) bytes, 16-byte aligned.  With it the MFMA forms (M % 32 == 0,
+ * H % 128 == 0) write per-workgroup partials there and a last kernel adds them in a fixed order: no contended float atomics (38-54 us
+ * of a 286-377 us backward at M = 403 456 / 272 384) and gradients that are bit-reproducible run to run; NULL keeps the float atomics. */
+size_t clibd_lora_workspace_bytes(int M, int H);
 int clibd_lora_wgrad(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* dt_bf16,
-                     int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v, void* stream);
+                     int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v,
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* The adapters' whole backward in one call: dt[M, 0:16] = dqkv . w_dt^T (bf16; columns 8..15 zero: the rank-8 operand of the QKV
  * dgrad), then the four parameter gradients of clibd_lora_wgrad (accumulating).  For large M (whole 32-token slabs, H % 128 == 0)
  * dq and dv are read ONCE: a first kernel produces dt and dB together, a second one dA from x and dt; otherwise it is the skinny
  * GEMM (clibd_gemm_bf16_nt_khole against w_dt) followed by clibd_lora_wgrad.  Replaces the autograd of _LoRA_qkv_timm.forward /
  * _LoRALayer.forward (image_encoder.py:40-46, dna_encoder.py:75-77) with respect to the adapter weights. */
 int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_bf16, const void* t_bf16, const void* w_dt_bf16,
-                        void* dt_bf16, int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v, void* stream);
+                        void* dt_bf16, int ld_dt, int M, int H, float* dA_q, float* dA_v, float* dB_q, float* dB_v,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Embeddings.

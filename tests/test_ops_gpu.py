@@ -452,6 +452,42 @@ def test_lora_backward_one_pass_over_dq_dv(ops, dev, M, H):
         assert rel_err(got.cpu().double() - i0.double(), ref) < 2e-5, name
 
 
+@pytest.mark.parametrize("M", [50432, 262144])
+def test_lora_backward_with_a_partials_workspace_is_deterministic(ops, dev, M):
+    """Round 5 (ABI 3): with a workspace (the default of ops.lora_backward / ops.lora_wgrad) the MFMA forms of the adapters' gradient
+    kernels write per-workgroup partials and a last kernel adds them in a fixed order — no contended float atomics.  The gradients are
+    then bit-identical run to run (the float-atomic form, workspace=False, is not in general) and equal to the atomic form's to
+    summation order; dt is unaffected.  M = 50 432 takes the two-call path (skinny GEMM + weight-gradient kernel), M = 262 144 the fused one."""
+    H = 768
+    g = torch.Generator().manual_seed(M)
+    w_dt = (torch.randn(16, 3 * H, generator=g) * 0.1).to(dev, BF16)
+    w_dt[8:] = 0
+    w_dt[:, H:2 * H] = 0
+    dqkv = torch.randn(M, 3 * H, generator=g).to(dev, BF16)
+    x = torch.randn(M, H, generator=g).to(dev, BF16)
+    t = torch.randn(M, 8, generator=g).to(dev, BF16)
+
+    def run(workspace):
+        grads = [torch.zeros((4, H), device=dev), torch.zeros((4, H), device=dev), torch.zeros((H, 4), device=dev), torch.zeros((H, 4), device=dev)]
+        dt = torch.empty((M, 16), dtype=BF16, device=dev)
+        ops.lora_backward(dqkv, x, t, w_dt, dt, *grads, workspace=workspace)
+        torch.cuda.synchronize()
+        return [v.clone() for v in grads] + [dt]
+
+    a, b_, c = run(None), run(None), run(False)
+    for u, v in zip(a, b_):
+        assert torch.equal(u, v), "the workspace form must be bit-reproducible"
+    assert torch.equal(a[4], c[4])
+    for name, u, v in zip(("dA_q", "dA_v", "dB_q", "dB_v"), a, c):
+        assert rel_err(u.cpu().double(), v.cpu().double()) < 2e-6, name
+    own = torch.empty((int(ops._lib.load().clibd_lora_workspace_bytes(M, H)),), dtype=torch.uint8, device=dev)   # the caller's buffer
+    d = run(own)
+    for u, v in zip(a, d):
+        assert torch.equal(u, v)
+    with pytest.raises(ValueError):
+        ops.lora_backward(dqkv, x, t, w_dt, torch.empty((M, 16), dtype=BF16, device=dev), *[torch.zeros_like(v) for v in a[:4]], workspace=own[:1024])
+
+
 # ----------------------------------------------------------------------------------------------- embeddings / heads
 def test_patchify_matches_conv_unfold(ops, dev):
     g = torch.Generator().manual_seed(12)

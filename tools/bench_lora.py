@@ -28,5 +28,6 @@ for M in (50432, 403456, 272384):
         ops.lora_wgrad(dqkv, x, t, dt, dA_q, dA_v, dB_q, dB_v)
     a = timeit(two_calls)
     b = timeit(lambda: ops.lora_backward(dqkv, x, t, w_dt, dt, dA_q, dA_v, dB_q, dB_v))
-    print(f"M={M}: dt GEMM + lora_wgrad {a*1e3:7.1f} us   lora_backward {b*1e3:7.1f} us", flush=True)
+    c = timeit(lambda: ops.lora_backward(dqkv, x, t, w_dt, dt, dA_q, dA_v, dB_q, dB_v, workspace=False))
+    print(f"M={M}: dt GEMM + lora_wgrad {a*1e3:7.1f} us   lora_backward {b*1e3:7.1f} us (partials workspace)   {c*1e3:7.1f} us (float atomics)", flush=True)
     del dqkv, x, t, dt
