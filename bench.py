@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 MAX_SCLK_MHZ = 2400.0         # the shader clock that figure is quoted at
 GF_PER_PAIR_TRAIN = 117.6     # LoRA training step, I+D pair (fwd 58.78 GF + dgrad-only bwd) — the reference model's FLOPs
-REFERENCE_NUMERICS = dict(residual_grad="fp32", gelu_grad="bf16", attn_bwd="2phase")   # the reference's backward semantics (engine.NUMERICS_CHOICES)
+REFERENCE_NUMERICS = dict(residual_grad="fp32", gelu_grad="bf16", attn_bwd="2phase", ln_fold="off")   # the reference's backward semantics (engine.NUMERICS_CHOICES)
 GF_PER_PAIR_FULLFT = 176.3    # full fine-tune (dgrad + wgrad), the authors' final configuration (`disable_lora: true`)
 
 
@@ -598,7 +598,7 @@ def main():
     # that stream in fp32, also under autocast.  Both figures belong in the line.
     ref_num = None
     if not args.no_ref_numerics and not args.fp8_forward:
-        cur = {k: v for k, v in next(iter(model.numerics().values())).items() if k in ("residual_grad", "gelu_grad", "attn_bwd")}
+        cur = {k: v for k, v in next(iter(model.numerics().values())).items() if k in REFERENCE_NUMERICS}
         if cur != REFERENCE_NUMERICS:
             model.set_numerics(**REFERENCE_NUMERICS)
             rsteps = min(args.steps, 5)
@@ -618,7 +618,7 @@ def main():
             ref_num = {"value": b * world * rsteps / float(er.item()), "unit": "paired samples/s", "ms_per_step": float(er.item()) / rsteps * 1e3,
                        "steps": rsteps, "numerics": dict(REFERENCE_NUMERICS),
                        "note": "the same step with every backward-numerics switch at the reference's semantics (fp32 residual-gradient stream, bf16 "
-                               "GELU', two-phase attention backward): what the headline would read without the disclosed relaxations of config.numerics"}
+                               "GELU', two-phase attention backward, LayerNorm as its own pass): what the headline would read without the disclosed relaxations of config.numerics"}
             model.set_numerics(**cur)
             one_step()   # (the weight-image / workspace state of the default numerics is what the following passes measure)
             torch.cuda.synchronize()

@@ -39,6 +39,9 @@ class GemmEpilogue(C.Structure):
         ("drop_thr16", C.c_int32),
         ("drop_scale", C.c_float),
         ("drop_ld", C.c_int32),
+        ("row_sums", c_void_p),
+        ("row_stats", c_void_p),
+        ("col_sum_w", c_void_p),
     ]
 
 
@@ -78,6 +81,8 @@ SIGNATURES = {
     "clibd_lora_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_patchify": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "clibd_patchify_u8": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "clibd_rowsum_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "clibd_ln_fold_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_vit_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "clibd_gelu_bwd_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "clibd_bert_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -56,6 +56,47 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* _
     }
 }
 
+// ---- LayerNorm -> Linear fold (round 5) ------------------------------------------------------------------------------------------
+// stats[m] = (mean, rstd) of row m from the per-slice partial sums the producing GEMM's epilogue wrote (clibd_gemm_epilogue.row_sums:
+// [S][M][2] = sum, sum of squares over slice s of the H = 128 S columns): what clibd_layernorm_fwd's `stats` holds, for the consumer GEMM
+// and for the LayerNorm BACKWARD, which is unchanged.  var = E[x^2] - mean^2 in fp32 (slice sums of <= 128 fp32 values; the rows of a
+// pre-LN residual stream have |mean| << sigma: tools/ln_fold_study.py), clamped at 0.
+__global__ __launch_bounds__(256) void rowsum_finalize_kernel(const float* __restrict__ sums, int S, int M, float inv_h, float eps, float* __restrict__ stats) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < S; ++j) {
+        const float2 v = *(const float2*)(sums + ((size_t)j * M + m) * 2);
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const float mean = s1 * inv_h;
+    const float var = fmaxf(s2 * inv_h - mean * mean, 0.f);
+    *(float2*)(stats + (size_t)m * 2) = make_float2(mean, rsqrtf(var + eps));
+}
+
+// Operand image of a frozen Linear behind a LayerNorm(gamma, beta) for the fold: wg[n,k] = bf16(w[n,k] gamma[k]), s[n] = sum_k float(wg[n,k])
+// (the sum of exactly what the MFMA multiplies), bp[n] = b[n] + sum_k w[n,k] beta[k] (fp32).  One wave per output row, once per weight version.
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ b, int N, int K, unsigned short* __restrict__ wg,
+                                                              float* __restrict__ s, float* __restrict__ bp) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float as = 0.f, ab = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const f32x4 wv = *(const f32x4*)(w + (size_t)n * K + k);
+        const f32x4 gv = *(const f32x4*)(gamma + k), bv = *(const f32x4*)(beta + k);
+        const unsigned short q0 = f2bf(wv[0] * gv[0]), q1 = f2bf(wv[1] * gv[1]), q2 = f2bf(wv[2] * gv[2]), q3 = f2bf(wv[3] * gv[3]);
+        *(uint2*)(wg + (size_t)n * K + k) = make_uint2((unsigned)q0 | ((unsigned)q1 << 16), (unsigned)q2 | ((unsigned)q3 << 16));
+        as += (bf2f(q0) + bf2f(q1)) + (bf2f(q2) + bf2f(q3));
+        ab += (wv[0] * bv[0] + wv[1] * bv[1]) + (wv[2] * bv[2] + wv[3] * bv[3]);
+    }
+    as = wave_sum(as);
+    ab = wave_sum(ab);
+    if (lane == 0) { s[n] = as; bp[n] = (b != nullptr ? b[n] : 0.f) + ab; }
+}
+
 // tok[b,0,:] = cls + pos[0,:];  tok[b,1+p,:] = proj[b*P+p,:] + pos[1+p,:]   (timm VisionTransformer._pos_embed)
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ proj, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, int B, int S, int H,
@@ -409,6 +450,23 @@ extern "C" int clibd_patchify_u8(const unsigned char* image, int B, void* patche
     hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for((size_t)B * 196 * 96)), dim3(256), 0, (hipStream_t)stream, image, B,
                        (unsigned short*)patches_bf16);
     return check_launch("patchify_u8");
+}
+
+extern "C" int clibd_rowsum_finalize(const float* row_sums, int slices, int M, int H, float eps, float* stats, void* stream) {
+    if (!row_sums || !stats || slices <= 0 || M <= 0 || H != 128 * slices) return set_error(CLIBD_EINVAL, "rowsum_finalize: need H == 128 * slices");
+    if (((uintptr_t)row_sums & 7) || ((uintptr_t)stats & 7)) return set_error(CLIBD_EINVAL, "rowsum_finalize: alignment");
+    hipLaunchKernelGGL(rowsum_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, row_sums, slices, M, 1.0f / (float)H, eps, stats);
+    return check_launch("rowsum_finalize");
+}
+
+extern "C" int clibd_ln_fold_weights(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K, void* wg_bf16,
+                                     float* col_sum_w, float* bias_folded, void* stream) {
+    if (!w || !gamma || !beta || !wg_bf16 || !col_sum_w || !bias_folded) return set_error(CLIBD_EINVAL, "ln_fold_weights: null pointer");
+    if (N <= 0 || K <= 0 || K % 4 != 0) return set_error(CLIBD_EINVAL, "ln_fold_weights: K must be a positive multiple of 4");
+    if (!aligned16(w) || !aligned16(gamma) || !aligned16(beta) || ((uintptr_t)wg_bf16 & 7)) return set_error(CLIBD_EINVAL, "ln_fold_weights: alignment");
+    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, bias, N, K,
+                       (unsigned short*)wg_bf16, col_sum_w, bias_folded);
+    return check_launch("ln_fold_weights");
 }
 
 extern "C" int clibd_vit_assemble_tokens(const float* proj, const float* cls, const float* pos, int B, int S, int H, float* tok,

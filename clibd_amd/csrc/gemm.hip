@@ -312,6 +312,17 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, int M, int 
     // ring, two workgroups per CU so epilogues overlap across workgroups — was built and measured: 800 TF at K=768 and
     // 920 TF at K=3072 against 944 / 1300 TF for the 256x256 8-phase kernel, so it was dropped.
     static const int forced = [] { const char* e = getenv("CLIBD_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
+    const bool fold_epi = ep->row_sums != nullptr || ep->row_stats != nullptr;   // LayerNorm -> Linear fold forms: 256x256 kernel only
+    if (fold_epi) {
+        if (epilogue_kind(p.ep) < 0)
+            return set_error(CLIBD_EINVAL, "gemm: LN-fold epilogue: row_sums needs bias + residual_f32 + out_f32 + out_bf16 (act NONE); row_stats needs "
+                                           "col_sum_w + bias + GELU_SAVE_GRAD with out_pre_bf16 + out_bf16; no rank update, dropout or split-K");
+        if ((ep->row_sums && !aligned16(ep->row_sums)) || (ep->row_stats && !aligned16(ep->row_stats)) || (ep->col_sum_w && !aligned16(ep->col_sum_w)))
+            return set_error(CLIBD_EINVAL, "gemm: LN-fold epilogue pointers must be 16-byte aligned");
+        if (forced == 1 || hole_len != 0 || !gemm256_try_launch(p, (hipStream_t)stream))
+            return set_error(CLIBD_EINVAL, "gemm: the LN-fold epilogues exist in the 256x256 kernel only (M >= 1024, N % 256 == 0, K % 128 == 0, >= 128 tiles)");
+        return check_launch("gemm256_bf16_nt");
+    }
     if (forced != 1 && hole_len == 0 && gemm256_try_launch(p, (hipStream_t)stream)) return check_launch("gemm256_bf16_nt");
     const long long nblocks = (long long)p.tiles_m * p.tiles_n * split;
     if (nblocks > 0x7fffffffLL) return set_error(CLIBD_EINVAL, "gemm: grid too large");

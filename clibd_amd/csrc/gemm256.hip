@@ -378,11 +378,14 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         // first use of the bias — is a vmcnt(0) that also waits for the previous row's store: one store in flight per
         // wave, 16 (fc1: 32) serial write round trips per tile.  The bias is therefore an inline-asm load (invisible to the
         // waitcnt pass), and the first row group of the two-pass kinds is loaded up here as well.
-        constexpr bool TWO_PASS = (epi_aux_kind(KIND) || KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP);
+        constexpr bool RES_KIND = (KIND == EPI_RES_F32 || KIND == EPI_RES_F32_DROP || KIND == EPI_RES_F32_COPY);
+        constexpr bool TWO_PASS = (epi_aux_kind(KIND) || RES_KIND || KIND == EPI_ROWNORM_GELU);
         constexpr bool PRELOAD_ROWS = TWO_PASS && !LORA && !FP8;  // (the LoRA / fp8 instantiations have no room for a row group)
         f32x4 bias_q[2];
         uint4 in_aux[8];
         f32x4 in_res[8][2];
+        float2 in_st[8];      // EPI_ROWNORM_GELU: (mean, rstd) of the first row group
+        f32x4 col_s[2];       // EPI_ROWNORM_GELU: s_n of this lane's eight columns
 #define GLOAD128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off ; EPI_OPERAND_LOAD" : "=&v"(dst) : "v"(ptr) : "memory")
         constexpr bool BIAS_ASM = BIAS && !FP8;  // (the fp8 instantiations spill with 8 more registers live across the dequantisation)
         if constexpr (BIAS_ASM) {
@@ -396,7 +399,9 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int mc = min(mb + 16 * n + r, p.M - 1);
-                    if constexpr (KIND == EPI_MUL_AUX_U8) {
+                    if constexpr (KIND == EPI_ROWNORM_GELU) {
+                        in_st[4 * n + r] = *(const float2*)(ep.row_stats + (size_t)mc * 2);
+                    } else if constexpr (KIND == EPI_MUL_AUX_U8) {
                         const uint2 c8 = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
                         in_aux[4 * n + r] = make_uint4(c8.x, c8.y, 0u, 0u);
                     } else if constexpr (epi_aux_kind(KIND)) {
@@ -407,6 +412,10 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                         in_res[4 * n + r][1] = rs[1];
                     }
                 }
+        }
+        if constexpr (KIND == EPI_ROWNORM_GELU) {
+            col_s[0] = *(const f32x4*)(ep.col_sum_w + nb);
+            col_s[1] = *(const f32x4*)(ep.col_sum_w + nb + 4);
         }
         if (has_next) {  // L'_6, L'_7: ahead of the stores in the in-order queue (L'_0..L'_5 went out in phases 2..7)
             ISSUE(1, 2, 1); __builtin_amdgcn_sched_barrier(0);
@@ -425,7 +434,10 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         // ONE tied wait statement on every path (two of them, one per branch, make hipcc merge their results through copies it
         // places BEFORE the wait: stale bias).  Without a next tile there is no LDS-DMA behind the operands: an untied wait for
         // the operands themselves comes first and the tied one is then a no-op that only carries the data dependence.
-        if constexpr (PRELOAD_ROWS && epi_aux_kind(KIND)) {
+        if constexpr (KIND == EPI_ROWNORM_GELU) {   // queue: [bias asm 2] [8 row-stat loads] [2 s_n loads] [4 LDS-DMA]
+            if (!has_next) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            EPI_TIED_WAIT(14);
+        } else if constexpr (PRELOAD_ROWS && epi_aux_kind(KIND)) {
             if (!has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             EPI_TIED_WAIT(12);
         } else if constexpr (PRELOAD_ROWS) {
@@ -527,12 +539,17 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                 // Pass 1 folds bias / dropout / aux / residual into the accumulators in place (loads only, rows clamped):
                 // row group hn = 0 from the operands requested before the prologue, group hn = 1 loads its own (8 aux /
                 // 16 residual 16-B loads in flight); pass 2 only stores.
+                float cs8[8];
+                if constexpr (KIND == EPI_ROWNORM_GELU) {
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) { cs8[e] = col_s[0][e]; cs8[4 + e] = col_s[1][e]; }
+                }
                 FOR_ROWS_HN(0, 1, {
                     const int mc = min(m, p.M - 1);
                     float v[8];
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
-                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = EPV(hm, t);
-                    if constexpr (PRELOAD_ROWS) fold_row8_in<KIND>(ep, mc, nb, v, in_aux[4 * n + r], in_res[4 * n + r][0], in_res[4 * n + r][1]);
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = (KIND == EPI_ROWNORM_GELU) ? acc[hm][t][hn][n][r] : EPV(hm, t);
+                    if constexpr (KIND == EPI_ROWNORM_GELU) fold_rownorm8(v, in_st[4 * n + r].x, in_st[4 * n + r].y, cs8, bias);
+                    else if constexpr (PRELOAD_ROWS) fold_row8_in<KIND>(ep, mc, nb, v, in_aux[4 * n + r], in_res[4 * n + r][0], in_res[4 * n + r][1]);
                     else fold_row8<KIND>(ep, mc, nb, v);
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
                         _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[hm][t][hn][n][r] = v[4 * hm + t];
@@ -542,26 +559,48 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                     const int mc = min(m, p.M - 1);
                     float v[8];
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
-                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = EPV(hm, t);
-                    fold_row8<KIND>(ep, mc, nb, v);
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = (KIND == EPI_ROWNORM_GELU) ? acc[hm][t][hn][n][r] : EPV(hm, t);
+                    if constexpr (KIND == EPI_ROWNORM_GELU) {
+                        const float2 st = *(const float2*)(ep.row_stats + (size_t)mc * 2);
+                        fold_rownorm8(v, st.x, st.y, cs8, bias);
+                    } else {
+                        fold_row8<KIND>(ep, mc, nb, v);
+                    }
                     _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
                         _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[hm][t][hn][n][r] = v[4 * hm + t];
                 })
                 PIN_GROUP(1);
+                float keep1 = 0.f, keep2 = 0.f;   // EPI_RES_F32_COPY: lane c keeps the sums of row j = c of its group's sixteen rows
                 FOR_ROWS({
                     if (m < p.M) {
                         float v[8];
                         _Pragma("unroll") for (int hm = 0; hm < 2; ++hm)
                             _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r];
-                        if (epi_aux_kind(KIND)) {
+                        if (KIND == EPI_ROWNORM_GELU) {
+                            store_row8<EPI_GELU_SAVE>(ep, m, nb, v);
+                        } else if (epi_aux_kind(KIND)) {
                             *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
                         } else {
                             f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
                             o[0] = (f32x4){v[0], v[1], v[2], v[3]};
                             o[1] = (f32x4){v[4], v[5], v[6], v[7]};
+                            if constexpr (KIND == EPI_RES_F32_COPY) {
+                                *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+                                float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                                float s2 = 0.f;
+                                _Pragma("unroll") for (int e = 0; e < 8; ++e) s2 = fmaf(v[e], v[e], s2);
+                                s1 = row16_sum(s1);   // (the 16 lanes of a DPP row share m: all of them are here)
+                                s2 = row16_sum(s2);
+                                if (erow == 8 * hn + 4 * n + r) { keep1 = s1; keep2 = s2; }
+                            }
                         }
                     }
                 })
+                if constexpr (KIND == EPI_RES_F32_COPY) {   // ONE store per wave and tile: 64 rows x (sum, sum of squares) of this 128-column slice
+                    const int jm = mb + 32 * (erow >> 3) + 16 * ((erow >> 2) & 1) + (erow & 3);
+                    const int slice = (n0 >> 7) + wm;
+                    if (jm < p.M) *(float2*)(ep.row_sums + ((size_t)slice * (size_t)p.M + (size_t)jm) * 2) = make_float2(keep1, keep2);
+                }
             } else {
                 FOR_ROWS({
                     if (m < p.M) {
@@ -624,6 +663,8 @@ static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
         case EPI_RES_F32: return K256(EPI_RES_F32);
         case EPI_RES_F32_DROP: return K256(EPI_RES_F32_DROP);
         case EPI_SPLITK_F32: return (const void*)gemm256_bf16_nt_kernel<EPI_SPLITK_F32, false, false, false, false>;
+        case EPI_RES_F32_COPY: return (lora || !bias || diag) ? nullptr : (const void*)gemm256_bf16_nt_kernel<EPI_RES_F32_COPY, false, true, false, false>;
+        case EPI_ROWNORM_GELU: return (lora || !bias || diag) ? nullptr : (const void*)gemm256_bf16_nt_kernel<EPI_ROWNORM_GELU, false, true, false, false>;
         default: return K256(EPI_GENERIC);
     }
 #undef K256
@@ -732,7 +773,10 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     const bool lora = p.ep.rank_u != nullptr;
     const bool diag = g_stamp_buffer != nullptr && !lora;
     void* args[] = {(void*)&q, (void*)&ntiles_i, (void*)&skew_arg, (void*)&stamp_arg};
-    if (hipLaunchKernel(kernel_ptr(kind, lora, p.ep.bias != nullptr, diag), dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) != hipSuccess) return false;
+    if (kind < 0) return false;                                   // an inconsistent fold epilogue (gemm_impl reports it)
+    const void* fn = kernel_ptr(kind, lora, p.ep.bias != nullptr, diag);
+    if (fn == nullptr) return false;
+    if (hipLaunchKernel(fn, dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) != hipSuccess) return false;
     return true;
 }
 

@@ -189,13 +189,19 @@ enum : int {
     EPI_ADD_AUX = 7,       // + aux_bf16 -> out_bf16                            (dgrad joining a bf16 residual-gradient stream)
     EPI_GELU_SAVE_U8 = 8,  // EPI_GELU_SAVE with gelu' as one byte per element     (fc1 forward; opt-in: numerics gelu_grad="u8")
     EPI_MUL_AUX_U8 = 9,    // EPI_MUL_AUX reading those bytes                      (fc2 dgrad x gelu'; opt-in, same switch)
-    EPI_NUM_KINDS = 10,
+    EPI_RES_F32_COPY = 10,    // EPI_RES_F32 + a bf16 copy of the result + per-slice row sums (LN -> Linear fold, producer: ViT projection)
+    EPI_ROWNORM_GELU = 11,    // rstd_m (acc - mean_m s_n) + b'_n -> EPI_GELU_SAVE                  (LN -> Linear fold, consumer: ViT fc1)
+    EPI_NUM_KINDS = 12,
 };
 constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX || kind == EPI_MUL_AUX_U8; }
 
 __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.split_k > 1) return EPI_GENERIC;
     const bool drop = ep.drop_thr16 > 0;
+    if (ep.row_sums != nullptr)
+        return (ep.act == CLIBD_ACT_NONE && !drop && !ep.out_pre_bf16 && ep.residual_f32 && ep.out_f32 && ep.out_bf16 && !ep.rank_u && ep.bias) ? EPI_RES_F32_COPY : -1;
+    if (ep.row_stats != nullptr)
+        return (ep.act == CLIBD_ACT_GELU_SAVE_GRAD && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && !ep.rank_u && ep.bias && ep.col_sum_w) ? EPI_ROWNORM_GELU : -1;
     if (ep.act == CLIBD_ACT_NONE && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_BF16;
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE;
     if (ep.act == CLIBD_ACT_MUL_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX;
@@ -362,6 +368,21 @@ __device__ __forceinline__ void fold_row8_in(const clibd_gemm_epilogue& ep, int 
         v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
         v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
     }
+}
+
+// LN -> Linear fold, consumer: v[e] = rstd * (acc[e] - mean * s[e]) + b'[e]   (st = (mean, rstd) of the row)
+__device__ __forceinline__ void fold_rownorm8(float v[8], float mean, float rstd, const float s[8], const float b[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(rstd, fmaf(-mean, s[e], v[e]), b[e]);
+}
+
+// sum over the 16 lanes of a DPP row (the lanes that hold one output row's 128 columns in gemm256): every lane gets the total
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_mov<DPP_QUAD_XOR1>(x);
+    x += dpp_mov<DPP_QUAD_XOR2>(x);
+    x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
+    x += dpp_mov<DPP_ROW_MIRROR>(x);
+    return x;
 }
 
 // the same with the loads

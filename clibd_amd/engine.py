@@ -55,8 +55,14 @@ class NotSupportedYet(NotImplementedError):
 #   single-pass form needs full sequences without a key mask, S <= 224 and the bf16 forward; everything else (text tower, the
 #   class-row-only last ViT block, fp8-forward mode) keeps the two-phase kernel.  Round 3 measurement: parity-green,
 #   1.7 x fewer MFMAs and half the exponentials per head, but as built 1.17 - 1.24 x SLOWER — it stays opt-in.
-NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"))
-_NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD")
+# ln_fold ("off" default | "on"; env CLIBD_LN_FOLD; pre-LN stacks = the ViT, frozen base, bf16 forward).  A FORWARD switch: norm2 -> mlp.fc1 of a
+#   block runs as the algebraic fold  fc1(LN(x)) = rstd (x . (gamma o W)^T - mean s) + b'  — the projection's epilogue also writes a bf16 copy
+#   of the residual stream and per-slice row sums, a 5-us kernel turns those into (mean, rstd), and fc1 takes the copy and the gamma-scaled
+#   weight image and applies the row terms in its epilogue: the LayerNorm's own HBM pass (6 bytes per element) disappears.  The bf16 rounding
+#   moves from LN(x) to x; measured error of the fc1 pre-activation against fp64: the same (tools/ln_fold_study.py: ratio 1.00 at random
+#   init, 1.2 with 100-sigma outlier channels).  The backward is the unchanged LayerNorm backward (same statistics).  DESIGN.md §3.1c.
+NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"))
+_NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD", ln_fold="CLIBD_LN_FOLD")
 
 
 def default_numerics() -> dict:
@@ -119,7 +125,8 @@ class _LayerCache:
     """bf16 device images of one layer's frozen weights: W [N,K] for forward, W^T [K,N] for dgrad.
     fp8-forward mode adds the e4m3 forward images and their per-channel dequantisation factors (w*8, cs_*)."""
     __slots__ = ("wqkv", "wqkv_t", "bqkv", "wo", "wo_t", "bo", "w1", "w1_t", "b1", "w2", "w2_t", "b2", "g1", "be1", "g2", "be2",
-                 "v_fwd", "v_bwd", "a_cat", "w_dt", "slot2", "wqkv8", "cs_qkv", "wo8", "cs_o", "w18", "cs_1", "w28", "cs_2")
+                 "v_fwd", "v_bwd", "a_cat", "w_dt", "slot2", "wqkv8", "cs_qkv", "wo8", "cs_o", "w18", "cs_1", "w28", "cs_2",
+                 "w1g", "s1", "b1f")   # ln_fold: bf16(gamma2 o W1), its row sums, b1 + W1 beta2
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -263,6 +270,9 @@ class TransformerStack:
                         c.wo8, c.cs_o = ops.quantize_rows_fp8(_f32c(L.proj_w), f8["proj_in"])
                     c.w18, c.cs_1 = ops.quantize_rows_fp8(_f32c(L.fc1_w), f8["fc1_in"])
                     c.w28, c.cs_2 = ops.quantize_rows_fp8(_f32c(L.fc2_w), f8["fc2_in"])
+                c.w1g = c.s1 = c.b1f = None
+                if self.pre_ln and not self.full_mode():   # operand image of the norm2 -> fc1 fold (numerics ln_fold), once per weight version
+                    c.w1g, c.s1, c.b1f = ops.ln_fold_weights(_f32c(L.fc1_w), c.g2, c.be2, c.b1)
                 c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = c.slot2 = None
                 self._cache.append(c)
         self._cache_key = key
@@ -357,6 +367,12 @@ class TransformerStack:
         h_tmp = new(FF, BF16) if (f8s is not None and not save) else None       # the fp8 fc1 form always writes gelu'
         t = t0
         sp_ok = save and key_mask is None and f8s is None and S <= 224 and self.numerics["attn_bwd"] == "sp"
+        # norm2 -> fc1 as the algebraic fold (numerics ln_fold): pre-LN, frozen base, bf16 forward, shapes the 256x256 kernel takes
+        fold = (self.pre_ln and self.numerics["ln_fold"] == "on" and f8s is None and not full and GG == BF16 and H % 256 == 0 and FF % 256 == 0
+                and M >= 1024 and ((M + 255) // 256) * (H // 256) >= 128 and H % 128 == 0)
+        fold_sums = torch.empty((H // 128, M, 2), dtype=F32, device=dev) if fold else None
+        if fold and h_tmp is None and not save:
+            h_tmp = new(FF, BF16)   # the consumer epilogue always writes gelu' (eval forward: into a scratch buffer)
         for i, (L, c) in enumerate(zip(self.layers, self._cache)):
             has_lora = L.lora is not None
             rec = {}
@@ -439,9 +455,16 @@ class TransformerStack:
                         ops.attention_fwd(qkv, B, S, self.heads, None, o, lse=att_sv["lse"], o_lo=att_sv["o_lo"])
                     else:
                         ops.attention_fwd(qkv, B, S, self.heads, key_mask, o)
-                    ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
-                    ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
-                    ops.gemm_nt(xn2, c.w1, bias=c.b1, act=act_save if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
+                    if fold and cal is None:
+                        # norm2 never makes a pass of its own: the projection writes x1, bf16(x1) (into the xn2 temporary) and its row
+                        # sums; (mean, rstd) -> st2 (what the LayerNorm backward reads); fc1 applies them to (x1b . (gamma o W1)^T)
+                        ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1, out_bf16=xn2, row_sums=fold_sums)
+                        ops.rowsum_finalize(fold_sums, self.eps, st2)
+                        ops.gemm_nt(xn2, c.w1g, bias=c.b1f, act=ops.ACT_GELU_SAVE_GRAD, out_pre=h if save else h_tmp, out_bf16=a, row_stats=st2, col_sum_w=c.s1)
+                    else:
+                        ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=x1)
+                        ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2, stats=st2)
+                        ops.gemm_nt(xn2, c.w1, bias=c.b1, act=act_save if save else ops.ACT_GELU, out_pre=h if save else None, out_bf16=a)
                     ops.gemm_nt(a, c.w2, bias=c.b2, residual=x1, out_f32=x2)
                     if crec is not None:
                         crec.update(qkv_in=amax(xn), proj_in=amax(o), fc1_in=amax(xn2), fc2_in=amax(a))

@@ -83,9 +83,14 @@ def gemm_nt(
     split_k: int = 1,
     drop: Optional["Drop"] = None,
     k_hole: Optional[tuple] = None,
+    row_sums: Optional[torch.Tensor] = None,
+    row_stats: Optional[torch.Tensor] = None,
+    col_sum_w: Optional[torch.Tensor] = None,
 ) -> None:
     """out = epilogue(a[M,K] @ w[N,K]^T); see clibd_gemm_bf16_nt in include/clibd_hip.h.
-    k_hole = (k0, length): the K range [k0, k0+length) of both operands is skipped (multiples of 64)."""
+    k_hole = (k0, length): the K range [k0, k0+length) of both operands is skipped (multiples of 64).
+    row_sums (fp32 [N/128, M, 2]) / row_stats (fp32 [M,2]) + col_sum_w (fp32 [N]): the producer / consumer epilogues of the
+    LayerNorm -> Linear fold (clibd_gemm_epilogue.row_sums, .row_stats)."""
     _chk(a, BF16, "a", contiguous=False)
     _chk(w, BF16, "w", contiguous=False)
     lda, ldw = _rowmajor(a, "a"), _rowmajor(w, "w")
@@ -130,11 +135,46 @@ def gemm_nt(
         ep.out_bf16, ep.ld_out_bf16 = out_bf16.data_ptr(), _rowmajor(out_bf16, "out_bf16")
     if out_f32 is not None:
         ep.out_f32, ep.ld_out_f32 = out_f32.data_ptr(), _rowmajor(out_f32, "out_f32")
+    if row_sums is not None:
+        _chk(row_sums, F32, "row_sums")
+        if N % 128 or tuple(row_sums.shape) != (N // 128, M, 2):
+            raise ValueError("gemm_nt: row_sums must be [N/128, M, 2]")
+        ep.row_sums = row_sums.data_ptr()
+    if row_stats is not None or col_sum_w is not None:
+        _chk(row_stats, F32, "row_stats")
+        _chk(col_sum_w, F32, "col_sum_w")
+        if tuple(row_stats.shape) != (M, 2) or col_sum_w.numel() != N:
+            raise ValueError("gemm_nt: row_stats must be [M,2], col_sum_w [N]")
+        ep.row_stats, ep.col_sum_w = row_stats.data_ptr(), col_sum_w.data_ptr()
     if k_hole is not None:
         check(_lib.load().clibd_gemm_bf16_nt_khole(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, int(k_hole[0]), int(k_hole[1]), C.byref(ep),
                                                    _stream()), "gemm_bf16_nt_khole")
         return
     check(_lib.load().clibd_gemm_bf16_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, C.byref(ep), _stream()), "gemm_bf16_nt")
+
+
+def rowsum_finalize(row_sums: torch.Tensor, eps: float, stats: torch.Tensor) -> None:
+    """stats[m] = (mean, rstd) from the fold producer's per-slice sums [S, M, 2] (H = 128 S)."""
+    _chk(row_sums, F32, "row_sums")
+    _chk(stats, F32, "stats")
+    S, M, _ = row_sums.shape
+    if tuple(stats.shape) != (M, 2):
+        raise ValueError("rowsum_finalize: stats must be [M,2]")
+    check(_lib.load().clibd_rowsum_finalize(row_sums.data_ptr(), S, M, 128 * S, float(eps), stats.data_ptr(), _stream()), "rowsum_finalize")
+
+
+def ln_fold_weights(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor]):
+    """(wg bf16 [N,K], col_sum_w fp32 [N], bias_folded fp32 [N]) of a frozen Linear behind LayerNorm(gamma, beta): clibd_ln_fold_weights."""
+    _chk(w, F32, "w")
+    _chk(gamma, F32, "gamma")
+    _chk(beta, F32, "beta")
+    N, K = w.shape
+    wg = torch.empty((N, K), dtype=BF16, device=w.device)
+    s = torch.empty((N,), dtype=F32, device=w.device)
+    bp = torch.empty((N,), dtype=F32, device=w.device)
+    check(_lib.load().clibd_ln_fold_weights(w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr() if bias is not None else None, N, K,
+                                            wg.data_ptr(), s.data_ptr(), bp.data_ptr(), _stream()), "ln_fold_weights")
+    return wg, s, bp
 
 
 def quantize_rows_fp8(w: torch.Tensor, act_scale: float):

@@ -82,6 +82,17 @@ typedef struct clibd_gemm_epilogue {
     int32_t drop_thr16;
     float drop_scale;
     int32_t drop_ld;
+    /* ABI 3 — the algebraic LayerNorm -> Linear fold of a pre-LN block (norm2 -> mlp.fc1 of timm's Block, image_encoder.py:106-107):
+     *   fc1(LN(x)) = rstd_m * ( x . (gamma o W)^T  -  mean_m * s_n ) + b'_n,   s_n = sum_k bf16(gamma_k W[n,k]),  b' = b + W beta.
+     * PRODUCER form (the GEMM that writes x: the attention projection): with row_sums != NULL, act NONE, residual_f32, out_f32 AND
+     * out_bf16 given, the epilogue also stores out_bf16 = bf16(out_f32 value) and, per 128-column slice j of the output,
+     * row_sums[(j * M + m) * 2 + {0, 1}] = sum / sum of squares of row m's fp32 values over that slice (N / 128 slices; 256x256 kernel only).
+     * CONSUMER form (fc1 on A = that bf16 copy, W = bf16(gamma o W)): with row_stats != NULL (fp32 [M, 2]: mean, rstd — what
+     * clibd_layernorm_fwd's `stats` holds, here from clibd_rowsum_finalize) and col_sum_w = s (fp32 [N]), act GELU_SAVE_GRAD, bias = b':
+     * v = rstd_m * (acc - mean_m * s_n) + b'_n before the activation (256x256 kernel only). */
+    float* row_sums;
+    const float* row_stats;
+    const float* col_sum_w;
 } clibd_gemm_epilogue;
 
 int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
@@ -261,6 +272,14 @@ int clibd_patchify(const float* image, int B, void* patches_bf16, void* stream);
  * reference's ToTensor computes on the host, util/dataset.py:185-195), so the result equals clibd_patchify(u8.float() / 255) bit
  * for bit while a quarter of the bytes cross PCIe (train_epoch.py:26-32 copies the fp32 tensor every step).  ABI version 3. */
 int clibd_patchify_u8(const unsigned char* image, int B, void* patches_bf16, void* stream);
+/* LayerNorm -> Linear fold (ABI 3; see clibd_gemm_epilogue.row_sums / row_stats).  clibd_rowsum_finalize: stats[m] = (mean, rstd) of
+ * row m (eps as the LayerNorm's) from the producer GEMM's per-slice sums row_sums[slices][M][2], H = 128 * slices — the `stats` of
+ * clibd_layernorm_fwd, consumed by the fold's consumer GEMM and by the unchanged clibd_layernorm_bwd.  clibd_ln_fold_weights (once per
+ * weight version): wg = bf16(w o gamma) [N,K], col_sum_w[n] = sum_k float(wg[n,k]), bias_folded = bias + w beta (bias may be NULL).
+ * Replaces timm Block's `self.mlp.fc1(self.norm2(x))` pair (vision_transformer.py via image_encoder.py:106-107) without an HBM pass for norm2. */
+int clibd_rowsum_finalize(const float* row_sums, int slices, int M, int H, float eps, float* stats, void* stream);
+int clibd_ln_fold_weights(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K, void* wg_bf16,
+                          float* col_sum_w, float* bias_folded, void* stream);
 int clibd_vit_assemble_tokens(const float* proj, const float* cls, const float* pos, int B, int S, int H, float* tok,
                               void* stream);
 int clibd_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int S, int H, int vocab,

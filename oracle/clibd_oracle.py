@@ -59,6 +59,23 @@ def precision(mode: str):
         _PRECISION = old
 
 
+_LN_FOLD = False
+
+
+@contextlib.contextmanager
+def ln_fold(on: bool = True):
+    """bf16 mode only: norm2 -> mlp.fc1 of every ViT block but the last evaluated as the kernels' algebraic fold
+    (clibd_amd.engine numerics ln_fold="on"): h = rstd (bf16(x) . bf16(gamma o W)^T - mean s) + (b + W beta), statistics from fp32 row
+    sums (var = E[x^2] - mean^2).  The VALUE is the fold's; the gradient is the unfolded pair's (the kernels' backward is the unchanged
+    LayerNorm / dgrad backward), through a straight-through substitution."""
+    global _LN_FOLD
+    old, _LN_FOLD = _LN_FOLD, bool(on)
+    try:
+        yield
+    finally:
+        _LN_FOLD = old
+
+
 def _r(x: torch.Tensor) -> torch.Tensor:
     """bf16 rounding with a straight-through gradient (autocast casts are differentiable identities)."""
     if _PRECISION == "fp32":
@@ -276,8 +293,21 @@ class Mlp(nn.Module):
         self.fc1 = nn.Linear(dim, hidden)
         self.fc2 = nn.Linear(hidden, dim)
 
-    def forward(self, x):
+    def forward(self, x, fold_from=None):
         h = olinear(x, self.fc1.weight, self.fc1.bias, fp8_scale=_fp8_scale(self, "fc1_in"))
+        if fold_from is not None:   # (x1, norm2): the value of the kernels' fold, the gradient of the line above
+            x1, ln = fold_from
+            rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
+            with torch.no_grad():
+                xd = x1.detach()
+                H = xd.shape[-1]
+                mean = xd.sum(-1, keepdim=True) / H
+                var = ((xd * xd).sum(-1, keepdim=True) / H - mean * mean).clamp_min(0.0)
+                rstd = torch.rsqrt(var + ln.eps)
+                wg = rb(self.fc1.weight.detach() * ln.weight.detach())
+                hf = rstd * (rb(xd) @ wg.T - mean * wg.sum(-1)) + (self.fc1.bias.detach() + self.fc1.weight.detach() @ ln.bias.detach())
+                hf = rb(hf)
+            h = h + (hf - h).detach()
         s2 = _fp8_scale(self, "fc2_in")   # fp8: the fc1 epilogue converts gelu(bf16(h)) (fp32) straight to e4m3
         a = gelu_erf(h)
         return olinear(_rg(_r(a) if s2 is None else a), self.fc2.weight, self.fc2.bias, round_out=False, fp8_scale=s2)
@@ -293,6 +323,8 @@ class Block(nn.Module):
 
     def forward(self, x):
         x = x + self.attn(self.norm1(x))
+        if _LN_FOLD and _PRECISION == "bf16" and not getattr(self, "_no_fold", False):
+            return x + self.mlp(self.norm2(x), fold_from=(x, self.norm2))
         return x + self.mlp(self.norm2(x))
 
 
@@ -307,6 +339,7 @@ class VisionTransformer(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
         self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches + 1, dim) * 0.02)
         self.blocks = nn.Sequential(*[Block(dim, heads) for _ in range(depth)])
+        self.blocks[-1]._no_fold = True   # the kernels evaluate the last block on the class row only, unfolded (engine cls_only_last)
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         self.head = nn.Linear(dim, num_classes) if num_classes > 0 else nn.Identity()
 

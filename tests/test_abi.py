@@ -55,11 +55,11 @@ def test_binding_refuses_a_library_built_from_other_sources(lib, monkeypatch):
 def test_epilogue_struct_layout_matches_header():
     from clibd_amd._lib import GemmEpilogue
 
-    # 8 pointers + 8 int32 + 4 dropout words (header order): 8*8 + 12*4 = 112 bytes
-    assert ctypes.sizeof(GemmEpilogue) == 112
+    # 8 pointers + 8 int32 + 4 dropout words + (ABI 3) the three LN-fold pointers: 8*8 + 12*4 + 3*8 = 136 bytes
+    assert ctypes.sizeof(GemmEpilogue) == 136
     assert [f[0] for f in GemmEpilogue._fields_] == ["bias", "rank_u", "rank_v", "aux_bf16", "residual_f32", "out_pre_bf16", "out_bf16",
                                                      "out_f32", "act", "ld_rank_u", "ld_aux", "ld_res", "ld_pre", "ld_out_bf16",
-                                                     "ld_out_f32", "split_k", "drop_seed", "drop_thr16", "drop_scale", "drop_ld"]
+                                                     "ld_out_f32", "split_k", "drop_seed", "drop_thr16", "drop_scale", "drop_ld", "row_sums", "row_stats", "col_sum_w"]
 
 
 def test_host_side_validation_needs_no_gpu(lib):

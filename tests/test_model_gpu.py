@@ -1055,3 +1055,50 @@ def test_full_finetune_residual_grad_streams_agree(dev, name):
         gs = torch.autograd.grad((yo * cot).sum(), [p for _, p in ps], allow_unused=True)
         go = {n: (torch.zeros_like(p) if g_ is None else g_) for (n, p), g_ in zip(ps, gs)}
     assert_grads(res["fp32"][1], go, rel_tol=3e-2, cos_tol=0.999, what=f"{name} full fine-tune, fp32 stream vs oracle", zero_tol=2e-6, zero_rel=1e-4)
+
+
+def test_ln_fold_tower_matches_oracle(dev):
+    """numerics ln_fold="on" (round 5): norm2 -> mlp.fc1 of every full ViT block as the algebraic fold (projection epilogue writes the bf16
+    copy of the residual stream and its row sums, fc1's epilogue applies (mean, rstd)): a width-768 ViT of four blocks (three folded, the
+    last on the class row as always) at batch 64 — the smallest batch whose projection GEMM the 256x256 kernel takes — against the oracle
+    evaluating THE SAME fold (value of the fold, gradient of the unfolded pair) at the tower gates, and against the oracle's STANDARD bf16
+    mode at the same gates: the fold moves a rounding point, not the error.  "off" and "on" must differ (the switch reaches the kernels)."""
+    from oracle import clibd_oracle as O
+    from clibd_amd.model import CLIBDImageEncoder, VisionTransformer
+
+    torch.manual_seed(23)
+    om = O.ImageEncoder(O.VisionTransformer(img_size=224, patch=16, dim=768, depth=4, heads=12, num_classes=0), 4, 768)
+    with torch.no_grad():
+        for n, p in om.named_parameters():
+            if "linear_b_" in n:
+                p.normal_(0, 0.02)
+            if "norm2" in n:   # a LayerNorm that is not the identity: gamma, beta enter the folded weight image and bias
+                p.add_(0.2 * torch.randn_like(p))
+    m = CLIBDImageEncoder(VisionTransformer(embed_dim=768, depth=4, num_heads=12, num_classes=0), r=4, num_classes=768)
+    m.load_state_dict(om.state_dict(), strict=True)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(24)
+    img = torch.rand(64, 3, 224, 224, generator=g)
+    cot = torch.randn(64, 768, generator=g)
+    res = {}
+    for mode in ("off", "on"):
+        m.tower().stack.set_numerics(ln_fold=mode)
+        y = m(img.to(dev))
+        res[mode] = (y.detach().cpu(), grads_named(m, (y * cot.to(dev)).sum()))
+    m.tower().stack.set_numerics(ln_fold="off")
+    assert not torch.equal(res["on"][0], res["off"][0]), "the switch did not reach the kernels"
+    assert rel(res["on"][0], res["off"][0]) < 4e-3
+
+    def oracle(fold):
+        with O.precision("bf16"), O.ln_fold(fold):
+            yo = om(img)
+            ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+            return yo.detach(), dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
+
+    yo_f, go_f = oracle(True)
+    yo_s, go_s = oracle(False)
+    e_ff, e_fs, e_ss = rel(res["on"][0], yo_f), rel(res["on"][0], yo_s), rel(res["off"][0], yo_s)
+    print(f"[ln_fold] embeddings: fold vs oracle-fold {e_ff:.2e}, fold vs oracle-standard {e_fs:.2e}, standard vs oracle-standard {e_ss:.2e}")
+    assert e_ff < 3e-3 and e_ss < 3e-3 and e_fs < 4e-3
+    assert_grads(res["on"][1], go_f, what="ln_fold on vs oracle fold")
+    assert_grads(res["on"][1], go_s, rel_tol=3e-2, cos_tol=0.999, what="ln_fold on vs oracle standard")

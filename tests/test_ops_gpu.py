@@ -1233,3 +1233,54 @@ def test_layernorm_bwd_any_bf16_stream_with_param_grads(ops, dev, M, H, f32dy, d
     assert rel_err(dg.cpu(), dg_r.cpu().double()) < 1e-5 and rel_err(db.cpu(), db_r.cpu().double()) < 1e-5
     with pytest.raises(ValueError):
         ops.layernorm_bwd(dyd, x, st, gam, dres_bf16=dres16, dx_res_bf16=res, dgamma=dg)       # d(gamma) and d(beta) come together
+
+
+def test_ln_fold_epilogues(ops, dev):
+    """Round 5, the algebraic LayerNorm -> Linear fold (clibd_gemm_epilogue.row_sums / row_stats): the PRODUCER epilogue (projection:
+    bias + fp32 residual -> fp32 out, its bf16 copy and per-128-column-slice row sums), clibd_rowsum_finalize (mean, rstd), clibd_ln_fold_weights
+    and the CONSUMER epilogue (rstd (acc - mean s) + b' -> GELU + GELU') against fp64 statements of the same operands, and against the
+    unfolded pair LayerNorm -> Linear it replaces."""
+    M, H, FF = 50 * 256 + 5, 768, 3072
+    g = torch.Generator().manual_seed(321)
+    a = torch.randn(M, H, generator=g).to(dev, BF16)
+    wo = (torch.randn(H, H, generator=g) * 0.03).to(dev, BF16)
+    bo = (torch.randn(H, generator=g) * 0.1).to(dev)
+    res = (torch.randn(M, H, generator=g) * 1.5 + 0.2).to(dev)
+    x1, x1b = torch.empty((M, H), device=dev), torch.empty((M, H), dtype=BF16, device=dev)
+    sums = torch.full((H // 128, M, 2), float("nan"), device=dev)
+    ops.gemm_nt(a, wo, bias=bo, residual=res, out_f32=x1, out_bf16=x1b, row_sums=sums)
+    ref = torch.empty((M, H), device=dev)
+    ops.gemm_nt(a, wo, bias=bo, residual=res, out_f32=ref)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, ref)                                           # the plain kind's value, bit for bit
+    assert torch.equal(x1b.view(torch.int16), x1.to(BF16).view(torch.int16))   # its bf16 rounding
+    s_ref = torch.stack([x1.double().view(M, H // 128, 128).sum(-1).T, (x1.double() ** 2).view(M, H // 128, 128).sum(-1).T], dim=-1)
+    assert rel_err(sums.cpu().double(), s_ref.cpu()) < 2e-6
+    stats = torch.empty((M, 2), device=dev)
+    ops.rowsum_finalize(sums, 1e-6, stats)
+    mean64 = x1.double().mean(-1)
+    rstd64 = (x1.double().var(-1, unbiased=False) + 1e-6).rsqrt()
+    torch.cuda.synchronize()
+    assert float((stats[:, 0].double() - mean64).abs().max()) < 1e-5 and rel_err(stats[:, 1].cpu().double(), rstd64.cpu()) < 1e-5
+    # consumer
+    gamma, beta = (1.0 + 0.2 * torch.randn(H, generator=g)).to(dev), (0.1 * torch.randn(H, generator=g)).to(dev)
+    w1 = (torch.randn(FF, H, generator=g) * 0.03).to(dev)
+    b1 = (torch.randn(FF, generator=g) * 0.1).to(dev)
+    wg, s_n, bp = ops.ln_fold_weights(w1, gamma, beta, b1)
+    torch.cuda.synchronize()
+    assert torch.equal(wg.view(torch.int16), (w1 * gamma).to(BF16).view(torch.int16))
+    assert rel_err(s_n.cpu().double(), wg.double().sum(-1).cpu()) < 1e-6 and rel_err(bp.cpu().double(), (b1.double() + w1.double() @ beta.double()).cpu()) < 1e-6
+    act, dg = torch.empty((M, FF), dtype=BF16, device=dev), torch.empty((M, FF), dtype=BF16, device=dev)
+    ops.gemm_nt(x1b, wg, bias=bp, act=ops.ACT_GELU_SAVE_GRAD, out_pre=dg, out_bf16=act, row_stats=stats, col_sum_w=s_n)
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 512), torch.arange(M - 300, M)])
+    h64 = stats[rows, 1:2].double() * (x1b[rows].double() @ wg.double().T - stats[rows, 0:1].double() * s_n.double()) + bp.double()
+    pre = h64.float().to(BF16).float()
+    assert rel_err(act[rows].float().cpu(), torch.nn.functional.gelu(pre).cpu()) < 5e-3
+    assert rel_err(dg[rows].float().cpu(), gelu_grad(pre.cpu())) < 5e-3
+    # against the pair it replaces: LayerNorm (fp32 statistics, bf16 output) -> Linear -> GELU
+    xn = torch.nn.functional.layer_norm(x1[rows], (H,), gamma, beta, 1e-6).to(BF16)
+    h_std = (xn.double() @ w1.to(BF16).double().T + b1.double()).float()
+    assert rel_err(act[rows].float().cpu(), torch.nn.functional.gelu(h_std.to(BF16).float()).cpu()) < 1.2e-2
+    with pytest.raises(Exception):   # the fold epilogues exist in the 256x256 kernel only
+        ops.gemm_nt(a[:300], wo, bias=bo, residual=res[:300], out_f32=x1[:300], out_bf16=x1b[:300], row_sums=sums[:, :300].contiguous())
