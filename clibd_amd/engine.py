@@ -171,7 +171,10 @@ class TransformerStack:
         self.numerics = default_numerics()   # backward arithmetic switches (see NUMERICS_CHOICES above); set_numerics() changes them
 
     def set_numerics(self, **settings):
+        before = self.numerics.get("ln_fold")
         self.numerics.update(check_numerics(settings))
+        if self.numerics.get("ln_fold") != before:
+            self._cache_key = None   # the fold's weight images are built with the frozen-weight images, only while the switch is on
 
     # ---- fp8-forward mode (BASELINE.json configs[4]) ----------------------------------------------------------------
     # activation sites, named by the GEMM that consumes them
@@ -271,7 +274,7 @@ class TransformerStack:
                     c.w18, c.cs_1 = ops.quantize_rows_fp8(_f32c(L.fc1_w), f8["fc1_in"])
                     c.w28, c.cs_2 = ops.quantize_rows_fp8(_f32c(L.fc2_w), f8["fc2_in"])
                 c.w1g = c.s1 = c.b1f = None
-                if self.pre_ln and not self.full_mode():   # operand image of the norm2 -> fc1 fold (numerics ln_fold), once per weight version
+                if self.pre_ln and self.numerics["ln_fold"] == "on" and not self.full_mode():   # operand image of the norm2 -> fc1 fold, once per weight version
                     c.w1g, c.s1, c.b1f = ops.ln_fold_weights(_f32c(L.fc1_w), c.g2, c.be2, c.b1)
                 c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = c.slot2 = None
                 self._cache.append(c)
@@ -368,7 +371,7 @@ class TransformerStack:
         t = t0
         sp_ok = save and key_mask is None and f8s is None and S <= 224 and self.numerics["attn_bwd"] == "sp"
         # norm2 -> fc1 as the algebraic fold (numerics ln_fold): pre-LN, frozen base, bf16 forward, shapes the 256x256 kernel takes
-        fold = (self.pre_ln and self.numerics["ln_fold"] == "on" and f8s is None and not full and GG == BF16 and H % 256 == 0 and FF % 256 == 0
+        fold = (self.pre_ln and self.numerics["ln_fold"] == "on" and self._cache[0].w1g is not None and f8s is None and not full and GG == BF16 and H % 256 == 0 and FF % 256 == 0
                 and M >= 1024 and ((M + 255) // 256) * (H // 256) >= 128 and H % 128 == 0)
         fold_sums = torch.empty((H // 128, M, 2), dtype=F32, device=dev) if fold else None
         if fold and h_tmp is None and not save:
