@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 MAX_SCLK_MHZ = 2400.0         # the shader clock that figure is quoted at
 GF_PER_PAIR_TRAIN = 117.6     # LoRA training step, I+D pair (fwd 58.78 GF + dgrad-only bwd) — the reference model's FLOPs
-REFERENCE_NUMERICS = dict(residual_grad="fp32", gelu_grad="bf16", attn_bwd="2phase", ln_fold="off")   # the reference's backward semantics (engine.NUMERICS_CHOICES)
+REFERENCE_NUMERICS = dict(residual_grad="fp32", gelu_grad="bf16", attn_bwd="2phase", ln_fold="off", dgrad="bf16")   # the reference's backward semantics (engine.NUMERICS_CHOICES)
 GF_PER_PAIR_FULLFT = 176.3    # full fine-tune (dgrad + wgrad), the authors' final configuration (`disable_lora: true`)
 
 
@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--fp8-forward", nargs="?", const="pooled", default=None, choices=["pooled", "pooled_mlp", "all"],
                     help="BASELINE configs[4] (not the headline config): forward GEMMs on the fp8 MFMA.  'pooled' (default) = the towers whose head "
                          "averages its tokens (BarcodeBERT, BERT-small): gradient-faithful; 'all' adds the ViT: embedding-grade")
+    ap.add_argument("--dgrad", choices=["bf16", "fp8"], default=None,
+                    help="numerics switch dgrad (BASELINE configs[4]): fp8 = the MLP / projection activation-gradient GEMMs of every tower on e4m3 operands with per-row scales (not the headline config)")
     ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
     ap.add_argument("--eval", action="store_true", help="eval path (SURVEY §8f-2, not the headline metric): no-grad embedding forward + K10 top-k search")
     ap.add_argument("--eval-queries", type=int, default=1024, help="--eval: queries per top-k launch")
@@ -112,8 +114,26 @@ class GemmTimer:
             timer.bytes += 1.0 * a.shape[1] * (a.shape[0] + w.shape[0]) + float(per_out) * a.shape[0] * w.shape[0]
             timer.shapes.append((a.shape[0], w.shape[0], a.shape[1], "fp8+" + "+".join(sorted(k for k, v in kw.items() if v is not None))))
 
+        inner8d = ops.gemm_fp8_dgrad_nt
+
+        def timed8d(a, w, cs, **kw):   # the 8-bit dgrad forms (numerics dgrad = fp8): priced at the fp8 peak like the fp8 forward
+            if not timer.enabled:
+                return inner8d(a, w, cs, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inner8d(a, w, cs, **kw)
+            e1.record()
+            timer.events.append((e0, e1))
+            fl = 2.0 * a.shape[0] * w.shape[0] * a.shape[1]
+            timer.flops += fl
+            timer.flops_fp8 += fl
+            per_out = sum(b_ for k_, b_ in (("out_bf16", 2), ("out_fp8", 1), ("aux", 2)) if kw.get(k_) is not None)
+            timer.bytes += 1.0 * a.shape[1] * (a.shape[0] + w.shape[0]) + float(per_out) * a.shape[0] * w.shape[0] + (4.0 * a.shape[0] if kw.get("a_row_dequant") is not None else 0.0)
+            timer.shapes.append((a.shape[0], w.shape[0], a.shape[1], "fp8dgrad+" + "+".join(sorted(k for k, v in kw.items() if v is not None and k not in ("act", "out_fp8_scale")))))
+
         ops.gemm_nt = timed
         ops.gemm_fp8_nt = timed8
+        ops.gemm_fp8_dgrad_nt = timed8d
         import clibd_amd.engine as eng
         import clibd_amd.towers as tw
 
@@ -517,6 +537,8 @@ def main():
             p_.requires_grad_(True)
     trainer = Trainer(model, lr=scale_learning_rate(1e-3, b, world_size=world), world_size=world, rank=rank, all_gather=True)
     batch = synthetic_batch(b, dev, seed=42, rank=rank, with_text=args.tri_modal)
+    if args.dgrad:
+        model.set_numerics(dgrad=args.dgrad)
     if args.fp8_forward:   # per-layer activation scales from one bf16 forward over the batch (outside the timed region)
         model.enable_fp8_forward(calibration_inputs=(batch["image"], batch["dna"], batch["text"]), towers=args.fp8_forward)
 
@@ -597,7 +619,7 @@ def main():
     # residual stream kept in bf16 between block halves (config.numerics.residual_grad, DESIGN §4's budget); the reference's autograd keeps
     # that stream in fp32, also under autocast.  Both figures belong in the line.
     ref_num = None
-    if not args.no_ref_numerics and not args.fp8_forward:
+    if not args.no_ref_numerics and not args.fp8_forward and args.dgrad != "fp8":
         cur = {k: v for k, v in next(iter(model.numerics().values())).items() if k in REFERENCE_NUMERICS}
         if cur != REFERENCE_NUMERICS:
             model.set_numerics(**REFERENCE_NUMERICS)
@@ -739,9 +761,9 @@ def main():
             "metric": (f"paired samples/sec/step (I+D contrastive), global batch {b * world}" if not args.tri_modal
                        else f"triples/sec/step (I+D+T contrastive), global batch {b * world}"),
             "value": pairs_per_s, "unit": "paired samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16" if not args.fp8_forward else "fp8 (e4m3) forward GEMMs + bf16",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": ("bf16" if not args.fp8_forward else "fp8 (e4m3) forward GEMMs + bf16") + (" + fp8 (e4m3) MLP / projection dgrad" if args.dgrad == "fp8" else ""),
             "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights)",
-            "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune and not args.fp8_forward else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
+            "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune and not args.fp8_forward and args.dgrad != "fp8" else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
                                    ("FULL fine-tune (disable_lora)" if args.full_finetune else "LoRA r=4") +
                                    (", bf16 MFMA" if not args.fp8_forward else f", fp8-forward mode (BASELINE configs[4], towers={args.fp8_forward}): forward GEMMs of " + ({"pooled": "the mean-pooled towers (BarcodeBERT)", "pooled_mlp": "the mean-pooled towers (BarcodeBERT) and the MLP pair of every ViT block"}.get(args.fp8_forward, "every tower")) + " on the fp8 MFMA, backward bf16") +
                                    (" + BERT-small text tower" if args.tri_modal else ""),

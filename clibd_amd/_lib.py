@@ -54,6 +54,8 @@ SIGNATURES = {
     "clibd_gemm_bf16_nt_khole": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
     "clibd_gemm_fp8_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, C.POINTER(GemmEpilogue), c_void_p]),
     "clibd_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "clibd_gemm_fp8_dgrad_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, C.POINTER(GemmEpilogue), c_void_p]),
+    "clibd_quantize_rows_fp8_bf16": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_transpose_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "clibd_transpose_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "clibd_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -66,6 +68,8 @@ SIGNATURES = {
     "clibd_attention_fwd_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_float, c_void_p]),
     "clibd_layernorm_bwd_res16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p]),
     "clibd_layernorm_bwd_any": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "clibd_layernorm_bwd_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clibd_layernorm_bwd_pg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clibd_attention_fwd_drop": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),
@@ -116,7 +120,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3   # what this binding was written against (clibd_abi_version(), csrc/capi.hip); load() refuses any other library
+ABI_VERSION = 4   # what this binding was written against (clibd_abi_version(), csrc/capi.hip); load() refuses any other library
 
 
 class ClibdHipError(RuntimeError):

@@ -426,7 +426,57 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const float* __r
     }
     if (lane == 0) col_scale[row] = 1.f / (s * act_scale);
 }
+// The image of a bf16 matrix (the transposed weight shadows the dgrad GEMMs already read) under a power-of-two row scale, plus the largest row l1 norm of the
+// DE-QUANTISED image: l1max = max_n sum_k |e4m3 value| / s_n (atomic max on the bits of a non-negative float; caller zeroes it).
+// It bounds the 8-bit dgrad's output, |sum_k a_k w_nk| <= max|a| * l1max, from which the fc2 dgrad's fixed output scale is derived.
+__global__ __launch_bounds__(256) void quantize_rows_fp8_bf16_kernel(const unsigned short* __restrict__ w, int N, int K, float act_scale,
+                                                                    unsigned char* __restrict__ w8, float* __restrict__ col_scale,
+                                                                    float* __restrict__ l1max) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const unsigned short* wr = w + (size_t)row * K;
+    float amax = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const uint2 pk = *(const uint2*)(wr + k);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(bf2f((unsigned short)(pk.x & 0xffff))), fabsf(bf2f((unsigned short)(pk.x >> 16))))),
+                     fmaxf(fabsf(bf2f((unsigned short)(pk.y & 0xffff))), fabsf(bf2f((unsigned short)(pk.y >> 16)))));
+    }
+    amax = wave_max(amax);
+    // a power-of-two scale, s = 2^(7 - floor(log2 amax)) (the row-scale rule of clibd_layernorm_bwd_fp8: scaled maximum in [128, 256)):
+    // exact in every arithmetic, so the image does not depend on how a division rounds — bf16 inputs sit ON e4m3 rounding ties
+    // under the 448 / amax scale of the fp32 quantiser (w / amax is a ratio of 8-bit integers)
+    float s = 1.f;
+    {
+        unsigned eb = (__float_as_uint(amax) >> 23) & 0xffu;
+        if (amax > 0.f && eb != 255u) s = __uint_as_float((261u - (eb < 8u ? 8u : eb)) << 23);
+    }
+    float l1 = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const uint2 pk = *(const uint2*)(wr + k);
+        const unsigned q = pack4fp8(bf2f((unsigned short)(pk.x & 0xffff)) * s, bf2f((unsigned short)(pk.x >> 16)) * s,
+                                    bf2f((unsigned short)(pk.y & 0xffff)) * s, bf2f((unsigned short)(pk.y >> 16)) * s);
+        *(unsigned*)(w8 + (size_t)row * K + k) = q;
+        l1 += (fabsf(__builtin_amdgcn_cvt_f32_fp8((int)q, 0)) + fabsf(__builtin_amdgcn_cvt_f32_fp8((int)q, 1))) +
+              (fabsf(__builtin_amdgcn_cvt_f32_fp8((int)q, 2)) + fabsf(__builtin_amdgcn_cvt_f32_fp8((int)q, 3)));
+    }
+    l1 = wave_sum(l1) / s;
+    if (lane == 0) {
+        col_scale[row] = 1.f / (s * act_scale);
+        if (l1max != nullptr) atomicMax((unsigned*)l1max, __float_as_uint(l1));
+    }
+}
 }  // namespace clibd
+
+extern "C" int clibd_quantize_rows_fp8_bf16(const void* w_bf16, int N, int K, float act_scale, void* w_fp8, float* col_scale, float* l1max,
+                                            void* stream) {
+    if (!w_bf16 || !w_fp8 || !col_scale) return set_error(CLIBD_EINVAL, "quantize_rows_fp8_bf16: null pointer");
+    if (N <= 0 || K <= 0 || (K & 3) || !(act_scale > 0.f) || ((uintptr_t)w_bf16 & 7) || ((uintptr_t)w_fp8 & 3) || ((uintptr_t)l1max & 3))
+        return set_error(CLIBD_EINVAL, "quantize_rows_fp8_bf16: bad args (K % 4, act_scale > 0, alignment)");
+    hipLaunchKernelGGL(clibd::quantize_rows_fp8_bf16_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)w_bf16, N, K, act_scale, (unsigned char*)w_fp8, col_scale, l1max);
+    return check_launch("quantize_rows_fp8_bf16");
+}
 
 extern "C" int clibd_quantize_rows_fp8(const float* w, int N, int K, float act_scale, void* w_fp8, float* col_scale, void* stream) {
     if (!w || !w_fp8 || !col_scale) return set_error(CLIBD_EINVAL, "quantize_rows_fp8: null pointer");

@@ -56,8 +56,14 @@ __device__ __forceinline__ i32x8 cat_frag(bf16x8 lo, bf16x8 hi) {
     return __builtin_shufflevector(__builtin_bit_cast(i32x4, lo), __builtin_bit_cast(i32x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8>
-__global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
+// DG (8-bit dgrad, round 5; FP8 only): the A operand is a GRADIENT as e4m3 bytes with one power-of-two scale per ROW (written by
+// clibd_layernorm_bwd_fp8), W the transposed frozen weight as e4m3 with one scale per row (= per input channel of the layer).
+//   EPI_BF16 / EPI_ADD_AUX: v = acc * col_scale[n] * a_row_dequant[m]  [+ aux]  -> out_bf16
+//   EPI_MUL_AUX           : out := e4m3(acc * col_scale[n] * aux[m,n] * out_fp8_scale) bytes — the row scale of A passes THROUGH to the
+//                           output (the next dgrad's A operand, dequantised by the same a_row_dequant; 1 / out_fp8_scale rides in its col_scale).
+template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8, bool DG>
+__device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, int skew_ticks, long long* stamps) {
+    static_assert(!DG || (FP8 && !LORA && !BIAS && !DIAG), "the 8-bit dgrad forms are fp8, bias-free and adapter-free");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -461,6 +467,18 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[hm][t][q >> 1][q & 1] *= c;
                 }
+            if constexpr (DG && KIND != EPI_MUL_AUX) {   // the A operand's row scales (M % 4 == 0, host-checked: a group of 4 rows is all in or all out)
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f32x4 rd = *(const f32x4*)(p.a_row_dequant + min(mb + 32 * hn + 16 * n, p.M - 4));
+#pragma unroll
+                        for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc[hm][t][hn][n] *= rd;
+                    }
+            }
         }
         // ---- LoRA rank-8 update: one extra zero-padded k-step (lanes with k-chunk 0 carry U[m,0:8] / V[n,0:8])
         // (compile-time flag: a run-time test here puts all 128 accumulators behind a phi the register allocator
@@ -578,6 +596,8 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
                             _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r];
                         if (KIND == EPI_ROWNORM_GELU) {
                             store_row8<EPI_GELU_SAVE>(ep, m, nb, v);
+                        } else if (DG && KIND == EPI_MUL_AUX) {
+                            *(uint2*)((unsigned char*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8fp8(v, p.out_fp8_scale);
                         } else if (epi_aux_kind(KIND)) {
                             *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
                         } else {
@@ -624,6 +644,15 @@ __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParam
         allow_case = (m0 + T_M <= p.M) ? stores_case : 0;
         tile = next;
     }
+}
+
+template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8>
+__global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
+    gemm256_body<KIND, LORA, BIAS, DIAG, FP8, false>(p, ntiles, skew_ticks, stamps);
+}
+template <int KIND>
+__global__ __launch_bounds__(G256_THREADS) void gemm256_fp8_dgrad_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
+    gemm256_body<KIND, false, false, false, true, true>(p, ntiles, skew_ticks, stamps);
 }
 
 // The product library has no mutable state.  The s_memtime stamp buffer and the start-up skew knob of
@@ -712,6 +741,41 @@ bool gemm256_fp8_launch(const GemmParams& p, hipStream_t stream) {
                 const void* f = kernel_ptr_fp8(k, l != 0);
                 if (f != nullptr) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
             }
+        return ok;
+    }();
+    if (!attr_ok) return false;
+    GemmParams q = p;
+    q.tiles_m = (p.M + T_M - 1) / T_M;
+    q.tiles_n = p.N / T_N;
+    q.splits = 1;
+    q.nk_split = nk;
+    q.split_stride = 0;
+    q.band = 4;
+    const long long tiles = (long long)q.tiles_m * q.tiles_n;
+    const int grid = (int)(tiles < device_cus() ? tiles : device_cus());
+    int ntiles_i = (int)tiles, skew = 0;
+    long long* stamp = nullptr;
+    void* args[] = {(void*)&q, (void*)&ntiles_i, (void*)&skew, (void*)&stamp};
+    return hipLaunchKernel(fn, dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) == hipSuccess;
+}
+
+// 8-bit dgrad launch (clibd_gemm_fp8_dgrad_nt): the three bias-free backward forms
+bool gemm256_fp8_dgrad_launch(const GemmParams& p, hipStream_t stream) {
+    const int nk = p.K / 128;
+    if (!p.fp8 || p.col_scale == nullptr || p.K % 128 != 0 || nk < 4 || (nk & 1) || p.N % T_N != 0 || p.M < 4 || (p.M & 3) || p.ep.split_k > 1) return false;
+    if (p.ep.bias != nullptr || p.ep.rank_u != nullptr || p.ep.drop_thr16 > 0) return false;
+    if ((unsigned long long)p.M * p.lda >= (1ull << 32) || (unsigned long long)p.N * p.ldw >= (1ull << 32)) return false;
+    const int kind = epilogue_kind(p.ep);
+    const void* fn = kind == EPI_BF16 ? (const void*)gemm256_fp8_dgrad_kernel<EPI_BF16>
+                   : kind == EPI_MUL_AUX ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX>
+                   : kind == EPI_ADD_AUX ? (const void*)gemm256_fp8_dgrad_kernel<EPI_ADD_AUX> : nullptr;
+    if (fn == nullptr) return false;
+    if ((p.out_fp8_scale > 0.f) != (kind == EPI_MUL_AUX)) return false;
+    if (kind != EPI_MUL_AUX && p.a_row_dequant == nullptr) return false;
+    static const bool attr_ok = [] {
+        bool ok = hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_ADD_AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         return ok;
     }();
     if (!attr_ok) return false;

@@ -25,6 +25,8 @@ struct GemmParams {
     int fp8;
     const float* col_scale;
     float out_fp8_scale;
+    // 8-bit dgrad forms (clibd_gemm_fp8_dgrad_nt): fp32 [M], the reciprocal of the per-row scale the producer of A applied
+    const float* a_row_dequant;
 };
 
 // Inside a wave's 64 output columns, MFMA n-tile t (0..3), MFMA row i (0..15) carries tile-local column
@@ -430,6 +432,7 @@ inline int plan_k_slices(int nk, int tiles, int num_cus, int* nks_out) {
 bool gemm256_try_launch(const GemmParams& p, hipStream_t stream);
 // fp8 operands (p.fp8, p.col_scale set; K / lda / ldw in bytes): true when launched
 bool gemm256_fp8_launch(const GemmParams& p, hipStream_t stream);
+bool gemm256_fp8_dgrad_launch(const GemmParams& p, hipStream_t stream);
 // split-K with a partials workspace; returns the number of splits (0: shape not taken)
 int gemm256_splitk_launch(const GemmParams& p, float* partials, size_t partials_elems, hipStream_t stream);
 

@@ -164,18 +164,23 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // PG (full fine-tune mode): also dgamma[c] += sum_rows dy * xhat, dbeta[c] += sum_rows dy — the kernel has dy and xhat in
 // registers anyway; every wave keeps its columns' partial sums over the rows it walks, the block combines its four waves in
 // LDS and issues ONE float atomic per column and parameter (the grid is capped so that these stay a few microseconds).
-template <int NCH, bool PG, int ROWS>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy_bf16,
-                                                            const float* __restrict__ dy_f32,
-                                                            const float* __restrict__ x,
-                                                            const float* __restrict__ stats,
-                                                            const float* __restrict__ gamma, int M, int H,
-                                                            const float* __restrict__ dres,
-                                                            float* __restrict__ dx_f32,
-                                                            unsigned short* __restrict__ dx_bf16, unsigned drop_seed,
-                                                            int drop_thr16, float drop_scale, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, const unsigned short* __restrict__ dres_b16,
-                                                            unsigned short* __restrict__ dx_res_b16) {
+// F8 (8-bit dgrad, round 5): the copy the dense branch's dgrad consumes (dropout mask applied, as dx_bf16) also leaves as e4m3 bytes with
+// ONE power-of-two scale per row, s = 2^(7 - floor(log2 max|row|)) (the scaled row maximum lies in [128, 256), e4m3's top binade but one;
+// an all-zero row takes s = 1), dx_fp8[row, c] = e4m3(value * s), row_dequant[row] = 1 / s — the A operand of clibd_gemm_fp8_dgrad_nt.
+// A wave owns whole rows, so the row maximum is a DPP reduction of values it already holds: no second pass, no history of maxima.
+template <int NCH, bool PG, int ROWS, bool F8>
+__device__ __forceinline__ void layernorm_bwd_body(const unsigned short* __restrict__ dy_bf16,
+                                                   const float* __restrict__ dy_f32,
+                                                   const float* __restrict__ x,
+                                                   const float* __restrict__ stats,
+                                                   const float* __restrict__ gamma, int M, int H,
+                                                   const float* __restrict__ dres,
+                                                   float* __restrict__ dx_f32,
+                                                   unsigned short* __restrict__ dx_bf16, unsigned drop_seed,
+                                                   int drop_thr16, float drop_scale, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, const unsigned short* __restrict__ dres_b16,
+                                                   unsigned short* __restrict__ dx_res_b16, unsigned char* __restrict__ dx_fp8,
+                                                   float* __restrict__ row_dequant) {
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
@@ -249,8 +254,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
         for (int rr = 0; rr < ROWS; ++rr) {
             if (!live[rr]) continue;
             const size_t row = (size_t)(row0 + rr);
+            f32x4 od[F8 ? NCH : 1];
+            float amax = 0.f;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
+                if (F8) od[j] = (f32x4){0, 0, 0, 0};
                 if (!act[j]) continue;
                 const int c = 4 * (lane + 64 * j);
                 f32x4 o;
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                     pk.y = pack2bf(o[2], o[3]);
                     *(uint2*)(dx_res_b16 + row * H + c) = pk;
                 }
-                if (dx_bf16 != nullptr) {
+                if (dx_bf16 != nullptr || F8) {
                     if (drop_thr16 > 0) {  // this copy is d(dense out) = d(sum) * mask / (1-p) of the forward's hidden dropout
                         const unsigned base = (unsigned)row * (unsigned)H + (unsigned)c;
                         float f0, f1, f2, f3;
@@ -271,11 +279,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                         drop_pair(drop_seed, base + 2, (unsigned)drop_thr16, drop_scale, f2, f3);
                         o[0] *= f0; o[1] *= f1; o[2] *= f2; o[3] *= f3;
                     }
-                    uint2 pk;
-                    pk.x = pack2bf(o[0], o[1]);
-                    pk.y = pack2bf(o[2], o[3]);
-                    *(uint2*)(dx_bf16 + row * H + c) = pk;
+                    if (dx_bf16 != nullptr) {
+                        uint2 pk;
+                        pk.x = pack2bf(o[0], o[1]);
+                        pk.y = pack2bf(o[2], o[3]);
+                        *(uint2*)(dx_bf16 + row * H + c) = pk;
+                    }
+                    if (F8) {
+                        od[j] = o;
+                        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                    }
                 }
+            }
+            if (F8) {
+                amax = wave_max(amax);
+                // biased exponent of the row maximum -> s = 2^(134 - eb), 1 / s = 2^(eb - 134); rows below 2^-119 (eb < 8) are scaled as if
+                // their maximum were 2^-119 (they quantise to zeros), a non-finite maximum (eb = 255) takes s = 1
+                unsigned eb = (__float_as_uint(amax) >> 23) & 0xffu;
+                float sc = 1.f, sinv = 1.f;
+                if (amax > 0.f && eb != 255u) {
+                    eb = eb < 8u ? 8u : eb;
+                    sc = __uint_as_float((261u - eb) << 23);
+                    sinv = __uint_as_float((eb - 7u) << 23);
+                }
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    if (!act[j]) continue;
+                    const int c = 4 * (lane + 64 * j);
+                    *(unsigned*)(dx_fp8 + row * H + c) = pack4fp8(od[j][0] * sc, od[j][1] * sc, od[j][2] * sc, od[j][3] * sc);
+                }
+                if (lane == 0) row_dequant[row] = sinv;
             }
         }
     }
@@ -295,6 +328,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             atomicAdd(dbeta + c, (pg_lds[1][0][c] + pg_lds[1][1][c]) + (pg_lds[1][2][c] + pg_lds[1][3][c]));
         }
     }
+}
+
+template <int NCH, bool PG, int ROWS>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+                                                            const float* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, int M, int H, const float* __restrict__ dres,
+                                                            float* __restrict__ dx_f32, unsigned short* __restrict__ dx_bf16, unsigned drop_seed,
+                                                            int drop_thr16, float drop_scale, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, const unsigned short* __restrict__ dres_b16,
+                                                            unsigned short* __restrict__ dx_res_b16) {
+    layernorm_bwd_body<NCH, PG, ROWS, false>(dy_bf16, dy_f32, x, stats, gamma, M, H, dres, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma,
+                                             dbeta, dres_b16, dx_res_b16, nullptr, nullptr);
+}
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) void layernorm_bwd_fp8_kernel(const unsigned short* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+                                                                const float* __restrict__ x, const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma, int M, int H, const float* __restrict__ dres,
+                                                                float* __restrict__ dx_f32, unsigned short* __restrict__ dx_bf16, unsigned drop_seed,
+                                                                int drop_thr16, float drop_scale, const unsigned short* __restrict__ dres_b16,
+                                                                unsigned short* __restrict__ dx_res_b16, unsigned char* __restrict__ dx_fp8,
+                                                                float* __restrict__ row_dequant) {
+    layernorm_bwd_body<NCH, false, ROWS, true>(dy_bf16, dy_f32, x, stats, gamma, M, H, dres, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, nullptr,
+                                               nullptr, dres_b16, dx_res_b16, dx_fp8, row_dequant);
 }
 
 static inline int ln_grid(int M) {
@@ -370,12 +426,14 @@ extern "C" int clibd_layernorm_fwd_fp8(const float* x, int M, int H, const float
 static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats,
                               const float* gamma, int M, int H, const float* dres_f32, float* dx_f32,
                               void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, float* dgamma, float* dbeta, void* stream,
-                              const void* dres_b16 = nullptr, void* dx_res_b16 = nullptr) {
+                              const void* dres_b16 = nullptr, void* dx_res_b16 = nullptr, void* dx_fp8 = nullptr, float* row_dequant = nullptr) {
     if (drop_thr16 < 0 || drop_thr16 > 65535) return set_error(CLIBD_EINVAL, "layernorm_bwd: bad dropout threshold");
     if (!x || !stats || !gamma) return set_error(CLIBD_EINVAL, "layernorm_bwd: null pointer");
     if ((dy_bf16 == nullptr) == (dy_f32 == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: exactly one of dy_bf16/dy_f32");
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_bwd: H must be a multiple of 64, <= 1024");
-    if (!dx_f32 && !dx_bf16 && !dx_res_b16) return set_error(CLIBD_EINVAL, "layernorm_bwd: no output");
+    if (!dx_f32 && !dx_bf16 && !dx_res_b16 && !dx_fp8) return set_error(CLIBD_EINVAL, "layernorm_bwd: no output");
+    if ((dx_fp8 == nullptr) != (row_dequant == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: dx_fp8 / row_dequant must come together");
+    if (dx_fp8 && (dgamma || ((uintptr_t)dx_fp8 & 3) || (H & 3))) return set_error(CLIBD_EINVAL, "layernorm_bwd: the fp8 output takes no parameter gradients; 4-byte alignment");
     if (dres_f32 && dres_b16) return set_error(CLIBD_EINVAL, "layernorm_bwd: the residual gradient is either fp32 or bf16");
     if (((uintptr_t)dres_b16 & 7) || ((uintptr_t)dx_res_b16 & 7)) return set_error(CLIBD_EINVAL, "layernorm_bwd: alignment");
     if ((dgamma == nullptr) != (dbeta == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: dgamma/dbeta must come together");
@@ -390,7 +448,11 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const fl
     const bool two_rows = !pg && dy_f32 == nullptr && dres_f32 == nullptr && dx_f32 == nullptr && M >= 131072;
 #define LAUNCH_R(N, R)                                                                                         \
     do {                                                                                                       \
-        if (pg)                                                                                                \
+        if (dx_fp8)                                                                                            \
+            hipLaunchKernelGGL((layernorm_bwd_fp8_kernel<N, R>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
+                               stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale, \
+                               (const unsigned short*)dres_b16, (unsigned short*)dx_res_b16, (unsigned char*)dx_fp8, row_dequant); \
+        else if (pg)                                                                                            \
             hipLaunchKernelGGL((layernorm_bwd_kernel<N, true, 1>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
                                stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma, dbeta, \
                                (const unsigned short*)dres_b16, (unsigned short*)dx_res_b16);                  \
@@ -442,6 +504,15 @@ extern "C" int clibd_layernorm_bwd_res16(const void* dy_bf16, const float* dy_f3
                                          void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* stream) {
     return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, nullptr, nullptr, dx_bf16, drop_seed, drop_thr16, drop_scale, nullptr,
                               nullptr, stream, dres_bf16, dx_res_bf16);
+}
+
+extern "C" int clibd_layernorm_bwd_fp8(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
+                                       int M, int H, const float* dres_f32, const void* dres_bf16, float* dx_f32, void* dx_res_bf16,
+                                       void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* dx_fp8, float* row_dequant,
+                                       void* stream) {
+    if (!dx_fp8 || !row_dequant) return set_error(CLIBD_EINVAL, "layernorm_bwd_fp8: null dx_fp8 / row_dequant");
+    return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, nullptr,
+                              nullptr, stream, dres_bf16, dx_res_bf16, dx_fp8, row_dequant);
 }
 
 extern "C" int clibd_layernorm_bwd_any(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,

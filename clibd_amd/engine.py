@@ -61,8 +61,18 @@ class NotSupportedYet(NotImplementedError):
 #   weight image and applies the row terms in its epilogue: the LayerNorm's own HBM pass (6 bytes per element) disappears.  The bf16 rounding
 #   moves from LN(x) to x; measured error of the fc1 pre-activation against fp64: the same (tools/ln_fold_study.py: ratio 1.00 at random
 #   init, 1.2 with 100-sigma outlier channels).  The backward is the unchanged LayerNorm backward (same statistics).  DESIGN.md §3.1c.
-NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"))
-_NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD", ln_fold="CLIBD_LN_FOLD")
+# * dgrad (round 5, BASELINE.json configs[4]): "bf16" — the activation-gradient GEMMs on bf16 operands; "fp8" — the MLP pair and the attention
+#   projection of every layer take their gradient operand as e4m3 with ONE power-of-two scale per token row (written by the LayerNorm backward
+#   that produces it, from the row maximum it already holds; d(fc1 out) inherits the row scale times a per-layer constant derived from an l1 bound
+#   on the fc2 weight, so nothing saturates and no history of maxima is kept) against the transposed frozen weight as e4m3 with one scale per
+#   input channel, on v_mfma_f32_16x16x128_f8f6f4.  The QKV dgrad (its operand feeds the adapters' bf16 weight gradients), attention and every
+#   weight gradient stay bf16.  Oracle study (full-size towers, tools/fp8_policy_study.py, profiles/r05_exp_fp8_dgrad_study.log): gradient cosine
+#   against the bf16 dgrad 0.9998 on the training batch / 0.9875 on a fresh one with BOTH towers on it.  Frozen-base (LoRA) mode with the bf16
+#   residual-gradient stream and bf16 gelu' only; a call whose token count is not a multiple of 4 takes the bf16 GEMMs.  DESIGN.md §3.1d.
+NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"),
+                        dgrad=("bf16", "fp8"))
+_NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD", ln_fold="CLIBD_LN_FOLD",
+                     dgrad="CLIBD_DGRAD")
 
 
 def default_numerics() -> dict:
@@ -126,7 +136,8 @@ class _LayerCache:
     fp8-forward mode adds the e4m3 forward images and their per-channel dequantisation factors (w*8, cs_*)."""
     __slots__ = ("wqkv", "wqkv_t", "bqkv", "wo", "wo_t", "bo", "w1", "w1_t", "b1", "w2", "w2_t", "b2", "g1", "be1", "g2", "be2",
                  "v_fwd", "v_bwd", "a_cat", "w_dt", "slot2", "wqkv8", "cs_qkv", "wo8", "cs_o", "w18", "cs_1", "w28", "cs_2",
-                 "w1g", "s1", "b1f")   # ln_fold: bf16(gamma2 o W1), its row sums, b1 + W1 beta2
+                 "w1g", "s1", "b1f",   # ln_fold: bf16(gamma2 o W1), its row sums, b1 + W1 beta2
+                 "wo_t8", "cs_ot", "w1_t8", "cs_1t", "w2_t8", "cs_2t", "c2")   # dgrad = fp8: e4m3 images of the transposed weights, c2 = d(fc1 out)'s fixed scale
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -171,10 +182,20 @@ class TransformerStack:
         self.numerics = default_numerics()   # backward arithmetic switches (see NUMERICS_CHOICES above); set_numerics() changes them
 
     def set_numerics(self, **settings):
-        before = self.numerics.get("ln_fold")
+        before = (self.numerics.get("ln_fold"), self.numerics.get("dgrad"))
         self.numerics.update(check_numerics(settings))
-        if self.numerics.get("ln_fold") != before:
-            self._cache_key = None   # the fold's weight images are built with the frozen-weight images, only while the switch is on
+        if (self.numerics.get("ln_fold"), self.numerics.get("dgrad")) != before:
+            self._cache_key = None   # the fold's / the 8-bit dgrad's weight images are built with the frozen-weight images, only while the switch is on
+
+    def _dgrad8_ok(self) -> bool:
+        """dgrad = "fp8" is on and this stack can take it (see NUMERICS_CHOICES); raises for a configuration that cannot."""
+        if self.numerics["dgrad"] != "fp8":
+            return False
+        if self.full_mode() or self.numerics["residual_grad"] != "bf16" or self.numerics["gelu_grad"] != "bf16":
+            raise NotSupportedYet("dgrad=fp8 needs frozen base weights (LoRA mode), residual_grad=bf16 and gelu_grad=bf16")
+        if self.H % 256 or self.H < 512 or self.FF % 256:
+            raise NotSupportedYet("dgrad=fp8 needs hidden % 256 == 0, hidden >= 512, intermediate % 256 == 0")
+        return True
 
     # ---- fp8-forward mode (BASELINE.json configs[4]) ----------------------------------------------------------------
     # activation sites, named by the GEMM that consumes them
@@ -277,7 +298,18 @@ class TransformerStack:
                 if self.pre_ln and self.numerics["ln_fold"] == "on" and not self.full_mode():   # operand image of the norm2 -> fc1 fold, once per weight version
                     c.w1g, c.s1, c.b1f = ops.ln_fold_weights(_f32c(L.fc1_w), c.g2, c.be2, c.b1)
                 c.v_fwd = c.v_bwd = c.a_cat = c.w_dt = c.slot2 = None
+                c.wo_t8 = c.cs_ot = c.w1_t8 = c.cs_1t = c.w2_t8 = c.cs_2t = c.c2 = None
                 self._cache.append(c)
+            if self._dgrad8_ok():   # e4m3 images of the transposed weights, once per weight version
+                dev = self._cache[0].w2_t.device
+                l1 = torch.zeros((len(self._cache),), dtype=F32, device=dev)
+                for i, c in enumerate(self._cache):
+                    c.w2_t8, c.cs_2t = ops.quantize_rows_fp8_bf16(c.w2_t, 1.0, l1[i:i + 1])
+                    c.wo_t8, c.cs_ot = ops.quantize_rows_fp8_bf16(c.wo_t, 1.0)
+                for c, v in zip(self._cache, l1.cpu().tolist()):   # (one synchronisation per weight version)
+                    # d(fc1 out) = e4m3(acc * col_scale * gelu' * c2): |acc * col_scale| <= 256 * l1max (scaled row maxima < 256), |gelu'| <= 1.13
+                    c.c2 = 2.0 ** math.floor(math.log2(448.0 / (256.0 * 1.13 * max(v, 1e-30))))
+                    c.w1_t8, c.cs_1t = ops.quantize_rows_fp8_bf16(c.w1_t, c.c2)   # its col_scale carries 1 / c2
         self._cache_key = key
 
     def pack_lora(self):
@@ -557,7 +589,7 @@ class TransformerStack:
         H, FF, M = self.H, self.FF, B * S
         dev = dx_f32.device
         new = lambda cols, dt: torch.empty((M, cols), dtype=dt, device=dev)
-        dh = new(FF, BF16)
+        dh = None   # d(fc1 out), bf16 [M,FF]: allocated by the first layer that takes the bf16 dgrad
         dtmp = new(H, BF16)
         dqkv = new(3 * H, BF16)
         dt = torch.empty((M, 16), dtype=BF16, device=dev)
@@ -568,6 +600,12 @@ class TransformerStack:
         # gradients ride along in the same kernel (clibd_layernorm_bwd_any), and the BOTTOM layer hands an fp32 gradient to the
         # embedding backward as before (`need32`).  409.6 ms per step at b = 2048 with the fp32 stream (profiles/r04_fullft_*_v1*).
         r16 = self.numerics["residual_grad"] == "bf16"
+        # 8-bit dgrad (numerics dgrad = "fp8"): every LayerNorm backward below also writes its output as e4m3 rows + one dequantisation
+        # factor per row (new8), which the next dgrad GEMM takes as its A operand; dx8 = that pair for the incoming stream gradient
+        dg8 = (not full) and self._dgrad8_ok() and self._cache[0].w2_t8 is not None and M % 4 == 0
+        new8 = lambda cols: (torch.empty((M, cols), dtype=torch.uint8, device=dev).view(ops.FP8), torch.empty((M,), dtype=F32, device=dev))
+        f8kw = lambda pair: dict(dx_fp8=pair[0], row_dequant=pair[1])
+        dx8 = None
         # full fine-tune: the LayerNorm backward accumulates d(gamma), d(beta) in the same pass (it holds dy and xhat anyway)
         pg = lambda w, b: (dict(dgamma=grads[id(w)].view(-1), dbeta=grads[id(b)].view(-1)) if full and id(w) in grads else {})
         wg = lambda dy, x, ws, bs: linear_wgrad(dy, x, ws, bs, grads) if full else None
@@ -600,7 +638,9 @@ class TransformerStack:
                         dres16, _ = ops.scatter_rows(dx1_f32, S, bf16=True, f32=False)           # residual path: class rows only
                         ndx_bf16 = new(H, BF16)
                         ndx_f32 = new(H, F32) if (full and i == 0) else None
-                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16, dx_f32=ndx_f32, **pg(L.ln1_w, L.ln1_b))
+                        dx8 = new8(H) if dg8 else None
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16, dx_f32=ndx_f32, **pg(L.ln1_w, L.ln1_b),
+                                          **(f8kw(dx8) if dg8 else {}))
                         dx_f32, dx_bf16 = ndx_f32, ndx_bf16
                     else:
                         _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)        # residual path: class rows only
@@ -609,17 +649,28 @@ class TransformerStack:
                         dx_f32, dx_bf16 = ndx_f32, ndx_bf16
             elif self.pre_ln:
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
-                ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)          # d(fc1 out)
-                wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
-                ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                                   # d(LN2 out)
+                if dg8 and dx8 is not None:   # d(fc1 out) leaves as e4m3 with the rows' scales x c2; the fc1 dgrad divides both back out
+                    dh8 = torch.empty((M, FF), dtype=torch.uint8, device=dev).view(ops.FP8)
+                    ops.gemm_fp8_dgrad_nt(dx8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=ops.ACT_MUL_AUX, out_fp8=dh8, out_fp8_scale=c.c2)
+                    ops.gemm_fp8_dgrad_nt(dh8, c.w1_t8, c.cs_1t, a_row_dequant=dx8[1], out_bf16=dtmp)
+                else:
+                    dh = new(FF, BF16) if dh is None else dh
+                    ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)      # d(fc1 out)
+                    wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
+                    ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                               # d(LN2 out)
+                dx18 = new8(H) if dg8 else None
                 if r16:
                     dx1_f32, dx1_bf16 = None, new(H, BF16)
-                    ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres_bf16=dx_bf16, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
+                    ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres_bf16=dx_bf16, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b),
+                                      **(f8kw(dx18) if dg8 else {}))
                 else:
                     dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
                     ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
                 wg(dx1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
-                ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtmp)                                             # d(attn out)
+                if dg8:
+                    ops.gemm_fp8_dgrad_nt(dx18[0], c.wo_t8, c.cs_ot, a_row_dequant=dx18[1], out_bf16=dtmp)   # d(attn out)
+                else:
+                    ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtmp)                                         # d(attn out)
                 self._attention_bwd(rec, dtmp, B, S, key_mask, dqkv)
                 if has_lora:
                     dt2 = self._lora_grads(L, c, dqkv, rec["xn"], rec["t"], dt, grads, rec.get("t2"))
@@ -629,7 +680,9 @@ class TransformerStack:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, residual=add32, out_bf16=dtmp)
                     if r16:
                         ndx_f32, ndx_bf16 = (new(H, F32) if (full and i == 0) else None), new(H, BF16)
-                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16, dx_f32=ndx_f32, **pg(L.ln1_w, L.ln1_b))
+                        dx8 = new8(H) if dg8 else None
+                        ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16, dx_f32=ndx_f32, **pg(L.ln1_w, L.ln1_b),
+                                          **(f8kw(dx8) if dg8 else {}))
                     else:
                         ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
                         ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
@@ -640,22 +693,35 @@ class TransformerStack:
                 # copy the dense branch's dgrad consumes; the two dgrads that re-join the stream add the residual copy in their epilogue.
                 def ln_back(dy, xs, st, gam, drop_site, pgk):
                     res = new(H, BF16)
+                    if dg8:   # the dense branch's dgrad takes the e4m3 rows: the masked bf16 copy is not written at all
+                        q8 = new8(H)
+                        ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, drop=drop_site, **f8kw(q8))
+                        return res, None, q8
                     if drop_site is not None and drop_site.thr16 > 0:
                         masked = new(H, BF16)
                         ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, dx_bf16=masked, drop=drop_site, **pgk)
-                        return res, masked
+                        return res, masked, None
                     ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, **pgk)
-                    return res, res
+                    return res, res, None
 
-                ds2_res, ds2_b = ln_back(dx_f32, rec["s2"], rec["st2"], c.g2, rec["d_h2"], pg(L.ln2_w, L.ln2_b))
-                wg(ds2_b, rec.get("a"), [L.fc2_w], [L.fc2_b])
-                ops.gemm_nt(ds2_b, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)
-                wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
+                ds2_res, ds2_b, ds2_8 = ln_back(dx_f32, rec["s2"], rec["st2"], c.g2, rec["d_h2"], pg(L.ln2_w, L.ln2_b))
                 dx1 = new(H, BF16)
-                ops.gemm_nt(dh, c.w1_t, act=ops.ACT_ADD_AUX, aux=ds2_res, out_bf16=dx1)
-                ds1_res, ds1_b = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"], pg(L.ln1_w, L.ln1_b))
-                wg(ds1_b, rec.get("o"), [L.proj_w], [L.proj_b])
-                ops.gemm_nt(ds1_b, c.wo_t, out_bf16=dtmp)
+                if dg8:
+                    dh8 = torch.empty((M, FF), dtype=torch.uint8, device=dev).view(ops.FP8)
+                    ops.gemm_fp8_dgrad_nt(ds2_8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=ops.ACT_MUL_AUX, out_fp8=dh8, out_fp8_scale=c.c2)
+                    ops.gemm_fp8_dgrad_nt(dh8, c.w1_t8, c.cs_1t, a_row_dequant=ds2_8[1], aux=ds2_res, act=ops.ACT_ADD_AUX, out_bf16=dx1)
+                else:
+                    dh = new(FF, BF16) if dh is None else dh
+                    wg(ds2_b, rec.get("a"), [L.fc2_w], [L.fc2_b])
+                    ops.gemm_nt(ds2_b, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)
+                    wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
+                    ops.gemm_nt(dh, c.w1_t, act=ops.ACT_ADD_AUX, aux=ds2_res, out_bf16=dx1)
+                ds1_res, ds1_b, ds1_8 = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"], pg(L.ln1_w, L.ln1_b))
+                if dg8:
+                    ops.gemm_fp8_dgrad_nt(ds1_8[0], c.wo_t8, c.cs_ot, a_row_dequant=ds1_8[1], out_bf16=dtmp)
+                else:
+                    wg(ds1_b, rec.get("o"), [L.proj_w], [L.proj_b])
+                    ops.gemm_nt(ds1_b, c.wo_t, out_bf16=dtmp)
                 self._attention_bwd(rec, dtmp, B, S, key_mask, dqkv, drop=rec["d_att"])
                 if has_lora:
                     dt2 = self._lora_grads(L, c, dqkv, rec["x_bf16"], rec["t"], dt, grads, rec.get("t2"))
@@ -675,6 +741,7 @@ class TransformerStack:
                 ds2_f32, ds2_bf16 = new(H, F32), new(H, BF16)
                 ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"], **pg(L.ln2_w, L.ln2_b))
                 wg(ds2_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
+                dh = new(FF, BF16) if dh is None else dh
                 ops.gemm_nt(ds2_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)
                 wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                 dx1 = new(H, F32)

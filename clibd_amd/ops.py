@@ -187,6 +187,69 @@ def quantize_rows_fp8(w: torch.Tensor, act_scale: float):
     return w8, cs
 
 
+def quantize_rows_fp8_bf16(w: torch.Tensor, act_scale: float = 1.0, l1max: Optional[torch.Tensor] = None):
+    """(w_fp8 [N,K] float8_e4m3fn, col_scale [N] fp32) from a bf16 matrix (a transposed weight shadow): the W operand of gemm_fp8_dgrad_nt.
+    l1max (fp32 scalar tensor, zeroed by the caller): raised to the largest row l1 norm of the de-quantised image."""
+    _chk(w, BF16, "w")
+    N, K = w.shape
+    w8 = torch.empty((N, K), dtype=torch.uint8, device=w.device).view(FP8)
+    cs = torch.empty((N,), dtype=F32, device=w.device)
+    if l1max is not None:
+        _chk(l1max, F32, "l1max")
+    check(_lib.load().clibd_quantize_rows_fp8_bf16(w.data_ptr(), N, K, float(act_scale), w8.data_ptr(), cs.data_ptr(), _p(l1max), _stream()),
+          "quantize_rows_fp8_bf16")
+    return w8, cs
+
+
+def gemm_fp8_dgrad_nt(a: torch.Tensor, w: torch.Tensor, col_scale: torch.Tensor, *, a_row_dequant: Optional[torch.Tensor] = None,
+                      aux: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_bf16: Optional[torch.Tensor] = None,
+                      out_fp8: Optional[torch.Tensor] = None, out_fp8_scale: float = 0.0) -> None:
+    """8-bit dgrad (clibd_gemm_fp8_dgrad_nt): a [M,K] e4m3 gradient rows with per-row scales (a_row_dequant [M] = 1 / scale), w [N,K] the
+    transposed weight from quantize_rows_fp8_bf16.  Forms: act NONE -> out_bf16 | ACT_ADD_AUX + aux -> out_bf16 (both need a_row_dequant) |
+    ACT_MUL_AUX + aux -> out_fp8 = e4m3(value * out_fp8_scale), which keeps a's row scales."""
+    _chk(a, FP8, "a", contiguous=False)
+    _chk(w, FP8, "w", contiguous=False)
+    _chk(col_scale, F32, "col_scale")
+    lda, ldw = _rowmajor(a, "a"), _rowmajor(w, "w")
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2 or col_scale.numel() != N:
+        raise ValueError("gemm_fp8_dgrad_nt: shape mismatch")
+    if act not in (ACT_NONE, ACT_ADD_AUX, ACT_MUL_AUX):
+        raise ValueError("gemm_fp8_dgrad_nt: act must be NONE, ADD_AUX or MUL_AUX")
+    if (act == ACT_NONE) != (aux is None):
+        raise ValueError("gemm_fp8_dgrad_nt: aux comes with ADD_AUX / MUL_AUX only")
+    ep = GemmEpilogue()
+    ep.split_k = 1
+    ep.act = act
+    if aux is not None:
+        _chk(aux, BF16, "aux", contiguous=False)
+        if tuple(aux.shape) != (M, N):
+            raise ValueError("gemm_fp8_dgrad_nt: aux must be [M,N]")
+        ep.aux_bf16, ep.ld_aux = aux.data_ptr(), _rowmajor(aux, "aux")
+    if act == ACT_MUL_AUX:
+        if out_fp8 is None or out_bf16 is not None or not out_fp8_scale > 0:
+            raise ValueError("gemm_fp8_dgrad_nt: the MUL_AUX form writes out_fp8 with a positive out_fp8_scale")
+        _chk(out_fp8, FP8, "out_fp8", contiguous=False)
+        if tuple(out_fp8.shape) != (M, N):
+            raise ValueError("gemm_fp8_dgrad_nt: out_fp8 must be [M,N]")
+        ep.out_bf16, ep.ld_out_bf16 = out_fp8.data_ptr(), _rowmajor(out_fp8, "out_fp8")
+    else:
+        if out_bf16 is None or out_fp8 is not None or a_row_dequant is None:
+            raise ValueError("gemm_fp8_dgrad_nt: the bf16-output forms need out_bf16 and a_row_dequant")
+        _chk(out_bf16, BF16, "out_bf16", contiguous=False)
+        if tuple(out_bf16.shape) != (M, N):
+            raise ValueError("gemm_fp8_dgrad_nt: out_bf16 must be [M,N]")
+        ep.out_bf16, ep.ld_out_bf16 = out_bf16.data_ptr(), _rowmajor(out_bf16, "out_bf16")
+        out_fp8_scale = 0.0
+    if a_row_dequant is not None:
+        _chk(a_row_dequant, F32, "a_row_dequant")
+        if a_row_dequant.numel() != M:
+            raise ValueError("gemm_fp8_dgrad_nt: a_row_dequant must have M elements")
+    check(_lib.load().clibd_gemm_fp8_dgrad_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, col_scale.data_ptr(), _p(a_row_dequant),
+                                              float(out_fp8_scale), C.byref(ep), _stream()), "gemm_fp8_dgrad_nt")
+
+
 def gemm_fp8_nt(
     a: torch.Tensor,
     w: torch.Tensor,
@@ -313,12 +376,37 @@ def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, stats=None, l
 
 
 def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, drop=None, dgamma=None, dbeta=None,
-                  dres_bf16=None, dx_res_bf16=None) -> None:
+                  dres_bf16=None, dx_res_bf16=None, dx_fp8=None, row_dequant=None) -> None:
     """dgamma / dbeta (fp32 [H], accumulate): the LayerNorm parameter gradients in the same pass (full fine-tune mode).
     dres_bf16 / dx_res_bf16: the residual gradient travels as bf16 (clibd_layernorm_bwd_res16): dx = LN'(dy) + dres_bf16,
-    dx_res_bf16 = bf16(dx) without the dropout mask that dx_bf16 carries; no fp32 input / output stream then."""
+    dx_res_bf16 = bf16(dx) without the dropout mask that dx_bf16 carries; no fp32 input / output stream then.
+    dx_fp8 [M,H] e4m3 + row_dequant [M] fp32 (8-bit dgrad, clibd_layernorm_bwd_fp8): the dx_bf16 values once more as the A operand of
+    gemm_fp8_dgrad_nt, one power-of-two scale per row; dx_bf16 itself becomes optional."""
     _chk(x, F32, "x")
     M, H = x.shape
+    if dx_fp8 is not None or row_dequant is not None:
+        if dx_fp8 is None or row_dequant is None or dgamma is not None or dbeta is not None:
+            raise ValueError("layernorm_bwd: dx_fp8 and row_dequant come together, without parameter gradients")
+        _chk(dx_fp8, FP8, "dx_fp8")
+        _chk(row_dequant, F32, "row_dequant")
+        if tuple(dx_fp8.shape) != (M, H) or row_dequant.numel() != M:
+            raise ValueError("layernorm_bwd: dx_fp8 must be [M,H], row_dequant [M]")
+        for nm, t, dt in (("dres", dres, F32), ("dres_bf16", dres_bf16, BF16), ("dx_f32", dx_f32, F32), ("dx_res_bf16", dx_res_bf16, BF16), ("dx_bf16", dx_bf16, BF16)):
+            if t is not None:
+                _chk(t, dt, nm)
+                if tuple(t.shape) != (M, H):
+                    raise ValueError(f"layernorm_bwd: {nm} shape")
+        if dy.dtype not in (BF16, F32) or tuple(dy.shape) != (M, H):
+            raise ValueError("layernorm_bwd: dy must be bf16 or fp32 [M,H]")
+        _chk(dy, dy.dtype, "dy")
+        _chk(stats, F32, "stats")
+        _chk(gamma, F32, "gamma")
+        d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
+        dyb, dyf = (dy.data_ptr(), None) if dy.dtype == BF16 else (None, dy.data_ptr())
+        check(_lib.load().clibd_layernorm_bwd_fp8(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres), _p(dres_bf16), _p(dx_f32),
+                                                  _p(dx_res_bf16), _p(dx_bf16), d.seed, d.thr16, d.scale, dx_fp8.data_ptr(), row_dequant.data_ptr(),
+                                                  _stream()), "layernorm_bwd_fp8")
+        return
     if dres_bf16 is not None or dx_res_bf16 is not None:
         if dres is not None:
             raise ValueError("layernorm_bwd: the residual gradient is either fp32 (dres) or bf16 (dres_bf16)")

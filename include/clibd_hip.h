@@ -118,6 +118,27 @@ int clibd_gemm_fp8_nt(const void* A, int lda, const void* W, int ldw, int M, int
  * producer of the activation operand applied before its e4m3 conversion.  w fp32 [N,K] dense, K % 4 == 0. */
 int clibd_quantize_rows_fp8(const float* w, int N, int K, float act_scale, void* w_fp8, float* col_scale, void* stream);
 
+/* 8-bit dgrad (ABI 4; BASELINE.json configs[4], numerics switch dgrad = "fp8"): the activation-gradient products dX = dY . W of a frozen
+ * nn.Linear (the backward of the same call sites as clibd_gemm_bf16_nt: timm Mlp.fc1 / fc2, Attention.proj, image_encoder.py:106-107; HF
+ * BertIntermediate / BertOutput / BertSelfOutput .dense, dna_encoder.py:137) on e4m3 operands.
+ *   A [M,K]  = the gradient dY as e4m3 bytes with ONE power-of-two scale per row: A[m,k] = e4m3(dY[m,k] * s_m), a_row_dequant[m] = 1 / s_m
+ *              (fp32 [M]; written by clibd_layernorm_bwd_fp8, or inherited from the form below);
+ *   W [N,K]  = the TRANSPOSED weight (row n = input channel n of the layer) as clibd_quantize_rows_fp8_bf16 writes it, col_scale[n] its
+ *              row's dequantisation factor (times 1 / out_fp8_scale of the producer when A came from the third form).
+ * Forms (bias-free, no adapters; M % 4 == 0, N % 256 == 0, K % 256 == 0, K >= 512; lda, ldw, K in bytes):
+ *   act NONE                : out_bf16 = bf16(acc * col_scale[n] * a_row_dequant[m])
+ *   act ADD_AUX + aux_bf16  : out_bf16 = bf16(acc * col_scale[n] * a_row_dequant[m] + aux[m,n])
+ *   act MUL_AUX + aux_bf16  : out_bf16 := e4m3(acc * col_scale[n] * aux[m,n] * out_fp8_scale) BYTES (ld_out_bf16 in bytes; a_row_dequant
+ *                             unused): the dgrad through GELU writes the next dgrad's A operand, which keeps A's row scales; out_fp8_scale
+ *                             (> 0 exactly for this form) is a power of two <= 448 / (256 * 1.13 * l1max) with l1max from
+ *                             clibd_quantize_rows_fp8_bf16, so that no value saturates (|gelu'| <= 1.13, scaled row maxima < 256). */
+int clibd_gemm_fp8_dgrad_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* col_scale,
+                            const float* a_row_dequant, float out_fp8_scale, const clibd_gemm_epilogue* ep, void* stream);
+/* Operand image of a bf16 matrix (the transposed weight shadow of the bf16 dgrad) with a POWER-OF-TWO scale per row:
+ * s_n = 2^(7 - floor(log2 max_k |w[n,k]|)) (1 for an all-zero row), w_fp8[n,k] = e4m3(w[n,k] * s_n), col_scale[n] = 1 / (s_n * act_scale);
+ * *l1max = max(*l1max, max_n sum_k |dequantised w8[n,k]|) (fp32 scalar, caller zeroes; may be NULL). */
+int clibd_quantize_rows_fp8_bf16(const void* w_bf16, int N, int K, float act_scale, void* w_fp8, float* col_scale, float* l1max, void* stream);
+
 /* bf16 transpose with zero padding: out[C, ld_out] (ld_out >= R) = in[R, C]^T; columns R..ld_out-1 zero.
  * Used to feed the weight-gradient GEMMs (contraction over the token dimension). */
 int clibd_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, void* stream);
@@ -176,6 +197,14 @@ int clibd_layernorm_bwd_res16(const void* dy_bf16, const float* dy_f32, const fl
 int clibd_layernorm_bwd_any(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
                             int M, int H, const float* dres_f32, const void* dres_bf16, float* dx_f32, void* dx_res_bf16,
                             void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, float* dgamma, float* dbeta,
+                            void* stream);
+/* 8-bit dgrad (ABI 4): clibd_layernorm_bwd_any without parameter gradients, and additionally the copy the dense branch's dgrad consumes
+ * (dropout mask applied, as dx_bf16 — which may now be NULL) as e4m3 bytes with one power-of-two scale per row:
+ *   s_m = 2^(7 - floor(log2 max_c |v[m,c]|))  (1 for an all-zero row),  dx_fp8[m,c] = e4m3(v[m,c] * s_m),  row_dequant[m] = 1 / s_m.
+ * dx_fp8 uint8 [M,H], row_dequant fp32 [M]: the A operand of clibd_gemm_fp8_dgrad_nt. */
+int clibd_layernorm_bwd_fp8(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
+                            int M, int H, const float* dres_f32, const void* dres_bf16, float* dx_f32, void* dx_res_bf16,
+                            void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* dx_fp8, float* row_dequant,
                             void* stream);
 /* full fine-tune mode: the same backward that also accumulates the parameter gradients it has the operands for
  *   dgamma[c] += sum_m dy[m,c] * xhat[m,c],  dbeta[c] += sum_m dy[m,c]     (fp32 [H], caller zeroes once per step). */

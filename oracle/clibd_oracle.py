@@ -76,6 +76,30 @@ def ln_fold(on: bool = True):
         _LN_FOLD = old
 
 
+_DGRAD8 = False
+
+
+@contextlib.contextmanager
+def dgrad8(on: bool = True):
+    """bf16 / fp8 modes: the activation-gradient products of attention projection, fc1 and fc2 of every layer evaluated as the kernels'
+    8-bit dgrad (clibd_amd.engine numerics dgrad="fp8", include/clibd_hip.h clibd_gemm_fp8_dgrad_nt / clibd_layernorm_bwd_fp8):
+      gradient rows  : e4m3(g[m,:] * s_m), s_m = 2^(7 - floor(log2 max|g[m,:]|)) taken from the fp32 gradient (1 for a zero row);
+      d(fc1 out)     : e4m3(value * s_m * c2) with the s_m of the fc2 dgrad's operand rows and the per-layer constant
+                       c2 = 2^floor(log2(448 / (256 * 1.13 * l1max))), l1max the largest row l1 norm of the quantised fc2^T image;
+      weights        : bf16(W)^T with one power-of-two scale per row (input channel), e4m3; fp32 accumulation.
+    Frozen base weights only (the mode has no 8-bit weight gradient)."""
+    global _DGRAD8
+    old, _DGRAD8 = _DGRAD8, bool(on)
+    try:
+        yield
+    finally:
+        _DGRAD8 = old
+
+
+def _dg8() -> bool:
+    return _DGRAD8 and _PRECISION != "fp32"
+
+
 def _r(x: torch.Tensor) -> torch.Tensor:
     """bf16 rounding with a straight-through gradient (autocast casts are differentiable identities)."""
     if _PRECISION == "fp32":
@@ -206,15 +230,65 @@ def _fp8_scale(module, site):
     return d.get(site)
 
 
-def olinear(x, weight, bias=None, round_out=True, fp8_scale=None):
+def pow2_row_scale(v: torch.Tensor) -> torch.Tensor:
+    """s = 2^(7 - floor(log2 max|row|)) per row of the last axis (1 for an all-zero row): the scaled row maximum lies in [128, 256)"""
+    amax = v.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax))))
+    return torch.where(amax > 0, torch.exp2(7.0 - e), torch.ones_like(amax))
+
+
+def quantize_rows_e4m3_pow2(w: torch.Tensor):
+    """(e4m3(w_n * s_n), s_n) with the power-of-two row scale — clibd_quantize_rows_fp8_bf16"""
+    s = pow2_row_scale(w)
+    return e4m3(w * s), s
+
+
+_DG8_ROWS = {}   # id(fc2 weight) -> s_m * c2 of the layer's current backward (set by the fc2 dgrad, read by the fc1 dgrad that follows it)
+
+
+class _Dgrad8Linear(torch.autograd.Function):
+    """value: y (computed by the caller on the mode's forward operands); input gradient: the 8-bit dgrad, see dgrad8()."""
+
+    @staticmethod
+    def forward(ctx, x, weight, y, site, pair_id):
+        if weight.requires_grad:
+            raise RuntimeError("dgrad8: the 8-bit dgrad needs frozen base weights")
+        ctx.save_for_backward(weight)
+        ctx.site, ctx.pair_id = site, pair_id
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        w8, sn = quantize_rows_e4m3_pow2(rb(weight.detach().float()).t().contiguous())   # [in, out]: rows = the dgrad's output channels
+        g = dy.float()
+        if ctx.site == "fc1":      # d(fc1 out): the scale it was WRITTEN with by the fc2 dgrad's epilogue
+            sm = _DG8_ROWS.pop(ctx.pair_id)
+        else:
+            sm = pow2_row_scale(g)
+            if ctx.site == "fc2":
+                l1max = float((w8.abs().sum(dim=1, keepdim=True) / sn).max())
+                _DG8_ROWS[ctx.pair_id] = sm * (2.0 ** math.floor(math.log2(448.0 / (256.0 * 1.13 * max(l1max, 1e-30)))))
+        dx = (e4m3(g * sm) @ (w8 / sn).t()) / sm
+        return dx, None, None, None, None
+
+
+def olinear(x, weight, bias=None, round_out=True, fp8_scale=None, dgrad=None):
     """nn.Linear with the kernels' rounding points: bf16 operands, fp32 accumulate, fp32 bias, bf16 output.
     round_out=False: the GEMM epilogue keeps fp32 (residual add / fp32 head output fused before any rounding);
     the gradient entering the GEMM is still bf16 (the dgrad GEMM's A operand).
-    fp8_scale (fp8 mode, one of the four layer GEMMs): e4m3 operands, x quantised from its fp32 value with that scale."""
+    fp8_scale (fp8 mode, one of the four layer GEMMs): e4m3 operands, x quantised from its fp32 value with that scale.
+    dgrad = (site, fc2 weight) for the three GEMMs the 8-bit dgrad covers ("proj", "fc1", "fc2"): under dgrad8() the input gradient is
+    that mode's, taken from the fp32 output gradient (the kernels quantise what the LayerNorm backward / the GELU epilogue holds in fp32)."""
     y = _Fp8Linear.apply(x, weight, float(fp8_scale)) if fp8_scale is not None else F.linear(_r(x), _r(weight), None)
+    dg = dgrad is not None and _dg8()
+    if dg:
+        y = _Dgrad8Linear.apply(x, weight, y.detach(), dgrad[0], id(dgrad[1]))
     if bias is not None:
         y = y + bias
-    return _rg(_r(y) if round_out else y)
+    y = _r(y) if round_out else y
+    return y if dg else _rg(y)
 
 
 def gelu_erf(x):
@@ -284,7 +358,7 @@ class Attention(nn.Module):
         q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
         sp = _fp8_scale(self, "proj_in")
         o = attention_core(q, k, v, round_out=sp is None).transpose(1, 2).reshape(B, N, C)
-        return olinear(o, self.proj.weight, self.proj.bias, round_out=False, fp8_scale=sp)
+        return olinear(o, self.proj.weight, self.proj.bias, round_out=False, fp8_scale=sp, dgrad=("proj", None))
 
 
 class Mlp(nn.Module):
@@ -294,7 +368,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x, fold_from=None):
-        h = olinear(x, self.fc1.weight, self.fc1.bias, fp8_scale=_fp8_scale(self, "fc1_in"))
+        h = olinear(x, self.fc1.weight, self.fc1.bias, fp8_scale=_fp8_scale(self, "fc1_in"), dgrad=("fc1", self.fc2.weight))
         if fold_from is not None:   # (x1, norm2): the value of the kernels' fold, the gradient of the line above
             x1, ln = fold_from
             rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
@@ -310,7 +384,8 @@ class Mlp(nn.Module):
             h = h + (hf - h).detach()
         s2 = _fp8_scale(self, "fc2_in")   # fp8: the fc1 epilogue converts gelu(bf16(h)) (fp32) straight to e4m3
         a = gelu_erf(h)
-        return olinear(_rg(_r(a) if s2 is None else a), self.fc2.weight, self.fc2.bias, round_out=False, fp8_scale=s2)
+        a = _r(a) if s2 is None else a
+        return olinear(a if _dg8() else _rg(a), self.fc2.weight, self.fc2.bias, round_out=False, fp8_scale=s2, dgrad=("fc2", self.fc2.weight))
 
 
 class Block(nn.Module):
@@ -322,6 +397,12 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x):
+        if getattr(self, "_no_fold", False) and _DGRAD8:   # the last block (class row only in the kernels) keeps the bf16 dgrad
+            with dgrad8(False):
+                return self._forward(x)
+        return self._forward(x)
+
+    def _forward(self, x):
         x = x + self.attn(self.norm1(x))
         if _LN_FOLD and _PRECISION == "bf16" and not getattr(self, "_no_fold", False):
             return x + self.mlp(self.norm2(x), fold_from=(x, self.norm2))
@@ -472,7 +553,8 @@ class _DenseLN(nn.Module):
         self.LayerNorm = nn.LayerNorm(dout, eps=eps)
 
     def forward(self, x, residual, layer=None, site=None, fp8_site=None):
-        y = olinear(x, self.dense.weight, self.dense.bias, round_out=False, fp8_scale=_fp8_scale(self, fp8_site) if fp8_site else None)
+        y = olinear(x, self.dense.weight, self.dense.bias, round_out=False, fp8_scale=_fp8_scale(self, fp8_site) if fp8_site else None,
+                    dgrad=({"proj_in": "proj", "fc2_in": "fc2"}[fp8_site], self.dense.weight) if fp8_site else None)
         if layer is not None:
             y = _hidden_drop(y, layer, site)
         return self.LayerNorm(y + residual)
@@ -500,9 +582,11 @@ class BertLayer(nn.Module):
 
     def forward(self, x, mask_add=None, layer=None):
         a = self.attention.output(self.attention.self(x, mask_add, layer), x, layer, 1, "proj_in")
-        h = olinear(a, self.intermediate.dense.weight, self.intermediate.dense.bias, fp8_scale=_fp8_scale(self, "fc1_in"))
+        h = olinear(a, self.intermediate.dense.weight, self.intermediate.dense.bias, fp8_scale=_fp8_scale(self, "fc1_in"),
+                    dgrad=("fc1", self.output.dense.weight))
         g = gelu_erf(h)
-        return self.output(_rg(_r(g) if _fp8_scale(self, "fc2_in") is None else g), a, layer, 2, "fc2_in")
+        g = _r(g) if _fp8_scale(self, "fc2_in") is None else g
+        return self.output(g if _dg8() else _rg(g), a, layer, 2, "fc2_in")
 
 
 class _Encoder(nn.Module):

@@ -38,13 +38,13 @@ def test_bench_prints_exactly_one_json_line(forced):
     # round 4: what arithmetic produced the line, and what the host paid to enqueue it
     assert d["config"]["train_mode"] is True                      # the reference steps in model.train() (train_epoch.py:19)
     num = d["config"]["numerics"]
-    assert set(num) == {"image_encoder", "dna_encoder"} and all(v["forward"] == "bf16" and v["residual_grad"] in ("bf16", "fp32") and v["ln_fold"] in ("off", "on") for v in num.values())
+    assert set(num) == {"image_encoder", "dna_encoder"} and all(v["forward"] == "bf16" and v["residual_grad"] in ("bf16", "fp32") and v["ln_fold"] in ("off", "on") and v["dgrad"] == "bf16" for v in num.values())
     he = d["host_enqueue_ms"]
     assert all(k in he for k in ("mean", "median", "p95", "cpu_mean", "cpu_median")) and 0 < he["cpu_median"] <= he["p95"] * 1.5 + 1.0
     assert roof["step_frac_gflop_per_pair"] == 117.6
     # round 5: the step at the reference's backward numerics rides in the same line; the host-fed legs are steady state + uint8 images
     rn = d["reference_numerics"]
-    assert rn["value"] > 0 and rn["numerics"] == {"residual_grad": "fp32", "gelu_grad": "bf16", "attn_bwd": "2phase", "ln_fold": "off"}
+    assert rn["value"] > 0 and rn["numerics"] == {"residual_grad": "fp32", "gelu_grad": "bf16", "attn_bwd": "2phase", "ln_fold": "off", "dgrad": "bf16"}
     if forced == "1":
         assert "collectives" in d
     else:

@@ -336,8 +336,9 @@ def test_numerics_switches_are_explicit_settings(monkeypatch, tmp_path):
     monkeypatch.delenv("CLIBD_GELU_GRAD", raising=False)
     monkeypatch.delenv("CLIBD_RESIDUAL_GRAD", raising=False)
     monkeypatch.delenv("CLIBD_LN_FOLD", raising=False)
+    monkeypatch.delenv("CLIBD_DGRAD", raising=False)
     a = build()
-    assert a.numerics()["image_encoder"] == dict(residual_grad="bf16", gelu_grad="bf16", attn_bwd="2phase", ln_fold="off", forward="bf16")
+    assert a.numerics()["image_encoder"] == dict(residual_grad="bf16", gelu_grad="bf16", attn_bwd="2phase", ln_fold="off", dgrad="bf16", forward="bf16")
     monkeypatch.setenv("CLIBD_GELU_GRAD", "u8")
     b = build()                                    # the variable is read at construction ...
     assert b.numerics()["dna_encoder"]["gelu_grad"] == "u8" and a.numerics()["dna_encoder"]["gelu_grad"] == "bf16"   # ... not by `a`

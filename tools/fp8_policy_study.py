@@ -37,7 +37,21 @@ STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 
 POLICY = dict(gran="tensor", cls_bf16=False, in_image=False, bf16_from_block=None, block_index=None, image_bf16=False, image_sites=None,
-              fp8_until_block=None)
+              fp8_until_block=None, dgrad=None, dgrad_margin=1.0)
+
+
+def fp8_grad(x, fmt, margin=1.0):
+    """A gradient tensor as an 8-bit dgrad GEMM would take it: one power-of-two scale for the tensor, 2^floor(log2(fmax / (2 amax)))
+    of the tensor itself (`margin` > 1 stands for a DELAYED scale that is off by that factor: the tensor is `margin` x larger than the
+    scale was made for), payload e5m2 (fmax 57344) or e4m3 (448).  Returns the de-quantised values."""
+    fmax, dt = (57344.0, torch.float8_e5m2) if fmt == "e5m2" else (448.0, torch.float8_e4m3fn)
+    if POLICY.get("dgrad_rows"):   # one scale per ROW (token) of the gradient: it factors out of the dgrad's contraction like a tensor scale does
+        amax = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        s = torch.exp2(torch.floor(torch.log2(fmax / (2.0 * amax * margin))))
+        return (x * s).clamp(-fmax, fmax).to(dt).to(x.dtype) / s
+    amax = x.abs().amax().clamp_min(1e-30)
+    s = float(2.0 ** torch.floor(torch.log2(fmax / (2.0 * amax * margin))))
+    return (x * s).clamp(-fmax, fmax).to(dt).to(x.dtype) / s
 
 
 def vit_site(weight):
@@ -77,10 +91,13 @@ class PolicyLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, sa):
         ctx.save_for_backward(weight)
+        ctx.in_image = POLICY["in_image"]
         xf, wf = x.detach().float(), weight.detach().float()
         rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
         blk, frm = POLICY["block_index"], POLICY["bf16_from_block"]
         if POLICY["in_image"] and POLICY["image_bf16"]:
+            return F.linear(rb(xf), rb(wf))
+        if POLICY.get("dna_fwd_bf16"):    # diagnostic: the 8-bit dgrad alone, forward on bf16 operands
             return F.linear(rb(xf), rb(wf))
         if POLICY["in_image"] and frm is not None and blk is not None and blk >= frm:
             return F.linear(rb(xf), rb(wf))
@@ -112,6 +129,16 @@ class PolicyLinear(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        # round 5: 8-bit dgrad on the towers whose forward is fp8 (never the ViT under image_bf16): the gradient as e5m2 / e4m3 with one
+        # scale per tensor, the weight as e4m3 with one scale per INPUT channel (the dgrad's output column, so the scale factors out)
+        if POLICY["dgrad"] is not None and (POLICY.get("dgrad_image") or not (ctx.in_image and POLICY["image_bf16"])):
+            wt = weight.detach().float().t().contiguous()          # [in, out]: rows = the dgrad GEMM's output channels
+            w8, sn = O.quantize_rows_e4m3(wt)
+            fmt, margin = POLICY["dgrad"], POLICY["dgrad_margin"]
+            if fmt == "mixed":   # rows that a LayerNorm backward produced (exact row maximum known): e4m3; d(fc1 out), whose scale is a bound: e5m2
+                is_dh = weight.shape[0] == 4 * weight.shape[1]
+                fmt, margin = ("e5m2", margin) if is_dh else ("e4m3", 1.0)
+            return fp8_grad(dy.float(), fmt, margin) @ (w8 / sn).t(), None, None
         return rb(dy) @ rb(weight.detach()), None, None
 
 
@@ -200,7 +227,21 @@ def main():
                 ("vit_mlp_cal", dict(gran="tensor_cal", cls_bf16=False, bf16_from_block=None, image_sites=("fc1", "fc2"))),
                 ("vit_mlp_first6", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc1", "fc2"), fp8_until_block=6)),
                 ("vit_mlp_first3", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc1", "fc2"), fp8_until_block=3)),
-                ("vit_fc2_first6", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc2",), fp8_until_block=6))]
+                ("vit_fc2_first6", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_sites=("fc2",), fp8_until_block=6)),
+                # round 5: 8-bit dgrad on the DNA tower (the "pooled" selection), forward as dna_only
+                ("dna_only+dgrad_e5m2", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e5m2")),
+                ("dna_only+dgrad_e4m3", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3")),
+                ("dna_only+dgrad_e5m2_x16", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e5m2", dgrad_margin=16.0)),
+                ("dna_only+dgrad_e4m3_x16", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_margin=16.0)),
+                ("dna_only+dgrad_rows_e5m2_x32", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e5m2", dgrad_margin=32.0, dgrad_rows=True)),
+                ("dna_only+dgrad_both_e5m2", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e5m2", dgrad_image=True)),
+                ("dna_only+dgrad_both_rows_e5m2_x32", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e5m2", dgrad_margin=32.0, dgrad_rows=True, dgrad_image=True)),
+                ("dna_only+dgrad_both_e4m3", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_image=True)),
+                ("dna_only+dgrad_both_rows_e4m3", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_rows=True, dgrad_image=True)),
+                ("dna_only+dgrad_both_rows_e4m3_x32", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_margin=32.0, dgrad_rows=True, dgrad_image=True)),
+                ("dna_only+dgrad_both_rows_mixed_x32", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="mixed", dgrad_margin=32.0, dgrad_rows=True, dgrad_image=True)),
+                ("dna_only+dgrad_rows_mixed_x32", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="mixed", dgrad_margin=32.0, dgrad_rows=True)),
+                ("dna_bf16fwd+dgrad_e5m2", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e5m2", dna_fwd_bf16=True))]
     for name, (image, dna, labels) in (("train batch", tr), ("fresh batch", fr)):
         with O.precision("bf16"):
             i16, d16, l16, g16 = evaluate(om, image, dna, labels)
@@ -209,7 +250,7 @@ def main():
         for pname, pol in policies:
             if only is not None and pname not in only:
                 continue
-            POLICY.update(image_bf16=False, image_sites=None, fp8_until_block=None)
+            POLICY.update(image_bf16=False, image_sites=None, fp8_until_block=None, dgrad=None, dgrad_margin=1.0, dna_fwd_bf16=False, dgrad_rows=False, dgrad_image=False)
             POLICY.update(pol)
             with O.precision("fp8"):
                 i8, d8, l8, g8 = evaluate(om, image, dna, labels)
