@@ -254,11 +254,9 @@ __device__ __forceinline__ void layernorm_bwd_body(const unsigned short* __restr
         for (int rr = 0; rr < ROWS; ++rr) {
             if (!live[rr]) continue;
             const size_t row = (size_t)(row0 + rr);
-            f32x4 od[F8 ? NCH : 1];
-            float amax = 0.f;
+            float amax = 0.f;   // F8: the masked values are kept in gy[rr][j] (dead once o is formed) until the row maximum is known
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                if (F8) od[j] = (f32x4){0, 0, 0, 0};
                 if (!act[j]) continue;
                 const int c = 4 * (lane + 64 * j);
                 f32x4 o;
@@ -286,7 +284,7 @@ __device__ __forceinline__ void layernorm_bwd_body(const unsigned short* __restr
                         *(uint2*)(dx_bf16 + row * H + c) = pk;
                     }
                     if (F8) {
-                        od[j] = o;
+                        gy[rr][j] = o;
                         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
                     }
                 }
@@ -306,7 +304,7 @@ __device__ __forceinline__ void layernorm_bwd_body(const unsigned short* __restr
                 for (int j = 0; j < NCH; ++j) {
                     if (!act[j]) continue;
                     const int c = 4 * (lane + 64 * j);
-                    *(unsigned*)(dx_fp8 + row * H + c) = pack4fp8(od[j][0] * sc, od[j][1] * sc, od[j][2] * sc, od[j][3] * sc);
+                    *(unsigned*)(dx_fp8 + row * H + c) = pack4fp8(gy[rr][j][0] * sc, gy[rr][j][1] * sc, gy[rr][j][2] * sc, gy[rr][j][3] * sc);
                 }
                 if (lane == 0) row_dequant[row] = sinv;
             }
@@ -341,8 +339,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     layernorm_bwd_body<NCH, PG, ROWS, false>(dy_bf16, dy_f32, x, stats, gamma, M, H, dres, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma,
                                              dbeta, dres_b16, dx_res_b16, nullptr, nullptr);
 }
+// (four waves per SIMD, as the plain kernel reaches at H = 768: without the bound the two-row form takes 131 registers — three waves)
+#ifndef CLIBD_LNB8_WAVES
+#define CLIBD_LNB8_WAVES 4
+#endif
 template <int NCH, int ROWS>
-__global__ __launch_bounds__(256) void layernorm_bwd_fp8_kernel(const unsigned short* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CLIBD_LNB8_WAVES, 8))) void layernorm_bwd_fp8_kernel(const unsigned short* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
                                                                 const float* __restrict__ x, const float* __restrict__ stats,
                                                                 const float* __restrict__ gamma, int M, int H, const float* __restrict__ dres,
                                                                 float* __restrict__ dx_f32, unsigned short* __restrict__ dx_bf16, unsigned drop_seed,
@@ -445,7 +447,10 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const fl
     // rows per wave and iteration: two pay for the long launches of the bf16 residual-gradient form (M = 403 456: 716-722 -> 652 us;
     // at M = 50 432 one row is the faster form: 97 -> 85-87 us against 91); the fp32 / parameter-gradient forms are indifferent
     // and keep one (profiles/r03_exp_layernorm_rows.log)
-    const bool two_rows = !pg && dy_f32 == nullptr && dres_f32 == nullptr && dx_f32 == nullptr && M >= 131072;
+    // the e4m3-row form: two rows (bounded to four waves per SIMD: 128 registers, 4 spilled) for the pre-LN call (incoming bf16 stream: 569 ->
+    // 635 us at M = 403 456, the 11 / 10 byte ratio; one row: 683), one row for the post-LN call, whose masked copy it replaces (591 -> 599 us;
+    // two rows: 561 -> 591): tools/bench_ln_bwd_fp8.py, profiles/r05_exp_ln_bwd_fp8_rows.log
+    const bool two_rows = !pg && dy_f32 == nullptr && dres_f32 == nullptr && dx_f32 == nullptr && M >= 131072 && (dx_fp8 == nullptr || (nch <= 3 && dres_b16 != nullptr));
 #define LAUNCH_R(N, R)                                                                                         \
     do {                                                                                                       \
         if (dx_fp8)                                                                                            \

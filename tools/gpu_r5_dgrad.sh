@@ -19,3 +19,13 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(f"{sys.argv[2]:36s} {d['ms_per_step']:8.2f} ms  {d['value']:8.1f} pairs/s  loss {d.get('loss')}  frac {d['roofline']['frac']:.3f}  sclk {d['roofline'].get('board', {}).get('sclk_mhz_mean')}")
 PY
 done
+if [ "${4:-}" = "prof" ]; then   # kernel statistics of the pooled forward + 8-bit dgrad step, serial towers
+  export CLIBD_TOWER_STREAMS=0
+  CMD="python3 bench.py --fp8-forward pooled --dgrad fp8 --per-gpu-batch $B --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics"
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_dgrad8" -- $CMD > "$OUT/prof_dgrad8.log" 2>&1
+  echo "prof exit $?"
+  unset CLIBD_TOWER_STREAMS
+  python tools/stamp_stats.py "$OUT/prof_dgrad8" "$OUT/kernel_stats_pooled_dgrad8_serial.csv" "CLIBD_TOWER_STREAMS=0 rocprofv3 --kernel-trace --stats -- $CMD"
+  find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
+  find "$OUT" -name "*.db" -delete
+fi
