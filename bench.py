@@ -62,8 +62,9 @@ def parse():
     ap.add_argument("--fp8-forward", nargs="?", const="pooled", default=None, choices=["pooled", "pooled_mlp", "all"],
                     help="BASELINE configs[4] (not the headline config): forward GEMMs on the fp8 MFMA.  'pooled' (default) = the towers whose head "
                          "averages its tokens (BarcodeBERT, BERT-small): gradient-faithful; 'all' adds the ViT: embedding-grade")
-    ap.add_argument("--dgrad", choices=["bf16", "fp8"], default=None,
-                    help="numerics switch dgrad (BASELINE configs[4]): fp8 = the MLP / projection activation-gradient GEMMs of every tower on e4m3 operands with per-row scales (not the headline config)")
+    ap.add_argument("--dgrad", choices=["bf16", "fp8", "fp8-pooled"], default=None,
+                    help="numerics switch dgrad (BASELINE configs[4]): fp8 = the MLP / projection activation-gradient GEMMs of every tower on e4m3 operands with per-row scales; "
+                         "fp8-pooled = of the mean-pooled towers only (BarcodeBERT, BERT-small).  Not the headline config")
     ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
     ap.add_argument("--eval", action="store_true", help="eval path (SURVEY §8f-2, not the headline metric): no-grad embedding forward + K10 top-k search")
     ap.add_argument("--eval-queries", type=int, default=1024, help="--eval: queries per top-k launch")
@@ -538,7 +539,7 @@ def main():
     trainer = Trainer(model, lr=scale_learning_rate(1e-3, b, world_size=world), world_size=world, rank=rank, all_gather=True)
     batch = synthetic_batch(b, dev, seed=42, rank=rank, with_text=args.tri_modal)
     if args.dgrad:
-        model.set_numerics(dgrad=args.dgrad)
+        model.enable_fp8_dgrad(towers="pooled" if args.dgrad == "fp8-pooled" else "all", enabled=args.dgrad != "bf16")
     if args.fp8_forward:   # per-layer activation scales from one bf16 forward over the batch (outside the timed region)
         model.enable_fp8_forward(calibration_inputs=(batch["image"], batch["dna"], batch["text"]), towers=args.fp8_forward)
 
@@ -619,7 +620,7 @@ def main():
     # residual stream kept in bf16 between block halves (config.numerics.residual_grad, DESIGN §4's budget); the reference's autograd keeps
     # that stream in fp32, also under autocast.  Both figures belong in the line.
     ref_num = None
-    if not args.no_ref_numerics and not args.fp8_forward and args.dgrad != "fp8":
+    if not args.no_ref_numerics and not args.fp8_forward and args.dgrad in (None, "bf16"):
         cur = {k: v for k, v in next(iter(model.numerics().values())).items() if k in REFERENCE_NUMERICS}
         if cur != REFERENCE_NUMERICS:
             model.set_numerics(**REFERENCE_NUMERICS)
@@ -761,9 +762,9 @@ def main():
             "metric": (f"paired samples/sec/step (I+D contrastive), global batch {b * world}" if not args.tri_modal
                        else f"triples/sec/step (I+D+T contrastive), global batch {b * world}"),
             "value": pairs_per_s, "unit": "paired samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": ("bf16" if not args.fp8_forward else "fp8 (e4m3) forward GEMMs + bf16") + (" + fp8 (e4m3) MLP / projection dgrad" if args.dgrad == "fp8" else ""),
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": ("bf16" if not args.fp8_forward else "fp8 (e4m3) forward GEMMs + bf16") + ({"fp8": " + fp8 (e4m3) MLP / projection dgrad", "fp8-pooled": " + fp8 (e4m3) MLP / projection dgrad of the mean-pooled towers"}.get(args.dgrad, "")),
             "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights)",
-            "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune and not args.fp8_forward and args.dgrad != "fp8" else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
+            "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune and not args.fp8_forward and args.dgrad in (None, "bf16") else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
                                    ("FULL fine-tune (disable_lora)" if args.full_finetune else "LoRA r=4") +
                                    (", bf16 MFMA" if not args.fp8_forward else f", fp8-forward mode (BASELINE configs[4], towers={args.fp8_forward}): forward GEMMs of " + ({"pooled": "the mean-pooled towers (BarcodeBERT)", "pooled_mlp": "the mean-pooled towers (BarcodeBERT) and the MLP pair of every ViT block"}.get(args.fp8_forward, "every tower")) + " on the fp8 MFMA, backward bf16") +
                                    (" + BERT-small text tower" if args.tri_modal else ""),

@@ -51,3 +51,21 @@ def test_bench_prints_exactly_one_json_line(forced):
         h = d["h2d_inclusive"]
         assert h["value"] > 0 and h["copy_at_top_of_step"]["value"] > 0 and h["uint8_images"]["value"] > 0
         assert h["uint8_images"]["host_bytes_per_step_per_gpu"] < h["host_bytes_per_step_per_gpu"] / 3
+
+
+def test_bench_line_of_the_fp8_configuration():
+    """BASELINE configs[4] as bench.py runs it (`--fp8-forward pooled --dgrad fp8`): the line says so in dtype / config, it is a secondary
+    config (never the metric's), the numerics record carries dgrad = fp8 for both towers and the fp8 forward for the pooled tower only, and
+    the roofline prices the fp8 launches (forward and 8-bit dgrad) at the fp8 peak."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--per-gpu-batch", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-h2d", "--fp8-forward", "pooled", "--dgrad", "fp8"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "fp8" in d["dtype"] and "dgrad" in d["dtype"] and "secondary config" in d["config"]["workload"]
+    num = d["config"]["numerics"]
+    assert num["image_encoder"]["dgrad"] == "fp8" and num["dna_encoder"]["dgrad"] == "fp8"
+    assert num["image_encoder"]["forward"] == "bf16" and num["dna_encoder"]["forward"].startswith("fp8")
+    assert d["value"] > 0 and d["loss"] == d["loss"] and "reference_numerics" not in d
+    assert 0 < d["roofline"]["frac"] < 1

@@ -355,3 +355,59 @@ def test_fp8_mode_sites_and_last_block_rule():
         gs = torch.autograd.grad(loss, [p for p in de.parameters() if p.requires_grad])
     assert torch.allclose(z8.sum(1), torch.ones(2), atol=1e-5) and 0 < (z8 - z16).abs().max().item() < 1e-2
     assert all(torch.isfinite(g_).all() for g_ in gs)
+
+
+def test_dgrad8_rule_row_scales_l1_bound_and_sites():
+    """The oracle's restatement of the 8-bit dgrad (numerics dgrad = "fp8"): power-of-two row scales that put every row maximum in
+    [128, 256); an input gradient that is EXACT when gradient and weights are representable; d(fc1 out) quantised with the fc2 dgrad's row
+    scales times the l1-bound constant; forward untouched; only projection / fc1 / fc2 change; the ViT's last block and fp32 mode stay out;
+    trainable base weights are refused."""
+    v = torch.tensor([[3.0, -200.0, 0.5], [0.0, 0.0, 0.0], [2.0 ** -20, 0.0, -2.0 ** -21], [255.9, 1.0, 1.0]])
+    s = O.pow2_row_scale(v)
+    assert torch.equal(s.flatten(), torch.tensor([1.0, 1.0, 2.0 ** 27, 1.0]))
+    assert all(128.0 <= float((v[i] * s[i]).abs().max()) < 256.0 for i in (0, 2, 3))
+    w8, sn = O.quantize_rows_e4m3_pow2(torch.tensor([[0.5, -0.75], [0.0, 0.0]]))
+    assert torch.equal(sn.flatten(), torch.tensor([256.0, 1.0])) and torch.equal(w8, torch.tensor([[128.0, -192.0], [0.0, 0.0]]))
+    # exact on representable operands: integer gradients (3 bits), weights that are e4m3 values under their row scale
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(6, 32, generator=g).requires_grad_(True)
+    w = torch.randint(-3, 4, (8, 32), generator=g).float() * 0.125
+    dy = torch.randint(-7, 8, (6, 8), generator=g).float()
+    with O.precision("bf16"), O.dgrad8(True):
+        y = O.olinear(x, w, None, round_out=False, dgrad=("proj", None))
+        (dx,) = torch.autograd.grad((y * dy).sum(), x)
+    assert torch.equal(dx, dy @ w)
+    with O.precision("bf16"):   # outside the mode the same call is the bf16 dgrad (here also exact)
+        (dx16,) = torch.autograd.grad((O.olinear(x, w, None, round_out=False, dgrad=("proj", None)) * dy).sum(), x)
+    assert torch.equal(dx16, dy @ w)
+    with O.precision("bf16"), O.dgrad8(True), pytest.raises(RuntimeError, match="frozen"):
+        O.olinear(x, w.clone().requires_grad_(True), None, dgrad=("proj", None))
+    # towers: forward identical, gradients within the mode's noise, fp32 precision ignores the switch
+    torch.manual_seed(0)
+    enc = O.ImageEncoder(O.VisionTransformer(img_size=32, dim=128, depth=3, heads=2, num_classes=0), 4, 64)
+    de = O.DNAEncoder(O.BertForMaskedLM(vocab=1027, hidden=128, layers=2, heads=2, ff=256), 4, 64)
+    with torch.no_grad():
+        for m in (enc, de):
+            for n, p in m.named_parameters():
+                if "linear_b" in n or ".w_b." in n:
+                    p.normal_(0, 0.02)
+    img, ids = torch.rand(4, 3, 32, 32), torch.randint(3, 1027, (4, 133))
+
+    def grads(m, inp, prec, dg):
+        with O.precision(prec), O.dgrad8(dg):
+            y = m(inp)
+            ps = [p for p in m.parameters() if p.requires_grad]
+            return y.detach(), torch.cat([g_.flatten() for g_ in torch.autograd.grad((y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum(), ps)])
+
+    for m, inp in ((enc, img), (de, ids)):
+        y0, g0 = grads(m, inp, "bf16", False)
+        y1, g1 = grads(m, inp, "bf16", True)
+        assert torch.equal(y0, y1) and not torch.equal(g0, g1)
+        assert float(torch.nn.functional.cosine_similarity(g0, g1, dim=0)) > 0.999
+        y2, g2 = grads(m, inp, "fp32", True)
+        y3, g3 = grads(m, inp, "fp32", False)
+        assert torch.equal(g2, g3)
+    assert not O._DG8_ROWS     # every fc2 dgrad's row scales were consumed by the fc1 dgrad of the same layer
+    # the ViT's last block (class row only in the kernels) keeps the bf16 dgrad: a one-block ViT does not change at all
+    enc1 = O.ImageEncoder(O.VisionTransformer(img_size=32, dim=128, depth=1, heads=2, num_classes=0), 4, 64)
+    assert torch.equal(grads(enc1, img, "bf16", True)[1], grads(enc1, img, "bf16", False)[1])

@@ -92,6 +92,7 @@ class PolicyLinear(torch.autograd.Function):
     def forward(ctx, x, weight, sa):
         ctx.save_for_backward(weight)
         ctx.in_image = POLICY["in_image"]
+        ctx.blk = POLICY["block_index"]
         xf, wf = x.detach().float(), weight.detach().float()
         rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
         blk, frm = POLICY["block_index"], POLICY["bf16_from_block"]
@@ -131,7 +132,8 @@ class PolicyLinear(torch.autograd.Function):
         rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
         # round 5: 8-bit dgrad on the towers whose forward is fp8 (never the ViT under image_bf16): the gradient as e5m2 / e4m3 with one
         # scale per tensor, the weight as e4m3 with one scale per INPUT channel (the dgrad's output column, so the scale factors out)
-        if POLICY["dgrad"] is not None and (POLICY.get("dgrad_image") or not (ctx.in_image and POLICY["image_bf16"])):
+        img_ok = POLICY.get("dgrad_image") and (POLICY.get("dgrad_image_until") is None or (ctx.blk is not None and ctx.blk < POLICY["dgrad_image_until"]))
+        if POLICY["dgrad"] is not None and (img_ok or not ctx.in_image):
             wt = weight.detach().float().t().contiguous()          # [in, out]: rows = the dgrad GEMM's output channels
             w8, sn = O.quantize_rows_e4m3(wt)
             fmt, margin = POLICY["dgrad"], POLICY["dgrad_margin"]
@@ -241,6 +243,9 @@ def main():
                 ("dna_only+dgrad_both_rows_e4m3_x32", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_margin=32.0, dgrad_rows=True, dgrad_image=True)),
                 ("dna_only+dgrad_both_rows_mixed_x32", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="mixed", dgrad_margin=32.0, dgrad_rows=True, dgrad_image=True)),
                 ("dna_only+dgrad_rows_mixed_x32", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="mixed", dgrad_margin=32.0, dgrad_rows=True)),
+                ("dna_only+dgrad_rows_e4m3+vit_first9", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_rows=True, dgrad_image=True, dgrad_image_until=9)),
+                ("dna_only+dgrad_rows_e4m3+vit_first6", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_rows=True, dgrad_image=True, dgrad_image_until=6)),
+                ("dna_only+dgrad_rows_e4m3", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_rows=True)),
                 ("dna_bf16fwd+dgrad_e5m2", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e5m2", dna_fwd_bf16=True))]
     for name, (image, dna, labels) in (("train batch", tr), ("fresh batch", fr)):
         with O.precision("bf16"):
@@ -250,7 +255,7 @@ def main():
         for pname, pol in policies:
             if only is not None and pname not in only:
                 continue
-            POLICY.update(image_bf16=False, image_sites=None, fp8_until_block=None, dgrad=None, dgrad_margin=1.0, dna_fwd_bf16=False, dgrad_rows=False, dgrad_image=False)
+            POLICY.update(image_bf16=False, image_sites=None, fp8_until_block=None, dgrad=None, dgrad_margin=1.0, dna_fwd_bf16=False, dgrad_rows=False, dgrad_image=False, dgrad_image_until=None)
             POLICY.update(pol)
             with O.precision("fp8"):
                 i8, d8, l8, g8 = evaluate(om, image, dna, labels)
