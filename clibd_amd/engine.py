@@ -67,7 +67,8 @@ class NotSupportedYet(NotImplementedError):
 #   on the fc2 weight, so nothing saturates and no history of maxima is kept) against the transposed frozen weight as e4m3 with one scale per
 #   input channel, on v_mfma_f32_16x16x128_f8f6f4.  The QKV dgrad (its operand feeds the adapters' bf16 weight gradients), attention and every
 #   weight gradient stay bf16.  Oracle study (full-size towers, tools/fp8_policy_study.py, profiles/r05_exp_fp8_dgrad_study.log): gradient cosine
-#   against the bf16 dgrad 0.9998 on the training batch / 0.9875 on a fresh one with BOTH towers on it.  Frozen-base (LoRA) mode with the bf16
+#   against the bf16 dgrad 0.9998 on the training batch / 0.9875 on a fresh one with BOTH towers on it (MI355X, trained weights: 0.9998-1.0000 on
+#   the mean-pooled towers, 0.987-0.9998 with the ViT's too; SimpleCLIP.enable_fp8_dgrad selects towers).  Frozen-base (LoRA) mode with the bf16
 #   residual-gradient stream and bf16 gelu' only; a call whose token count is not a multiple of 4 takes the bf16 GEMMs.  DESIGN.md §3.1d.
 NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"),
                         dgrad=("bf16", "fp8"))
