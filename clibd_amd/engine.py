@@ -181,6 +181,7 @@ class TransformerStack:
         self.fp8 = None  # fp8-forward mode: [{site: activation scale}] per layer; see enable_fp8
         self._calib = None
         self.numerics = default_numerics()   # backward arithmetic switches (see NUMERICS_CHOICES above); set_numerics() changes them
+        self.dgrad8_sites = ("mlp", "proj")   # dgrad = "fp8": which of the covered GEMMs take it ("mlp" = the fc2 -> fc1 pair, "proj"); tools/dgrad8_sites_study.py
 
     def set_numerics(self, **settings):
         before = (self.numerics.get("ln_fold"), self.numerics.get("dgrad"))
@@ -639,9 +640,9 @@ class TransformerStack:
                         dres16, _ = ops.scatter_rows(dx1_f32, S, bf16=True, f32=False)           # residual path: class rows only
                         ndx_bf16 = new(H, BF16)
                         ndx_f32 = new(H, F32) if (full and i == 0) else None
-                        dx8 = new8(H) if dg8 else None
+                        dx8 = new8(H) if (dg8 and "mlp" in self.dgrad8_sites) else None
                         ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dres16, dx_bf16=ndx_bf16, dx_f32=ndx_f32, **pg(L.ln1_w, L.ln1_b),
-                                          **(f8kw(dx8) if dg8 else {}))
+                                          **(f8kw(dx8) if dx8 is not None else {}))
                         dx_f32, dx_bf16 = ndx_f32, ndx_bf16
                     else:
                         _, dres_full = ops.scatter_rows(dx1_f32, S, bf16=False, f32=True)        # residual path: class rows only
@@ -659,16 +660,16 @@ class TransformerStack:
                     ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)      # d(fc1 out)
                     wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                     ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                               # d(LN2 out)
-                dx18 = new8(H) if dg8 else None
+                dx18 = new8(H) if (dg8 and "proj" in self.dgrad8_sites) else None
                 if r16:
                     dx1_f32, dx1_bf16 = None, new(H, BF16)
                     ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres_bf16=dx_bf16, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b),
-                                      **(f8kw(dx18) if dg8 else {}))
+                                      **(f8kw(dx18) if dx18 is not None else {}))
                 else:
                     dx1_f32, dx1_bf16 = new(H, F32), new(H, BF16)
                     ops.layernorm_bwd(dtmp, rec["x1"], rec["st2"], c.g2, dres=dx_f32, dx_f32=dx1_f32, dx_bf16=dx1_bf16, **pg(L.ln2_w, L.ln2_b))
                 wg(dx1_bf16, rec.get("o"), [L.proj_w], [L.proj_b])
-                if dg8:
+                if dx18 is not None:
                     ops.gemm_fp8_dgrad_nt(dx18[0], c.wo_t8, c.cs_ot, a_row_dequant=dx18[1], out_bf16=dtmp)   # d(attn out)
                 else:
                     ops.gemm_nt(dx1_bf16, c.wo_t, out_bf16=dtmp)                                         # d(attn out)
@@ -681,9 +682,9 @@ class TransformerStack:
                     ops.gemm_nt(dqkv, c.wqkv_t, rank_u=dt if has_lora else None, rank_v=c.v_bwd if has_lora else None, residual=add32, out_bf16=dtmp)
                     if r16:
                         ndx_f32, ndx_bf16 = (new(H, F32) if (full and i == 0) else None), new(H, BF16)
-                        dx8 = new8(H) if dg8 else None
+                        dx8 = new8(H) if (dg8 and "mlp" in self.dgrad8_sites) else None
                         ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres_bf16=dx1_bf16, dx_bf16=ndx_bf16, dx_f32=ndx_f32, **pg(L.ln1_w, L.ln1_b),
-                                          **(f8kw(dx8) if dg8 else {}))
+                                          **(f8kw(dx8) if dx8 is not None else {}))
                     else:
                         ndx_f32, ndx_bf16 = new(H, F32), new(H, BF16)
                         ops.layernorm_bwd(dtmp, rec["x_in"], rec["st1"], c.g1, dres=dx1_f32, dx_f32=ndx_f32, dx_bf16=ndx_bf16, **pg(L.ln1_w, L.ln1_b))
