@@ -249,3 +249,29 @@ def test_dgrad8_needs_the_bf16_stream_and_frozen_weights(dev):
     m3.tower().stack.set_numerics(dgrad="fp8")
     with pytest.raises(NotSupportedYet, match="hidden % 256"):
         m3(ids.to(dev)).sum().backward()
+
+
+def test_dgrad8_falls_back_to_bf16_when_the_token_count_is_not_a_multiple_of_four(dev):
+    """The e4m3 dgrad forms load a row group's four dequantisation factors as one vector (M % 4 == 0): a call with another token count
+    (here 3 sequences of 133 tokens) takes the bf16 GEMMs — the same gradients as with the switch off."""
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder
+
+    torch.manual_seed(41)
+    m = CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, hidden_size=512, num_hidden_layers=2, num_attention_heads=8, intermediate_size=1024)), r=4, num_classes=64).to(dev).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if ".w_b." in n:
+                p.normal_(0, 0.02)
+    cot = torch.randn(4, 64, generator=torch.Generator().manual_seed(1)).to(dev)
+    out = {}
+    for B in (3, 4):
+        ids = torch.randint(3, 1027, (B, 133), generator=torch.Generator().manual_seed(B)).to(dev)
+        for mode in ("bf16", "fp8"):
+            m.tower().stack.set_numerics(dgrad=mode)
+            out[(B, mode)] = _grads(m.named_parameters(), (m(ids) * cot[:B]).sum())
+    m.tower().stack.set_numerics(dgrad="bf16")
+    # (at M = 399 the adapters' gradients are reduced with float atomics — the partials workspace needs M % 32 == 0 — so "the same" means
+    #  to the order of those additions, 1e-6; the 8-bit dgrad moves the gradients by 1e-3 and more)
+    dist = lambda B: max(float((out[(B, "bf16")][n] - out[(B, "fp8")][n]).norm() / (out[(B, "bf16")][n].norm() + 1e-30)) for n in out[(B, "bf16")])
+    assert dist(3) < 1e-5, dist(3)
+    assert dist(4) > 1e-4, dist(4)
