@@ -417,26 +417,35 @@ __global__ __launch_bounds__(256) void lora_dt_db_kernel(const unsigned short* _
     }
 }
 
-// dst[i] += sum over copies x < G of ws[x][i], copies added in index order (deterministic).  Element i of the copy layout
+// dst[i] += sum over copies x < G of ws[x][i], copies added in a fixed order (deterministic: bit-reproducible gradients).  Element i of the copy layout
 // [dB_q (4H) | dB_v (4H) | dA_q (4H) | dA_v (4H)]; the dB half was written by g_b workgroups, the dA half by g_a (0: that half is skipped).
 __global__ __launch_bounds__(256) void lora_reduce_kernel(const float* __restrict__ ws, int H, int g_b, int g_a, float* __restrict__ dB_q,
                                                           float* __restrict__ dB_v, float* __restrict__ dA_q, float* __restrict__ dA_v) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 16 * H) return;
-    const int part = i / (4 * H);
-    const int G = part < 2 ? g_b : g_a;
-    if (G <= 0) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four chains, recombined in a fixed order
-    int x = 0;
-    for (; x + 4 <= G; x += 4) {
-        s0 += ws[(size_t)x * 16 * H + i];
-        s1 += ws[(size_t)(x + 1) * 16 * H + i];
-        s2 += ws[(size_t)(x + 2) * 16 * H + i];
-        s3 += ws[(size_t)(x + 3) * 16 * H + i];
+    // 64 elements per workgroup, wave w adds the copies x = w, w + 4, ... in four chains; the four waves' sums meet in LDS in a fixed order.
+    // (Round 5, later: one element per THREAD with all G copies in sequence was 48 workgroups and 64 dependent loads deep — 32 us per layer
+    // at every batch size, 2 % of the b = 256 step.)
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + e;               // 16 H is a multiple of 64, and so is 4 H: a workgroup stays inside one matrix
+    const int which = i / (4 * H);
+    const int G = which < 2 ? g_b : g_a;
+    if (G <= 0) return;                              // (uniform per workgroup)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const size_t stride = (size_t)16 * H;
+    int x = w;
+    for (; x + 12 < G; x += 16) {
+        s0 += ws[(size_t)x * stride + i];
+        s1 += ws[(size_t)(x + 4) * stride + i];
+        s2 += ws[(size_t)(x + 8) * stride + i];
+        s3 += ws[(size_t)(x + 12) * stride + i];
     }
-    for (; x < G; ++x) s0 += ws[(size_t)x * 16 * H + i];
-    float* dst = part == 0 ? dB_q : part == 1 ? dB_v : part == 2 ? dA_q : dA_v;
-    dst[i - part * 4 * H] += (s0 + s1) + (s2 + s3);
+    for (; x < G; x += 4) s0 += ws[(size_t)x * stride + i];
+    part[w][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0) {
+        float* dst = which == 0 ? dB_q : which == 1 ? dB_v : which == 2 ? dA_q : dA_v;
+        dst[i - which * 4 * H] += (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    }
 }
 
 // Standalone down-projection t[m, 0:8] = bf16(x[m, :] . a_cat[0:8, :]^T) (bf16 operands, fp32 accumulation) — the arithmetic the
@@ -501,7 +510,7 @@ extern "C" size_t clibd_lora_workspace_bytes(int M, int H) {
 }
 
 static int lora_reduce_launch(const float* ws, int H, int g_b, int g_a, float* dA_q, float* dA_v, float* dB_q, float* dB_v, hipStream_t st) {
-    hipLaunchKernelGGL(lora_reduce_kernel, dim3((unsigned)((16 * H + 255) / 256)), dim3(256), 0, st, ws, H, g_b, g_a, dB_q, dB_v, dA_q, dA_v);
+    hipLaunchKernelGGL(lora_reduce_kernel, dim3((unsigned)(16 * H / 64)), dim3(256), 0, st, ws, H, g_b, g_a, dB_q, dB_v, dA_q, dA_v);
     return check_launch("lora_reduce");
 }
 
