@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-gemm-timing", action="store_true")
     ap.add_argument("--no-ref-numerics", action="store_true", help="skip the side measurement at the reference's backward numerics")
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
-    ap.add_argument("--fp8-forward", nargs="?", const="pooled", default=None, choices=["pooled", "pooled_mlp", "all"],
+    ap.add_argument("--fp8-forward", nargs="?", const="pooled", default=None, choices=["pooled", "pooled_ffn", "pooled_mlp", "all"],
                     help="BASELINE configs[4] (not the headline config): forward GEMMs on the fp8 MFMA.  'pooled' (default) = the towers whose head "
                          "averages its tokens (BarcodeBERT, BERT-small): gradient-faithful; 'all' adds the ViT: embedding-grade")
     ap.add_argument("--dgrad", choices=["bf16", "fp8", "fp8-pooled"], default=None,
@@ -766,7 +766,7 @@ def main():
             "data": "synthetic (rand 224x224 images, random 660-nt barcodes = 133 5-mer tokens, random-init weights)",
             "config": {"workload": f"global batch {b * world} = {world} GPU x {b} (" + ("BASELINE.json metric config" if b * world == 2048 and not args.tri_modal and not args.full_finetune and not args.fp8_forward and args.dgrad in (None, "bf16") else "secondary config") + "): Image+DNA contrastive training step, ViT-B/16 + BarcodeBERT(BERT-base) " +
                                    ("FULL fine-tune (disable_lora)" if args.full_finetune else "LoRA r=4") +
-                                   (", bf16 MFMA" if not args.fp8_forward else f", fp8-forward mode (BASELINE configs[4], towers={args.fp8_forward}): forward GEMMs of " + ({"pooled": "the mean-pooled towers (BarcodeBERT)", "pooled_mlp": "the mean-pooled towers (BarcodeBERT) and the MLP pair of every ViT block"}.get(args.fp8_forward, "every tower")) + " on the fp8 MFMA, backward bf16") +
+                                   (", bf16 MFMA" if not args.fp8_forward else f", fp8-forward mode (BASELINE configs[4], towers={args.fp8_forward}): forward GEMMs of " + ({"pooled": "the mean-pooled towers (BarcodeBERT)", "pooled_ffn": "the MLP pair of the mean-pooled towers (BarcodeBERT)", "pooled_mlp": "the mean-pooled towers (BarcodeBERT) and the MLP pair of every ViT block"}.get(args.fp8_forward, "every tower")) + " on the fp8 MFMA, backward bf16") +
                                    (" + BERT-small text tower" if args.tri_modal else ""),
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}", "image": "3x224x224", "dna_tokens": 133,
                        "loss": "soft-target InfoNCE over the all-gathered global batch", "optimizer": "fused AdamW",

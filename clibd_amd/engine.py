@@ -214,7 +214,7 @@ class TransformerStack:
             lightly trained towers; pretrained checkpoints with outlier channels want the calibration).
         The backward is unchanged bf16 (it needs gelu', qkv, statistics and — for the adapters — the bf16 LayerNorm output
         only): gradients are those of the bf16 network evaluated at the fp8 forward's activations.  LoRA / frozen-base mode only.
-        sites (round 5; pre-LN stacks only): a subset of FP8_SITES — ("fc1_in", "fc2_in") runs the MLP of every block on the fp8 MFMA
+        sites (round 5): a subset of FP8_SITES — ("fc1_in", "fc2_in") runs the MLP of every block on the fp8 MFMA
         and leaves QKV, attention and the projection on bf16 operands (the per-layer dicts then hold those sites only, which is also
         how the oracle is told: a site without a scale is a bf16 site).  The oracle study behind it: profiles/r05_exp_fp8_vit_sites.log."""
         if sites is not None:
@@ -222,8 +222,8 @@ class TransformerStack:
             if any(s not in self.FP8_SITES for s in sites):
                 raise ValueError(f"enable_fp8: sites must come from {self.FP8_SITES}")
             if set(sites) != set(self.FP8_SITES):
-                if not self.pre_ln or set(sites) != {"fc1_in", "fc2_in"}:
-                    raise NotSupportedYet("fp8 site selection: only the MLP pair (fc1_in, fc2_in) of a pre-LN stack is built")
+                if set(sites) != {"fc1_in", "fc2_in"}:
+                    raise NotSupportedYet("fp8 site selection: only the MLP pair (fc1_in, fc2_in) is built")
         if self.full_mode():
             raise NotSupportedYet("fp8 forward needs frozen base weights (their gradients would need the bf16 GEMM inputs)")
         if self.H % 256 or self.H < 512 or self.FF % 256:
@@ -530,7 +530,17 @@ class TransformerStack:
                 nxt = self.lora_a(i + 1)
                 t_next = torch.empty((M, 8), dtype=BF16, device=dev) if nxt is not None else None
                 ru, rv = (t if has_lora else None), (c.v_fwd if has_lora else None)
-                if f8 is not None:
+                if f8 is not None and mlp_only:   # fp8 on the MLP pair only (round 5): the attention half is the bf16 path's, LayerNorm 1 feeds fc1 as e4m3
+                    x1_bf16 = None
+                    x18 = new(H, ops.FP8)
+                    ops.gemm_nt(x_bf16, c.wqkv, bias=c.bqkv, rank_u=ru, rank_v=rv, out_bf16=qkv)
+                    ops.attention_fwd(qkv, B, S, self.heads, key_mask, o, drop=d_att)
+                    ops.gemm_nt(o, c.wo, bias=c.bo, residual=x_f32, out_f32=s1, drop=d_h1)
+                    ops.layernorm_fwd(s1, c.g1, c.be1, self.eps, y_f32=x1_f32, stats=st1, y_fp8=x18, fp8_scale=f8["fc1_in"])
+                    ops.gemm_fp8_nt(x18, c.w18, c.cs_1, bias=c.b1, gelu_out_fp8=a, gelu_out_scale=f8["fc2_in"], out_pre=h if save else h_tmp)
+                    ops.gemm_fp8_nt(a, c.w28, c.cs_2, bias=c.b2, residual=x1_f32, out_f32=s2, drop=d_h2)
+                    ops.layernorm_fwd(s2, c.g2, c.be2, self.eps, y_bf16=x2_bf16, y_f32=x2_f32, stats=st2, lora_a=nxt, t_out=t_next)
+                elif f8 is not None:
                     if x_fp8 is None:
                         raise ValueError("fp8 forward (post-LN): the caller passes the e4m3 image of x")
                     x1_bf16 = None

@@ -119,9 +119,13 @@ class SimpleCLIP(nn.Module):
     # Round 5: "pooled_mlp" = "pooled" plus the MLP pair (fc1, fc2) of every ViT block — the oracle study of SITE selections
     # (profiles/r05_exp_fp8_vit_sites.log) found the class row's sensitivity to sit in the attention half (fp8 on QKV + projection alone:
     # cosine 0.954; on fc1 + fc2 alone 0.985; on everything 0.937, training batch).
+    # Round 5, later: "pooled_ffn" = the MLP pair (fc1, fc2) of the mean-pooled towers ONLY, their attention half on bf16 — the oracle study of
+    # site selections inside the DNA tower (profiles/r05_exp_fp8_dna_sites.log) puts the pooled towers' loss of gradient fidelity in the
+    # attention half too (fresh batch: all four sites 0.9901, QKV + projection alone 0.9902, fc1 + fc2 alone 0.9987, fc2 alone 0.9991).
     FP8_TOWER_SETS = {"pooled": ("dna_encoder", "language_encoder"), "all": ("image_encoder", "dna_encoder", "language_encoder"),
-                      "pooled_mlp": ("image_encoder", "dna_encoder", "language_encoder")}
-    FP8_TOWER_SITES = {"pooled_mlp": {"image_encoder": ("fc1_in", "fc2_in")}}   # towers of a set that take a site selection
+                      "pooled_mlp": ("image_encoder", "dna_encoder", "language_encoder"), "pooled_ffn": ("dna_encoder", "language_encoder")}
+    FP8_TOWER_SITES = {"pooled_mlp": {"image_encoder": ("fc1_in", "fc2_in")},    # towers of a set that take a site selection
+                       "pooled_ffn": {"dna_encoder": ("fc1_in", "fc2_in"), "language_encoder": ("fc1_in", "fc2_in")}}
 
     def enable_fp8_forward(self, scales: Optional[dict] = None, enabled: bool = True, calibration_inputs=None, margin: float = 2.0,
                            towers=None):

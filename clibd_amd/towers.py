@@ -315,6 +315,8 @@ class BertTower(_Tower):
             d_emb = ops.Drop(self.p_hidden, ops.derive_seed(base, 255, 3))
         st_e = torch.empty((M, 2), dtype=F32, device=dev) if full else None
         f8 = self.stack.fp8
+        if f8 is not None and "qkv_in" not in f8[0]:
+            f8 = None   # fp8 site selection (MLP pair only): QKV takes the bf16 image of the embeddings
         x_fp8 = torch.empty((M, H), dtype=ops.FP8, device=dev) if f8 is not None else None
         ops.layernorm_fwd(e, _f32c(emb.LayerNorm.weight), _f32c(emb.LayerNorm.bias), float(emb.LayerNorm.eps), y_bf16=x_bf16, y_f32=x_f32,
                           stats=st_e, lora_a=a0, t_out=t0, drop=d_emb, y_fp8=x_fp8, fp8_scale=f8[0]["qkv_in"] if f8 is not None else 0.0)

@@ -1089,16 +1089,14 @@ def test_ln_fold_tower_matches_oracle(dev):
     assert not torch.equal(res["on"][0], res["off"][0]), "the switch did not reach the kernels"
     assert rel(res["on"][0], res["off"][0]) < 4e-3
 
-    def oracle(fold):
-        with O.precision("bf16"), O.ln_fold(fold):
-            yo = om(img)
-            ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
-            return yo.detach(), dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
-
-    yo_f, go_f = oracle(True)
-    yo_s, go_s = oracle(False)
+    with O.precision("bf16"), O.ln_fold(True):
+        yo = om(img)
+        ps = [(n, p) for n, p in om.named_parameters() if p.requires_grad]
+        yo_f, go_f = yo.detach(), dict(zip([n for n, _ in ps], torch.autograd.grad((yo * cot).sum(), [p for _, p in ps])))
+    with O.precision("bf16"), torch.no_grad():    # (the standard mode's gradients are test_image_tower_parity's business)
+        yo_s = om(img)
     e_ff, e_fs, e_ss = rel(res["on"][0], yo_f), rel(res["on"][0], yo_s), rel(res["off"][0], yo_s)
     print(f"[ln_fold] embeddings: fold vs oracle-fold {e_ff:.2e}, fold vs oracle-standard {e_fs:.2e}, standard vs oracle-standard {e_ss:.2e}")
     assert e_ff < 3e-3 and e_ss < 3e-3 and e_fs < 4e-3
     assert_grads(res["on"][1], go_f, what="ln_fold on vs oracle fold")
-    assert_grads(res["on"][1], go_s, rel_tol=3e-2, cos_tol=0.999, what="ln_fold on vs oracle standard")
+    assert_grads(res["on"][1], res["off"][1], rel_tol=3e-2, cos_tol=0.999, what="ln_fold on vs off")   # the fold moves the gradients by bf16 noise only

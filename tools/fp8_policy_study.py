@@ -98,6 +98,8 @@ class PolicyLinear(torch.autograd.Function):
         blk, frm = POLICY["block_index"], POLICY["bf16_from_block"]
         if POLICY["in_image"] and POLICY["image_bf16"]:
             return F.linear(rb(xf), rb(wf))
+        if (not POLICY["in_image"]) and POLICY.get("dna_sites") is not None and vit_site(weight) not in POLICY["dna_sites"]:
+            return F.linear(rb(xf), rb(wf))   # round 5: fp8 forward on SOME of the DNA tower's GEMM sites (q / k / v / attention output are [H,H]: "proj")
         if POLICY.get("dna_fwd_bf16"):    # diagnostic: the 8-bit dgrad alone, forward on bf16 operands
             return F.linear(rb(xf), rb(wf))
         if POLICY["in_image"] and frm is not None and blk is not None and blk >= frm:
@@ -246,6 +248,10 @@ def main():
                 ("dna_only+dgrad_rows_e4m3+vit_first9", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_rows=True, dgrad_image=True, dgrad_image_until=9)),
                 ("dna_only+dgrad_rows_e4m3+vit_first6", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_rows=True, dgrad_image=True, dgrad_image_until=6)),
                 ("dna_only+dgrad_rows_e4m3", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e4m3", dgrad_rows=True)),
+                ("dna_mlp", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dna_sites=("fc1", "fc2"))),
+                ("dna_mlp+dgrad_both_rows_e4m3", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dna_sites=("fc1", "fc2"), dgrad="e4m3", dgrad_rows=True, dgrad_image=True)),
+                ("dna_fc2", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dna_sites=("fc2",))),
+                ("dna_attn", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dna_sites=("proj",))),
                 ("dna_bf16fwd+dgrad_e5m2", dict(gran="tensor", cls_bf16=False, bf16_from_block=None, image_bf16=True, dgrad="e5m2", dna_fwd_bf16=True))]
     for name, (image, dna, labels) in (("train batch", tr), ("fresh batch", fr)):
         with O.precision("bf16"):
@@ -255,7 +261,7 @@ def main():
         for pname, pol in policies:
             if only is not None and pname not in only:
                 continue
-            POLICY.update(image_bf16=False, image_sites=None, fp8_until_block=None, dgrad=None, dgrad_margin=1.0, dna_fwd_bf16=False, dgrad_rows=False, dgrad_image=False, dgrad_image_until=None)
+            POLICY.update(image_bf16=False, image_sites=None, fp8_until_block=None, dgrad=None, dgrad_margin=1.0, dna_fwd_bf16=False, dgrad_rows=False, dgrad_image=False, dgrad_image_until=None, dna_sites=None)
             POLICY.update(pol)
             with O.precision("fp8"):
                 i8, d8, l8, g8 = evaluate(om, image, dna, labels)
