@@ -175,8 +175,8 @@ class SimpleCLIP(nn.Module):
         """The 8-bit dgrad (engine numerics dgrad = "fp8") on a SELECTION of towers, the bf16 dgrad on the others:
         "pooled" = the mean-pooled towers (BarcodeBERT, BERT-small), where the oracle study and the MI355X measurement put its cost at
         <= 2e-4 of gradient cosine; "all" adds the ViT (about 1e-4 per block in the oracle study, more on MI355X's trained weights): the
-        gradient stays within cosine 0.987-0.9998 of the bf16 dgrad's, and together with the pooled fp8 FORWARD 0.977-0.9996 — at the 0.98
-        gate, under it on fresh batches in one of two runs.  set_numerics(dgrad="fp8") is this with towers="all".
+        gradient stays within cosine 0.987-0.9998 of the bf16 dgrad's; together with the "pooled_ffn" fp8 FORWARD 0.978-0.9997 (fresh
+        batches 0.978-0.988), with the all-site "pooled" forward 0.976-0.9996.  set_numerics(dgrad="fp8") is this with towers="all".
         An iterable of encoder attribute names selects towers explicitly."""
         names = self.FP8_TOWER_SETS[towers] if isinstance(towers, str) else tuple(towers)
         for n in names:
