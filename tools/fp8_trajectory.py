@@ -1,7 +1,7 @@
 """Loss trajectories of the same training run in bf16, fp8-forward "pooled" and fp8-forward "all" (full-size ViT-B/16 + BERT-base, LoRA r=4,
 the towers in train mode with identical dropout seeds, 256 fixed synthetic pairs cycled in batches of 64, AdamW through Trainer.step,
 fp8 scales re-calibrated every 10 steps): how far the fp8 modes drift from the bf16 run they approximate.
-Round 5: a mode is <forward>[+dgrad8] with forward in bf16 | pooled | pooled_mlp | all; "+dgrad8" switches the 8-bit dgrad on (numerics dgrad = "fp8").
+Round 5: a mode is <forward>[+dgrad8|+dgrad8p] with forward in bf16 | pooled | pooled_ffn | pooled_mlp | all; "+dgrad8" switches the 8-bit dgrad on for every tower (numerics dgrad = "fp8"), "+dgrad8p" for the mean-pooled towers only.
     python tools/fp8_trajectory.py [steps=80] [modes=pooled,all] > gpurun_out/<tag>/fp8_trajectory.log"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,7 +29,9 @@ def run(mode):
     if fwd != "bf16":
         model.enable_fp8_forward(towers=fwd)
     if mode.endswith("+dgrad8"):
-        model.set_numerics(dgrad="fp8")
+        model.enable_fp8_dgrad(towers="all")
+    elif mode.endswith("+dgrad8p"):     # the 8-bit dgrad on the mean-pooled towers only
+        model.enable_fp8_dgrad(towers="pooled")
     tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True, fp8_recalibrate_every=10 if fwd != "bf16" else 0)
     out = []
     torch.manual_seed(999)                      # the same dropout seeds in every mode
