@@ -614,7 +614,7 @@ class TransformerStack:
         r16 = self.numerics["residual_grad"] == "bf16"
         # 8-bit dgrad (numerics dgrad = "fp8"): every LayerNorm backward below also writes its output as e4m3 rows + one dequantisation
         # factor per row (new8), which the next dgrad GEMM takes as its A operand; dx8 = that pair for the incoming stream gradient
-        dg8 = (not full) and self._dgrad8_ok() and self._cache[0].w2_t8 is not None and M % 4 == 0
+        dg8 = (not full) and self._dgrad8_ok() and self._cache[0].w2_t8 is not None and M % 4 == 0 and M * FF < 2 ** 32   # (the fp8 kernel addresses operands with 32-bit byte offsets)
         new8 = lambda cols: (torch.empty((M, cols), dtype=torch.uint8, device=dev).view(ops.FP8), torch.empty((M,), dtype=F32, device=dev))
         f8kw = lambda pair: dict(dx_fp8=pair[0], row_dequant=pair[1])
         dx8 = None
