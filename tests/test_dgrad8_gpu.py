@@ -275,3 +275,27 @@ def test_dgrad8_falls_back_to_bf16_when_the_token_count_is_not_a_multiple_of_fou
     dist = lambda B: max(float((out[(B, "bf16")][n] - out[(B, "fp8")][n]).norm() / (out[(B, "bf16")][n].norm() + 1e-30)) for n in out[(B, "bf16")])
     assert dist(3) < 1e-5, dist(3)
     assert dist(4) > 1e-4, dist(4)
+
+
+def test_dgrad8_text_tower_with_a_padding_mask_matches_oracle(dev):
+    """BERT-small (H = 512, FF = 2048 — the smallest shapes the fp8 kernel takes — S = 20 with a key mask, mean over all 20 positions): the third
+    tower of the tri-modal configuration on the 8-bit dgrad against the oracle's restatement, and against its own bf16 dgrad."""
+    from oracle import clibd_oracle as O
+    from tests.test_model_gpu import _bert_small_pair, _text_batch
+
+    om, m = _bert_small_pair(dev)
+    x = _text_batch(64, 7)
+    cot = torch.randn(64, 768, generator=torch.Generator().manual_seed(8))
+    xd = {k: v.to(dev) for k, v in x.items()}
+    res = {}
+    for mode in ("bf16", "fp8"):
+        m.tower().stack.set_numerics(dgrad=mode)
+        y = m(xd)
+        res[mode] = (y.detach().cpu(), _grads(m.named_parameters(), (y * cot.to(dev)).sum()))
+    m.tower().stack.set_numerics(dgrad="bf16")
+    assert torch.equal(res["bf16"][0], res["fp8"][0])
+    with O.precision("bf16"), O.dgrad8(True):
+        yo = om(x)
+        ora = _grads(om.named_parameters(), (yo * cot).sum())
+    keep = lambda g_: {n: v for n, v in g_.items() if n in ora}
+    _compare(keep(res["fp8"][1]), keep(res["bf16"][1]), ora, "BERT-small with a padding mask", 0.999, 0.995)
