@@ -602,7 +602,7 @@ def main():
         overlapped["steps"] = min(args.steps, 5)
     serial = None
     if overlapped and overlap_on:
-        timer.events, timer.flops, timer.shapes, timer.bytes = [], 0.0, [], 0.0
+        timer.events, timer.flops, timer.flops_fp8, timer.shapes, timer.bytes = [], 0.0, 0.0, [], 0.0
         model.overlap_towers = False
         serial_steps = min(args.steps, 5)
         one_step()
@@ -745,6 +745,9 @@ def main():
             roof.update(achieved=gemm["tflops"], frac=gemm["frac"], launches=gemm["launches"],
                         gemm_ms_per_step=gemm["total_ms"] / gsteps, avg_launch_us=gemm["total_ms"] / gemm["launches"] * 1e3,
                         algorithmic_bytes_per_launch=gemm["bytes_per_launch"])
+            if gemm.get("fp8_flop_share"):   # configs[4] lines: frac prices every launch at the dense peak of ITS operand type (fp8 = 2 x bf16)
+                roof["fp8_flop_share"] = gemm["fp8_flop_share"]
+                roof["frac_note"] = "fp8 launches (forward and 8-bit dgrad) priced at 5.0 PFLOP/s, bf16 launches at 2.5"
             if serial is not None:
                 roof["timed_region"] = {"achieved": overlapped["tflops"], "gemm_ms_per_step": overlapped["total_ms"] / overlapped["steps"],
                                         "avg_launch_us": overlapped["total_ms"] / overlapped["launches"] * 1e3, "streams": 2}
