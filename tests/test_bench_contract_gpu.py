@@ -68,4 +68,4 @@ def test_bench_line_of_the_fp8_configuration():
     assert num["image_encoder"]["dgrad"] == "fp8" and num["dna_encoder"]["dgrad"] == "fp8"
     assert num["image_encoder"]["forward"] == "bf16" and num["dna_encoder"]["forward"].startswith("fp8")
     assert d["value"] > 0 and d["loss"] == d["loss"] and "reference_numerics" not in d
-    assert 0 < d["roofline"]["frac"] < 1
+    assert 0 < d["roofline"]["frac"] < 1 and 0.2 < d["roofline"]["fp8_flop_share"] < 0.9   # DNA forward + MLP / projection dgrads of both towers
