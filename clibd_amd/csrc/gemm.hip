@@ -377,6 +377,8 @@ extern "C" int clibd_gemm_fp8_dgrad_nt(const void* A, int lda, const void* W, in
     if ((lda & 15) || (ldw & 15) || !aligned16(A) || !aligned16(W) || !aligned16(col_scale) || (a_row_dequant && !aligned16(a_row_dequant)))
         return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: alignment (lda, ldw % 16)");
     if (ep->ld_out_bf16 & 7 || ep->ld_aux & 7) return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: leading dimensions");
+    if (ep->act == CLIBD_ACT_MUL_AUX_U8 && (!ep->aux_bf16 || ep->ld_aux % 16 || ep->ld_aux < N))
+        return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: MUL_AUX_U8 needs aux (one byte per element) with ld_aux >= N, % 16");
     if (!ep->out_bf16 || !aligned16(ep->out_bf16) || (ep->aux_bf16 && !aligned16(ep->aux_bf16))) return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: out_bf16 / aux alignment");
     if (ep->out_f32 || ep->out_pre_bf16 || ep->residual_f32 || ep->bias || ep->rank_u || ep->rank_v || ep->row_sums || ep->row_stats || ep->col_sum_w)
         return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: only out_bf16 [+ aux_bf16] epilogues");
@@ -388,7 +390,7 @@ extern "C" int clibd_gemm_fp8_dgrad_nt(const void* A, int lda, const void* W, in
     p.fp8 = 1; p.col_scale = col_scale; p.out_fp8_scale = out_fp8_scale; p.a_row_dequant = a_row_dequant;
     if (!gemm256_fp8_dgrad_launch(p, (hipStream_t)stream))
         return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: shape / epilogue not supported (M % 4, N % 256, K % 256, K >= 512; forms: -> bf16 | + aux_bf16 -> bf16 "
-                                       "(both need a_row_dequant) | x aux_bf16 -> fp8 (needs out_fp8_scale > 0))");
+                                       "(both need a_row_dequant) | x aux (bf16 gelu' or its one-byte code) -> fp8 (needs out_fp8_scale > 0))");
     return check_launch("gemm256_fp8_dgrad_nt");
 }
 

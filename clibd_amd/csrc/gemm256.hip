@@ -59,7 +59,7 @@ __device__ __forceinline__ i32x8 cat_frag(bf16x8 lo, bf16x8 hi) {
 // DG (8-bit dgrad, round 5; FP8 only): the A operand is a GRADIENT as e4m3 bytes with one power-of-two scale per ROW (written by
 // clibd_layernorm_bwd_fp8), W the transposed frozen weight as e4m3 with one scale per row (= per input channel of the layer).
 //   EPI_BF16 / EPI_ADD_AUX: v = acc * col_scale[n] * a_row_dequant[m]  [+ aux]  -> out_bf16
-//   EPI_MUL_AUX           : out := e4m3(acc * col_scale[n] * aux[m,n] * out_fp8_scale) bytes — the row scale of A passes THROUGH to the
+//   EPI_MUL_AUX[_U8]      : out := e4m3(acc * col_scale[n] * aux[m,n] * out_fp8_scale) bytes (aux = gelu' as bf16, or as the one-byte code of §4) — the row scale of A passes THROUGH to the
 //                           output (the next dgrad's A operand, dequantised by the same a_row_dequant; 1 / out_fp8_scale rides in its col_scale).
 template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8, bool DG>
 __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, int skew_ticks, long long* stamps) {
@@ -467,7 +467,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[hm][t][q >> 1][q & 1] *= c;
                 }
-            if constexpr (DG && KIND != EPI_MUL_AUX) {   // the A operand's row scales (M % 4 == 0, host-checked: a group of 4 rows is all in or all out)
+            if constexpr (DG && KIND != EPI_MUL_AUX && KIND != EPI_MUL_AUX_U8) {   // the A operand's row scales (M % 4 == 0, host-checked: a group of 4 rows is all in or all out)
 #pragma unroll
                 for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
@@ -596,7 +596,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                             _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r];
                         if (KIND == EPI_ROWNORM_GELU) {
                             store_row8<EPI_GELU_SAVE>(ep, m, nb, v);
-                        } else if (DG && KIND == EPI_MUL_AUX) {
+                        } else if (DG && (KIND == EPI_MUL_AUX || KIND == EPI_MUL_AUX_U8)) {
                             *(uint2*)((unsigned char*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8fp8(v, p.out_fp8_scale);
                         } else if (epi_aux_kind(KIND)) {
                             *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
@@ -768,13 +768,16 @@ bool gemm256_fp8_dgrad_launch(const GemmParams& p, hipStream_t stream) {
     const int kind = epilogue_kind(p.ep);
     const void* fn = kind == EPI_BF16 ? (const void*)gemm256_fp8_dgrad_kernel<EPI_BF16>
                    : kind == EPI_MUL_AUX ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX>
+                   : kind == EPI_MUL_AUX_U8 ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8>
                    : kind == EPI_ADD_AUX ? (const void*)gemm256_fp8_dgrad_kernel<EPI_ADD_AUX> : nullptr;
     if (fn == nullptr) return false;
-    if ((p.out_fp8_scale > 0.f) != (kind == EPI_MUL_AUX)) return false;
-    if (kind != EPI_MUL_AUX && p.a_row_dequant == nullptr) return false;
+    const bool mul = kind == EPI_MUL_AUX || kind == EPI_MUL_AUX_U8;
+    if ((p.out_fp8_scale > 0.f) != mul) return false;
+    if (!mul && p.a_row_dequant == nullptr) return false;
     static const bool attr_ok = [] {
         bool ok = hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_ADD_AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         return ok;
     }();

@@ -69,7 +69,7 @@ class NotSupportedYet(NotImplementedError):
 #   weight gradient stay bf16.  Oracle study (full-size towers, tools/fp8_policy_study.py, profiles/r05_exp_fp8_dgrad_study.log): gradient cosine
 #   against the bf16 dgrad 0.9998 on the training batch / 0.9875 on a fresh one with BOTH towers on it (MI355X, trained weights: 0.9998-1.0000 on
 #   the mean-pooled towers, 0.987-0.9998 with the ViT's too; SimpleCLIP.enable_fp8_dgrad selects towers).  Frozen-base (LoRA) mode with the bf16
-#   residual-gradient stream and bf16 gelu' only; a call whose token count is not a multiple of 4 takes the bf16 GEMMs.  DESIGN.md §3.1d.
+#   residual-gradient stream only (gelu' as bf16 or as its one-byte code); a call whose token count is not a multiple of 4 takes the bf16 GEMMs.  DESIGN.md §3.1d.
 NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"),
                         dgrad=("bf16", "fp8"))
 _NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD", ln_fold="CLIBD_LN_FOLD",
@@ -193,8 +193,8 @@ class TransformerStack:
         """dgrad = "fp8" is on and this stack can take it (see NUMERICS_CHOICES); raises for a configuration that cannot."""
         if self.numerics["dgrad"] != "fp8":
             return False
-        if self.full_mode() or self.numerics["residual_grad"] != "bf16" or self.numerics["gelu_grad"] != "bf16":
-            raise NotSupportedYet("dgrad=fp8 needs frozen base weights (LoRA mode), residual_grad=bf16 and gelu_grad=bf16")
+        if self.full_mode() or self.numerics["residual_grad"] != "bf16":
+            raise NotSupportedYet("dgrad=fp8 needs frozen base weights (LoRA mode) and residual_grad=bf16")
         if self.H % 256 or self.H < 512 or self.FF % 256:
             raise NotSupportedYet("dgrad=fp8 needs hidden % 256 == 0, hidden >= 512, intermediate % 256 == 0")
         return True
@@ -663,7 +663,7 @@ class TransformerStack:
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 if dg8 and dx8 is not None:   # d(fc1 out) leaves as e4m3 with the rows' scales x c2; the fc1 dgrad divides both back out
                     dh8 = torch.empty((M, FF), dtype=torch.uint8, device=dev).view(ops.FP8)
-                    ops.gemm_fp8_dgrad_nt(dx8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=ops.ACT_MUL_AUX, out_fp8=dh8, out_fp8_scale=c.c2)
+                    ops.gemm_fp8_dgrad_nt(dx8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"]), out_fp8=dh8, out_fp8_scale=c.c2)
                     ops.gemm_fp8_dgrad_nt(dh8, c.w1_t8, c.cs_1t, a_row_dequant=dx8[1], out_bf16=dtmp)
                 else:
                     dh = new(FF, BF16) if dh is None else dh
@@ -720,7 +720,7 @@ class TransformerStack:
                 dx1 = new(H, BF16)
                 if dg8:
                     dh8 = torch.empty((M, FF), dtype=torch.uint8, device=dev).view(ops.FP8)
-                    ops.gemm_fp8_dgrad_nt(ds2_8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=ops.ACT_MUL_AUX, out_fp8=dh8, out_fp8_scale=c.c2)
+                    ops.gemm_fp8_dgrad_nt(ds2_8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"]), out_fp8=dh8, out_fp8_scale=c.c2)
                     ops.gemm_fp8_dgrad_nt(dh8, c.w1_t8, c.cs_1t, a_row_dequant=ds2_8[1], aux=ds2_res, act=ops.ACT_ADD_AUX, out_bf16=dx1)
                 else:
                     dh = new(FF, BF16) if dh is None else dh

@@ -206,7 +206,7 @@ def gemm_fp8_dgrad_nt(a: torch.Tensor, w: torch.Tensor, col_scale: torch.Tensor,
                       out_fp8: Optional[torch.Tensor] = None, out_fp8_scale: float = 0.0) -> None:
     """8-bit dgrad (clibd_gemm_fp8_dgrad_nt): a [M,K] e4m3 gradient rows with per-row scales (a_row_dequant [M] = 1 / scale), w [N,K] the
     transposed weight from quantize_rows_fp8_bf16.  Forms: act NONE -> out_bf16 | ACT_ADD_AUX + aux -> out_bf16 (both need a_row_dequant) |
-    ACT_MUL_AUX + aux -> out_fp8 = e4m3(value * out_fp8_scale), which keeps a's row scales."""
+    ACT_MUL_AUX (bf16 aux) / ACT_MUL_AUX_U8 (one-byte gelu' codes) -> out_fp8 = e4m3(value * out_fp8_scale), which keeps a's row scales."""
     _chk(a, FP8, "a", contiguous=False)
     _chk(w, FP8, "w", contiguous=False)
     _chk(col_scale, F32, "col_scale")
@@ -215,19 +215,19 @@ def gemm_fp8_dgrad_nt(a: torch.Tensor, w: torch.Tensor, col_scale: torch.Tensor,
     N, K2 = w.shape
     if K != K2 or col_scale.numel() != N:
         raise ValueError("gemm_fp8_dgrad_nt: shape mismatch")
-    if act not in (ACT_NONE, ACT_ADD_AUX, ACT_MUL_AUX):
-        raise ValueError("gemm_fp8_dgrad_nt: act must be NONE, ADD_AUX or MUL_AUX")
+    if act not in (ACT_NONE, ACT_ADD_AUX, ACT_MUL_AUX, ACT_MUL_AUX_U8):
+        raise ValueError("gemm_fp8_dgrad_nt: act must be NONE, ADD_AUX, MUL_AUX or MUL_AUX_U8")
     if (act == ACT_NONE) != (aux is None):
         raise ValueError("gemm_fp8_dgrad_nt: aux comes with ADD_AUX / MUL_AUX only")
     ep = GemmEpilogue()
     ep.split_k = 1
     ep.act = act
     if aux is not None:
-        _chk(aux, BF16, "aux", contiguous=False)
+        _chk(aux, torch.uint8 if act == ACT_MUL_AUX_U8 else BF16, "aux", contiguous=False)
         if tuple(aux.shape) != (M, N):
             raise ValueError("gemm_fp8_dgrad_nt: aux must be [M,N]")
         ep.aux_bf16, ep.ld_aux = aux.data_ptr(), _rowmajor(aux, "aux")
-    if act == ACT_MUL_AUX:
+    if act in (ACT_MUL_AUX, ACT_MUL_AUX_U8):
         if out_fp8 is None or out_bf16 is not None or not out_fp8_scale > 0:
             raise ValueError("gemm_fp8_dgrad_nt: the MUL_AUX form writes out_fp8 with a positive out_fp8_scale")
         _chk(out_fp8, FP8, "out_fp8", contiguous=False)

@@ -128,7 +128,8 @@ int clibd_quantize_rows_fp8(const float* w, int N, int K, float act_scale, void*
  * Forms (bias-free, no adapters; M % 4 == 0, N % 256 == 0, K % 256 == 0, K >= 512; lda, ldw, K in bytes):
  *   act NONE                : out_bf16 = bf16(acc * col_scale[n] * a_row_dequant[m])
  *   act ADD_AUX + aux_bf16  : out_bf16 = bf16(acc * col_scale[n] * a_row_dequant[m] + aux[m,n])
- *   act MUL_AUX + aux_bf16  : out_bf16 := e4m3(acc * col_scale[n] * aux[m,n] * out_fp8_scale) BYTES (ld_out_bf16 in bytes; a_row_dequant
+ *   act MUL_AUX[_U8] + aux  : (aux = gelu' as bf16, or its one-byte code as in clibd_gemm_bf16_nt's MUL_AUX_U8, ld_aux in bytes % 16)
+ *                             out_bf16 := e4m3(acc * col_scale[n] * aux[m,n] * out_fp8_scale) BYTES (ld_out_bf16 in bytes; a_row_dequant
  *                             unused): the dgrad through GELU writes the next dgrad's A operand, which keeps A's row scales; out_fp8_scale
  *                             (> 0 exactly for this form) is a power of two <= 448 / (256 * 1.13 * l1max) with l1max from
  *                             clibd_quantize_rows_fp8_bf16, so that no value saturates (|gelu'| <= 1.13, scaled row maxima < 256). */

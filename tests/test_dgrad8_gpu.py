@@ -299,3 +299,54 @@ def test_dgrad8_text_tower_with_a_padding_mask_matches_oracle(dev):
         ora = _grads(om.named_parameters(), (yo * cot).sum())
     keep = lambda g_: {n: v for n, v in g_.items() if n in ora}
     _compare(keep(res["fp8"][1]), keep(res["bf16"][1]), ora, "BERT-small with a padding mask", 0.999, 0.995)
+
+
+def test_gemm_fp8_dgrad_takes_the_one_byte_gelu_grad(dev):
+    """The fc2 dgrad's MUL_AUX form with gelu' as the one-byte code of numerics gelu_grad = "u8" (code * 1.265625 / 255 - 0.1328125): e4m3 bytes equal to a
+    torch evaluation of the same decode, up to the places where the decode's last fp32 bit lands on the other side of an e4m3 rounding boundary."""
+    from clibd_amd import ops
+
+    M, N, K = 1108, 3072, 768
+    g = torch.Generator().manual_seed(77)
+    a, w = ints((M, K), -3, 3, g), ints((N, K), -2, 2, g)
+    cs = 2.0 ** torch.randint(-3, 2, (N,), generator=g).float()
+    codes = torch.randint(0, 256, (M, N), generator=g, dtype=torch.int64).to(torch.uint8)
+    o8 = torch.empty((M, N), dtype=torch.uint8, device=dev).view(FP8)
+    ops.gemm_fp8_dgrad_nt(a.to(FP8).to(dev), w.to(FP8).to(dev), cs.to(dev), aux=codes.to(dev), act=ops.ACT_MUL_AUX_U8, out_fp8=o8, out_fp8_scale=2.0 ** -5)
+    gp = codes.float() * (1.265625 / 255.0) - 0.1328125
+    want = ((a.double() @ w.double().T) * cs.double()).float() * gp * 2.0 ** -5
+    wq, got = want.clamp(-448, 448).to(FP8).float(), o8.cpu().float()
+    assert float((got != wq).float().mean()) < 5e-3
+    assert bool(((got - wq).abs() <= torch.maximum(wq.abs() * 0.125, torch.tensor(2.0 ** -9))).all())
+    with pytest.raises(TypeError):       # bf16 aux with the one-byte act
+        ops.gemm_fp8_dgrad_nt(a.to(FP8).to(dev), w.to(FP8).to(dev), cs.to(dev), aux=torch.zeros((M, N), dtype=torch.bfloat16, device=dev), act=ops.ACT_MUL_AUX_U8,
+                              out_fp8=o8, out_fp8_scale=1.0)
+
+
+def test_dgrad8_with_the_one_byte_gelu_grad_in_a_tower(dev):
+    """numerics dgrad = "fp8" together with gelu_grad = "u8" (ViT width 768, three blocks, batch 16): the gradients of the two-switch mode stay within the
+    8-bit dgrad's own noise of the dgrad = "fp8" / bf16-gelu' mode (the one-byte code's error, 2.5e-3 absolute on gelu', is far below e4m3's)."""
+    from clibd_amd.model import CLIBDImageEncoder, VisionTransformer
+
+    torch.manual_seed(35)
+    m = CLIBDImageEncoder(VisionTransformer(embed_dim=768, depth=3, num_heads=12, num_classes=0), r=4, num_classes=768)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "linear_b_" in n:
+                p.normal_(0, 0.02)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(36)
+    img, cot = torch.rand(16, 3, 224, 224, generator=g).to(dev), torch.randn(16, 768, generator=g).to(dev)
+    res = {}
+    for key, kw in (("bf16", dict(dgrad="bf16", gelu_grad="bf16")), ("fp8", dict(dgrad="fp8", gelu_grad="bf16")), ("fp8+u8", dict(dgrad="fp8", gelu_grad="u8"))):
+        m.tower().stack.set_numerics(**kw)
+        y = m(img)
+        res[key] = (y.detach().cpu(), _grads(m.named_parameters(), (y * cot).sum()))
+    m.tower().stack.set_numerics(dgrad="bf16", gelu_grad="bf16")
+    names = sorted(res["bf16"][1])
+    f = {k: _flat(v[1], names) for k, v in res.items()}
+    assert torch.equal(res["fp8"][0], res["fp8+u8"][0])                       # the forward's activations do not depend on how gelu' is stored
+    assert not torch.equal(f["fp8"], f["fp8+u8"])
+    c8, c8u = _cos(f["fp8"], f["bf16"]), _cos(f["fp8+u8"], f["bf16"])
+    print(f"[dgrad8 + one-byte gelu'] cosine vs the bf16 dgrad: dgrad8 {c8:.6f}, dgrad8 + u8 {c8u:.6f}; between the two {_cos(f['fp8'], f['fp8+u8']):.6f}")
+    assert c8u > 0.999 and c8u > c8 - 2e-4
