@@ -356,3 +356,13 @@ def test_numerics_switches_are_explicit_settings(monkeypatch, tmp_path):
     with pytest.raises(ValueError):
         a.enable_fp8_forward(towers=("vision_tower",))
     assert SimpleCLIP.FP8_TOWER_SETS["pooled"] == ("dna_encoder", "language_encoder")
+    # round 5: the 8-bit dgrad is a per-tower numerics switch; the model-level selection sets it tower by tower
+    a.enable_fp8_dgrad(towers="pooled")
+    assert a.numerics()["dna_encoder"]["dgrad"] == "fp8" and a.numerics()["image_encoder"]["dgrad"] == "bf16"
+    a.enable_fp8_dgrad(towers="all")
+    assert a.numerics()["image_encoder"]["dgrad"] == "fp8"
+    a.enable_fp8_dgrad(enabled=False)
+    assert all(v["dgrad"] == "bf16" for v in a.numerics().values())
+    with pytest.raises(ValueError):
+        a.enable_fp8_dgrad(towers=("vision_tower",))
+    assert SimpleCLIP.FP8_TOWER_SETS["pooled_ffn"] == ("dna_encoder", "language_encoder") and SimpleCLIP.FP8_TOWER_SITES["pooled_ffn"]["dna_encoder"] == ("fc1_in", "fc2_in")

@@ -16,7 +16,7 @@ for cfg in $CFGS; do
     && python - "$OUT/bench_$name.json" "$name" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(f"{sys.argv[2]:36s} {d['ms_per_step']:8.2f} ms  {d['value']:8.1f} pairs/s  loss {d.get('loss')}  frac {d['roofline']['frac']:.3f}  sclk {d['roofline'].get('board', {}).get('sclk_mhz_mean')}")
+print(f"{sys.argv[2]:36s} {d['ms_per_step']:8.2f} ms  {d['value']:8.1f} pairs/s  loss {d.get('loss')}  frac {d['roofline']['frac']:.3f}  sclk {d['roofline'].get('board', {}).get('sclk_mhz')}")
 PY
 done
 if [ "${4:-}" = "prof" ]; then   # kernel statistics of the pooled forward + 8-bit dgrad step, serial towers
