@@ -43,6 +43,15 @@ constexpr int HALF_BYTES = 128 * T_K * 2;      // 16 KiB
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // 64 KiB
 constexpr int G256_THREADS = 512;
 constexpr int G256_LDS = 2 * STAGE_BYTES;      // 128 KiB
+// tile order (gemm_common.h tile_coords): W-stationary n-groups of 6 column tiles for every launch (round 5: in-step A/B against the m-bands of 4 of
+// rounds 1-4: -0.8 % of the b = 2048 step, -1.3 % at b = 256, -0.7 % in the fp8 modes; profiles/r05_exp_gemm_ws_in_step.log).  The -D knobs build the A/B variants.
+#ifndef CLIBD_WS_MIN_TILES_N
+#define CLIBD_WS_MIN_TILES_N 1
+#endif
+#ifndef CLIBD_WS_GROUP
+#define CLIBD_WS_GROUP 6
+#endif
+constexpr int G256_WS_MIN_TILES_N = CLIBD_WS_MIN_TILES_N, G256_WS_GROUP = CLIBD_WS_GROUP;
 
 #define CLIBD_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -750,7 +759,7 @@ bool gemm256_fp8_launch(const GemmParams& p, hipStream_t stream) {
     q.splits = 1;
     q.nk_split = nk;
     q.split_stride = 0;
-    q.band = 4;
+    q.band = q.tiles_n >= G256_WS_MIN_TILES_N ? -G256_WS_GROUP : 4;
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
     const int grid = (int)(tiles < device_cus() ? tiles : device_cus());
     int ntiles_i = (int)tiles, skew = 0;
@@ -788,7 +797,7 @@ bool gemm256_fp8_dgrad_launch(const GemmParams& p, hipStream_t stream) {
     q.splits = 1;
     q.nk_split = nk;
     q.split_stride = 0;
-    q.band = 4;
+    q.band = q.tiles_n >= G256_WS_MIN_TILES_N ? -G256_WS_GROUP : 4;
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
     const int grid = (int)(tiles < device_cus() ? tiles : device_cus());
     int ntiles_i = (int)tiles, skew = 0;
@@ -829,7 +838,7 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     q.splits = 1;
     q.nk_split = nk;
     q.split_stride = 0;
-    q.band = band_env_value() > 0 ? band_env_value() : 4;
+    q.band = band_env_value() != 0 ? band_env_value() : (q.tiles_n >= G256_WS_MIN_TILES_N ? -G256_WS_GROUP : 4);
     const int grid = (int)(tiles < num_cus ? tiles : num_cus);
     const int kind = epilogue_kind(p.ep);
     int ntiles_i = (int)tiles;

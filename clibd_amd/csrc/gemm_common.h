@@ -38,11 +38,24 @@ __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 +
 
 // XCD-aware, L2-friendly tile order: blocks sharing an XCD (id % 8) walk a contiguous range of tile ids; ids run
 // m-fastest inside bands of `band` m-tiles, so a band's A panels stay hot while its W panels stream through.
+// band < 0 (the product's order since round 5): W-stationary — n-groups of -band column tiles; inside a group m runs over ALL row tiles with the group's column
+// tiles fastest, so a group's W panels (six: 2.4 MB at K = 768) stay in the XCD's L2 while every A panel streams past once per group: 15-25 % fewer fabric
+// reads than the m-bands (round 3, profiles/r03_exp_tile_order.log: at equal time on isolated launches); inside the two-stream step, where both towers share the
+// fabric under the power cap, that is worth 0.8 % of the step (profiles/r05_exp_gemm_ws_in_step.log).
 __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int band, int& tile_m, int& tile_n) {
     const int ntiles = tiles_m * tiles_n;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (band < 0) {   // W-stationary order (round 5): n-groups of -band column tiles; inside a group m runs over ALL row tiles, the group's column tiles fastest
+        const int G = -band;
+        const int g = bid / (tiles_m * G);
+        const int rem = bid - g * tiles_m * G;
+        const int gw = min(G, tiles_n - g * G);
+        tile_m = rem / gw;
+        tile_n = g * G + rem - tile_m * gw;
+        return;
+    }
     const int band_id = bid / (band * tiles_n);
     const int band_m0 = band_id * band;
     const int band_h = min(band, tiles_m - band_m0);
