@@ -355,9 +355,9 @@ def test_fp8_gradients_on_spread_embeddings(dev):
 
     Round 5: the same measurement for the forward selection "pooled_ffn" (fp8 on fc1 / fc2 of the mean-pooled towers only: their loss sat in the
     attention half), for the 8-bit dgrad (numerics dgrad = "fp8") on the mean-pooled towers / on all towers with a bf16 forward, and for the
-    combinations.  Five MI355X runs (fresh batches, worst ... best; training batches >= 0.998 everywhere): pooled 0.9799 ... 0.9899,
-    pooled_ffn 0.9899 ... 0.9959, dgrad8(pooled) 0.9998 ... 0.9999, dgrad8(all) 0.9866 ... 0.9950, pooled_ffn + dgrad8(pooled) 0.9924 ... 0.9958,
-    pooled_ffn + dgrad8(all) 0.9784 ... 0.9883, pooled + dgrad8(all) 0.9763 ... 0.9835 (which of these is configs[4]'s mode)."""
+    combinations.  Seven MI355X runs (fresh batches, worst ... best; training batches >= 0.998 everywhere): pooled 0.9799 ... 0.9899,
+    pooled_ffn 0.9844 ... 0.9959, dgrad8(pooled) 0.9998 ... 0.9999, dgrad8(all) 0.9866 ... 0.9950, pooled_ffn + dgrad8(pooled) 0.9843 ... 0.9958,
+    pooled_ffn + dgrad8(all) 0.9780 ... 0.9885, pooled + dgrad8(all) 0.9746 ... 0.9835 (which of these is configs[4]'s mode)."""
     from clibd_amd.data import synthetic_batch
     from clibd_amd.model import ClipLoss
     from clibd_amd.train import Trainer
@@ -428,13 +428,13 @@ def test_fp8_gradients_on_spread_embeddings(dev):
         elif k[2] == "dgrad8(all)":
             assert c >= 0.975 and de == 0.0 and dd == 0.0, (k, c, de, dd)  # + the ViT's: measured 0.9866 - 0.9998
         elif k[2] in ("pooled_ffn", "pooled_ffn+dgrad8(pooled)"):
-            assert c >= 0.98 and de == 0.0 and dd < 3e-2, (k, c, de, dd)   # fp8 forward on the pooled towers' MLP pair [+ their 8-bit dgrad]: measured 0.9899 - 0.9999
+            assert c >= 0.975 and de == 0.0 and dd < 3e-2, (k, c, de, dd)  # fp8 forward on the pooled towers' MLP pair [+ their 8-bit dgrad]: measured 0.9843 - 0.9999
         elif k[2] == "pooled_ffn+dgrad8(all)":
-            assert c >= 0.965 and de == 0.0 and dd < 3e-2, (k, c, de, dd)  # +15 %: measured 0.9784 - 0.9997
+            assert c >= 0.965 and de == 0.0 and dd < 3e-2, (k, c, de, dd)  # +15 %: measured 0.9780 - 0.9997
         elif k[2] in ("pooled", "pooled+dgrad8(pooled)"):
             assert c >= 0.97 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # round 4's selection: measured 0.9799 - 0.9998
         elif k[2] == "pooled+dgrad8(all)":
-            assert c >= 0.96 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # measured 0.9763 - 0.9996: the two errors add
+            assert c >= 0.96 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # measured 0.9746 - 0.9996: the two errors add
         else:
             # embedding-grade: the floor round 3's measurement set.  "pooled_mlp" (round 5: + the ViT's MLP pair) sits between the two —
             # the oracle study (profiles/r05_exp_fp8_vit_sites.log) has it at 0.985 on the training batch and 0.82 on a fresh one after
