@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--dgrad", choices=["bf16", "fp8", "fp8-pooled"], default=None,
                     help="numerics switch dgrad (BASELINE configs[4]): fp8 = the MLP / projection activation-gradient GEMMs of every tower on e4m3 operands with per-row scales; "
                          "fp8-pooled = of the mean-pooled towers only (BarcodeBERT, BERT-small).  Not the headline config")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the BASELINE configs[4] side record (per-GPU batch 1024: bf16 vs pooled_ffn fp8 forward + fp8-pooled dgrad)")
+    ap.add_argument("--configs4-batch", type=int, default=1024, help="per-GPU batch of the configs[4] side record (BIOSCAN-5M-shaped run: 1024)")
     ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
     ap.add_argument("--eval", action="store_true", help="eval path (SURVEY §8f-2, not the headline metric): no-grad embedding forward + K10 top-k search")
     ap.add_argument("--eval-queries", type=int, default=1024, help="--eval: queries per top-k launch")
@@ -158,6 +160,66 @@ class GemmTimer:
         for (M, N, K, kinds), (n, t) in rows:
             print(f"[gemm] M={M:6d} N={N:5d} K={K:5d} x{n // steps:3d}/step {t / steps:7.3f} ms/step {t / n * 1e3:7.1f} us each "
                   f"{2.0 * M * N * K * n / (t * 1e-3) / 1e12:7.1f} TF  {kinds}", file=sys.stderr, flush=True)
+
+
+class CollectiveTimer:
+    """HIP-event brackets around the step's collectives (torch.distributed = RCCL), recorded on the stream each one is issued from:
+    the packed all-gather and the reduce-scatter inside ClipLoss, the flat gradient all-reduce of the trainer.  A synchronous collective
+    is bracketed call-to-return (the issuing stream waits for RCCL's stream, so the bracket holds the transfer AND the wait for the
+    slowest rank); an async one (bucketed full-fine-tune all-reduce) from issue to the end of its wait()."""
+
+    NAMES = {"all_gather_into_tensor": "all_gather", "reduce_scatter_tensor": "reduce_scatter", "all_reduce": "all_reduce"}
+
+    def __init__(self):
+        self.enabled, self.events = False, {v: [] for v in self.NAMES.values()}
+        self.bytes = {v: 0 for v in self.NAMES.values()}
+
+    def install(self, dist):
+        timer = self
+
+        class _Work:
+            def __init__(self, w, e0, key):
+                self._w, self._e0, self._key = w, e0, key
+
+            def wait(self, *a, **k):
+                r = self._w.wait(*a, **k)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                timer.events[self._key].append((self._e0, e1))
+                return r
+
+            def __getattr__(self, n):
+                return getattr(self._w, n)
+
+        def wrap(fname, key):
+            inner = getattr(dist, fname)
+
+            def timed(*a, **kw):
+                if not timer.enabled:
+                    return inner(*a, **kw)
+                t = a[0]
+                timer.bytes[key] += t.numel() * t.element_size()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = inner(*a, **kw)
+                if kw.get("async_op"):
+                    return _Work(r, e0, key)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                timer.events[key].append((e0, e1))
+                return r
+
+            setattr(dist, fname, timed)
+
+        for fname, key in self.NAMES.items():
+            wrap(fname, key)
+
+    def result(self, steps):
+        out = {}
+        for key, evs in self.events.items():
+            out[key] = {"ms_per_step": sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(steps, 1), "calls_per_step": len(evs) / max(steps, 1),
+                        "bytes_per_step": self.bytes[key] / max(steps, 1)}
+        return out
 
 
 def _pci_slot(local_rank: int):
@@ -431,6 +493,107 @@ def eval_bench(args, model, batch, b, world, rank, dev, dist, timer):
         emit(out_line)
 
 
+def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
+    """BASELINE configs[4] at its per-GPU batch (1024), bf16 against the recommended fp8 mode, same model, same process: see the call site."""
+    from clibd_amd.data import synthetic_batch
+
+    b4 = args.configs4_batch
+    with_full = args.full_finetune
+    batch4 = synthetic_batch(b4, dev, seed=44, rank=rank, with_text=False)
+    fresh4 = synthetic_batch(b4, dev, seed=45, rank=rank, with_text=False)
+    nsteps = min(args.steps, 5)
+
+    def timed_steps():
+        trainer.step(batch4["image"], batch4["dna"], None, batch4["labels"])     # warm-up at this shape / mode (workspaces, weight images)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            trainer.step(batch4["image"], batch4["dna"], None, batch4["labels"])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()) / nsteps * 1e3
+
+    towers = [enc.tower() for enc in (model.image_encoder, model.dna_encoder) if enc is not None]
+    params = list(trainer.optimizer.param_groups[0]["params"])
+
+    def grad_vector(bt):
+        """the step's gradient (forward + loss + backward, no optimizer) as one fp32 vector; same dropout masks on every call"""
+        sinks = [tw.grad_sink for tw in towers]
+        for tw in towers:
+            tw.grad_sink = None          # plain autograd outputs, the trainer's flat bucket untouched
+        try:
+            torch.manual_seed(4242)      # the towers draw their dropout base seeds from the CPU generator
+            hi, hd, _, scale, _ = model(bt["image"], bt["dna"], None)
+            loss = trainer.criterion(hi, hd, None, bt["labels"], scale)
+            gs = torch.autograd.grad(loss, params, allow_unused=True)
+            model.join_streams()
+            torch.cuda.synchronize()
+            return torch.cat([(torch.zeros_like(p) if g is None else g).detach().flatten().double() for p, g in zip(params, gs)])
+        finally:
+            for tw, sk in zip(towers, sinks):
+                tw.grad_sink = sk
+
+    def set_mode(on):
+        model.enable_fp8_dgrad(towers="pooled", enabled=on)
+        if on:
+            model.enable_fp8_forward(calibration_inputs=(batch4["image"], batch4["dna"], None), towers="pooled_ffn")
+        else:
+            model.enable_fp8_forward(enabled=False)
+
+    try:
+        ms16 = timed_steps()
+        set_mode(True)
+        ms8 = timed_steps()
+        share = None
+        if timer is not None and not args.no_gemm_timing:
+            timer.events, timer.flops, timer.flops_fp8, timer.shapes, timer.bytes = [], 0.0, 0.0, [], 0.0
+            timer.enabled = True
+            trainer.step(batch4["image"], batch4["dna"], None, batch4["labels"])
+            torch.cuda.synchronize()
+            timer.enabled = False
+            r = timer.result()
+            share = r["fp8_flop_share"] if r else None
+        # gradient fidelity of the model as it stands now, on the batch it just trained on and on one it has never seen
+        cos = {}
+        for name, bt in (("train_batch", batch4), ("fresh_batch", fresh4)):
+            g8 = grad_vector(bt)
+            set_mode(False)
+            g16 = grad_vector(bt)
+            set_mode(True)
+            cos[name] = float((g8 @ g16) / (g8.norm() * g16.norm()).clamp_min(1e-300))
+        set_mode(False)
+    except Exception as e:   # the side record must never take the headline line down with it
+        try:
+            set_mode(False)
+        except Exception:
+            pass
+        return {"error": repr(e)}
+    if world > 1:   # one number per job: the worst rank's cosine
+        c = torch.tensor([cos["train_batch"], cos["fresh_batch"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.MIN)
+        cos = {"train_batch": float(c[0]), "fresh_batch": float(c[1])}
+    return {"workload": f"BASELINE configs[4] per-rank shape: {world} GPU x {b4} pairs (global {world * b4}), Image+DNA, " +
+                        ("FULL fine-tune" if with_full else "LoRA r=4") + ", train mode",
+            "per_gpu_batch": b4, "global_batch": world * b4, "steps": nsteps,
+            "bf16": {"ms_per_step": ms16, "value": world * b4 / (ms16 * 1e-3), "unit": "paired samples/s"},
+            "fp8": {"ms_per_step": ms8, "value": world * b4 / (ms8 * 1e-3), "unit": "paired samples/s",
+                    "mode": "--fp8-forward pooled_ffn --dgrad fp8-pooled: e4m3 operands on fc1 / fc2 of the mean-pooled tower(s) (BarcodeBERT) forward, and on "
+                            "their MLP / projection activation-gradient GEMMs backward (per-row power-of-two scales); the ViT, attention, QKV and every "
+                            "weight gradient stay bf16",
+                    "fp8_flop_share": share},
+            "speedup": ms16 / ms8,
+            "gradient_cosine_vs_bf16": cos,
+            "note": "same model, same process, measured after the headline passes (the model has taken those optimizer steps on the synthetic batch: "
+                    "random-init towers + trained adapters / heads — no pretrained weights exist on this box); gradient_cosine = cos(fp8-mode gradient, bf16 "
+                    "gradient) over ALL trainable tensors, same dropout masks, on the configs4 training batch and on a batch never seen; at N > 1 the minimum over ranks"}
+
+
 _JSON_FD = None   # the process's original stdout, saved by main() before fd 1 is pointed at stderr
 
 
@@ -512,6 +675,11 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    ctimer = None
+    if world > 1 or forced:
+        ctimer = CollectiveTimer()
+        ctimer.install(dist)   # before clibd_amd.model / .train bind `dist` (they call through the module attribute)
+
     from clibd_amd.data import synthetic_batch
     from clibd_amd.model import (CLIBDDNAEncoder, CLIBDImageEncoder, CLIBDLanguageEncoder, SimpleCLIP, create_vit,
                                  load_pre_trained_bert, load_pre_trained_bioscan_bert)
@@ -572,6 +740,7 @@ def main():
         host_wall.append(time.perf_counter() - hw)
         host_cpu.append(time.thread_time() - hc)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0      # this rank's own clock, BEFORE the closing barrier makes every rank wait for the slowest
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -717,6 +886,47 @@ def main():
         del host8
         del host
 
+
+    # Multi-GPU diagnostics (never `value`): what a first SCALE run needs to be read from its one line.  HIP-event
+    # brackets around the step's three collectives on the streams they are issued from (a few extra steps right after the timed region),
+    # every rank's OWN step time (clock stopped before the closing barrier), and what the process group says it is.
+    multi = None
+    if ctimer is not None:
+        csteps = min(args.steps, 5)
+        one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ctimer.enabled = True
+        for _ in range(csteps):
+            one_step()
+        torch.cuda.synchronize()
+        ctimer.enabled = False
+        own = torch.tensor([own_elapsed / args.steps * 1e3], dtype=torch.float64, device=dev)
+        allr = torch.empty((world,), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, own)
+        per_rank = [float(v) for v in allr.tolist()]
+        try:
+            nccl_v = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            nccl_v = None
+        multi = {"collectives_ms": {k: v["ms_per_step"] for k, v in ctimer.result(csteps).items()},
+                 "collectives_detail": ctimer.result(csteps),
+                 "per_rank_ms": per_rank, "rank_skew_ms": max(per_rank) - min(per_rank),
+                 "rccl_ranks": {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": nccl_v,
+                                "devices": torch.cuda.device_count()},
+                 "note": "collectives_ms: rank 0, HIP events on the issuing stream around each collective (all_gather = the packed embeddings + labels "
+                         "inside ClipLoss, reduce_scatter = its backward, all_reduce = the flat gradient bucket + the loss slot), mean per step over "
+                         f"{csteps} steps after the timed region — a bracket holds the transfer AND the wait for the slowest rank; per_rank_ms: each "
+                         "rank's own mean step time over the timed region, its clock stopped before the closing barrier; rank_skew_ms = max - min of those"}
+
+    # Side record (never `value`): BASELINE configs[4] — the BIOSCAN-5M-shaped run, per-GPU batch 1024, "fp8 MFMA attention/GEMM path" — as this
+    # build recommends it: fp8 forward on the MLP pair of the mean-pooled towers ("pooled_ffn") + their 8-bit dgrad ("fp8-pooled"), against
+    # the bf16 step at the same batch, with the gradient cosine of THIS model (as the steps above left it) on a fresh batch measured in-run.
+    cfg4 = None
+    if not args.no_configs4 and not args.fp8_forward and args.dgrad in (None, "bf16") and not args.tri_modal and not args.full_finetune:
+        cfg4 = configs4_record(args, model, trainer, dev, world, rank, dist, timer)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         pairs_per_s = b * world * args.steps / elapsed
@@ -788,6 +998,10 @@ def main():
             out["invalid"] = "CLIBD_BENCH_SHARED_GPU: ranks shared a GPU over gloo (code-path check, not a measurement)"
         if forced:
             out["collectives"] = "CLIBD_FORCE_COLLECTIVES: the step's three collectives ran over a ONE-rank RCCL group (their launch path, no transfer)"
+        if multi is not None:
+            out.update(multi)
+        if cfg4 is not None:
+            out["configs4"] = cfg4
         if ref_num is not None:
             if ref_num.get("value") is None:
                 ref_num.update(value=pairs_per_s, ms_per_step=ms_per_step)

@@ -58,6 +58,8 @@ SIGNATURES = {
     "clibd_quantize_rows_fp8_bf16": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_transpose_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "clibd_transpose_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "clibd_transpose_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "clibd_transpose_colsum_bf16_ws": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "clibd_cast_transpose_f32_to_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "clibd_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -120,7 +122,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4   # what this binding was written against (clibd_abi_version(), csrc/capi.hip); load() refuses any other library
+ABI_VERSION = 5   # what this binding was written against (clibd_abi_version(), csrc/capi.hip); load() refuses any other library
 
 
 class ClibdHipError(RuntimeError):

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned shor
 template <int RB>
 __global__ __launch_bounds__(256) void transpose_colsum_bf16_kernel(const unsigned short* __restrict__ in, int ld_in, int R, int C,
                                                                     unsigned short* __restrict__ out, int ld_out,
-                                                                    float* __restrict__ colsum) {
+                                                                    float* __restrict__ colsum, float* __restrict__ partials) {
     __shared__ __attribute__((aligned(16))) unsigned short tile[64 * RB * 66];
     const int r0 = blockIdx.y * (64 * RB), c0 = blockIdx.x * 64;
     const int t = threadIdx.x;
@@ -222,9 +222,29 @@ __global__ __launch_bounds__(256) void transpose_colsum_bf16_kernel(const unsign
             sum += dpp_mov<DPP_QUAD_XOR1>(sum);
             sum += dpp_mov<DPP_QUAD_XOR2>(sum);
             sum += dpp_mov<DPP_ROW_HALF_MIRROR>(sum);
-            if (rch == 0 && c0 + c < C) atomicAdd(colsum + c0 + c, sum);
+            if (rch == 0 && c0 + c < C) {
+                if (partials != nullptr) partials[(size_t)blockIdx.y * C + c0 + c] = sum;   // summed in row-block order by colsum_partials_kernel
+                else atomicAdd(colsum + c0 + c, sum);
+            }
         }
     }
+}
+
+// colsum[c] += sum_b partials[b, c] in the fixed order b = 0, 1, ... (four interleaved chains, combined in a fixed order): the bias
+// gradient of the workspace form of the transpose (clibd_transpose_colsum_bf16_ws) repeats bit for bit from run to run.
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ colsum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += partials[(size_t)b * C + c];
+        s1 += partials[(size_t)(b + 1) * C + c];
+        s2 += partials[(size_t)(b + 2) * C + c];
+        s3 += partials[(size_t)(b + 3) * C + c];
+    }
+    for (; b < nblk; ++b) s0 += partials[(size_t)b * C + c];
+    colsum[c] += (s0 + s1) + (s2 + s3);
 }
 
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* in, unsigned short* out, size_t n) {
@@ -450,21 +470,33 @@ extern "C" int clibd_gemm_bf16_tn_splitk(const void* A, int lda, const void* B, 
     return check_launch("reduce_splits");
 }
 
-static int transpose_impl(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum, void* stream) {
+static inline int transpose_row_tile(int ld_out) { return ld_out >= 1024 ? 256 : 64; }
+
+static int transpose_impl(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum, void* stream,
+                          float* partials = nullptr, size_t partials_bytes = 0) {
     if (!in || !out || R <= 0 || C <= 0 || ld_in < C || ld_out < R) return set_error(CLIBD_EINVAL, "transpose: bad args");
     dim3 grid((C + 63) / 64, (ld_out + 63) / 64);
     if (grid.y > 65535u) return set_error(CLIBD_EINVAL, "transpose: too many rows for one launch");
     const bool fast = (C % 8 == 0) && (ld_in % 8 == 0) && (ld_out % 8 == 0) && aligned16(in) && aligned16(out);
     if (fast) {
-        if (ld_out >= 1024) {   // long row dimension (activations): 256-row tiles
-            dim3 grid4((C + 63) / 64, (ld_out + 255) / 256);
+        const int tile_rows = transpose_row_tile(ld_out);
+        const int nblk = (ld_out + tile_rows - 1) / tile_rows;
+        if (partials != nullptr && (partials_bytes < (size_t)nblk * C * sizeof(float) || ((uintptr_t)partials & 3)))
+            return set_error(CLIBD_EINVAL, "transpose_colsum: workspace too small (clibd_transpose_colsum_workspace_bytes)");
+        if (tile_rows == 256) {   // long row dimension (activations): 256-row tiles
+            dim3 grid4((C + 63) / 64, nblk);
             hipLaunchKernelGGL(transpose_colsum_bf16_kernel<4>, grid4, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, ld_in, R, C,
-                               (unsigned short*)out, ld_out, colsum);
+                               (unsigned short*)out, ld_out, colsum, partials);
         } else {
             hipLaunchKernelGGL(transpose_colsum_bf16_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, ld_in, R, C,
-                               (unsigned short*)out, ld_out, colsum);
+                               (unsigned short*)out, ld_out, colsum, partials);
         }
-        return check_launch("transpose_colsum_bf16");
+        if (int e = check_launch("transpose_colsum_bf16")) return e;
+        if (partials != nullptr && colsum != nullptr) {
+            hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)partials, nblk, C, colsum);
+            return check_launch("colsum_partials");
+        }
+        return CLIBD_OK;
     }
     if (colsum != nullptr) return set_error(CLIBD_EINVAL, "transpose_colsum: needs C, ld_in, ld_out multiples of 8 and 16-byte aligned bases");
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in,
@@ -479,6 +511,18 @@ extern "C" int clibd_transpose_bf16(const void* in, int ld_in, int R, int C, voi
 extern "C" int clibd_transpose_colsum_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum, void* stream) {
     if (!colsum) return set_error(CLIBD_EINVAL, "transpose_colsum: null colsum");
     return transpose_impl(in, ld_in, R, C, out, ld_out, colsum, stream);
+}
+
+extern "C" size_t clibd_transpose_colsum_workspace_bytes(int ld_out, int C) {
+    if (ld_out <= 0 || C <= 0) return 0;
+    const int tile_rows = transpose_row_tile(ld_out);
+    return (size_t)((ld_out + tile_rows - 1) / tile_rows) * (size_t)C * sizeof(float);
+}
+
+extern "C" int clibd_transpose_colsum_bf16_ws(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+    if (!colsum || !workspace) return set_error(CLIBD_EINVAL, "transpose_colsum_ws: null colsum / workspace");
+    return transpose_impl(in, ld_in, R, C, out, ld_out, colsum, stream, (float*)workspace, workspace_bytes);
 }
 
 extern "C" int clibd_cast_f32_to_bf16(const float* in, void* out, size_t n, void* stream) {

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void softce_rows_fwd_kernel(const float* __res
                                                               const int64_t* __restrict__ labels, int row0,
                                                               const float* __restrict__ scale_ptr,
                                                               float* __restrict__ lse, float* __restrict__ tsum_out,
-                                                              float* __restrict__ loss_sum) {
+                                                              float* __restrict__ row_loss) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Nx) return;
@@ -75,20 +75,36 @@ __global__ __launch_bounds__(256) void softce_rows_fwd_kernel(const float* __res
         const float l = mw + __logf(s);
         lse[row] = l;
         tsum_out[row] = ts;
-        atomicAdd(loss_sum, l * ts - td);
+        row_loss[row] = l * ts - td;   // summed in a fixed order by reduce_rows_add_kernel (round 6: no float atomics on the loss path)
     }
+}
+
+// out[0] += sum_i v[i], one workgroup, a fixed summation order (thread t takes i = t, t + 256, ...; then an LDS tree): the loss value and
+// the temperature gradient repeat bit for bit from run to run.  Rounds 1-5 accumulated both with one float atomic per row, whose order —
+// and with it the last bits of d(logit_scale), which AdamW turns into a different trajectory — changed from launch to launch.
+__global__ __launch_bounds__(256) void reduce_rows_add_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float part[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += part[0];
 }
 
 // g_ij = w * (tsum_i * exp(scale*R_ij - lse_i) - T_ij) with R = raw similarities;
 // scale * g_ij = hi + lo (bf16 each) is written as the row image [hi | hi | lo] of width 3 * Np (zero padded past N);
-// dscale += sum_ij g_ij * R_ij
+// row_ds[i] = sum_j g_ij * R_ij   (dscale += their fixed-order sum, reduce_rows_add_kernel)
 __global__ __launch_bounds__(256) void softce_rows_bwd_kernel(const float* __restrict__ S, int ldS, int Nx, int N,
                                                               const int64_t* __restrict__ labels, int row0,
                                                               const float* __restrict__ lse, const float* __restrict__ tsum,
                                                               float w, const float* __restrict__ wscale_ptr,
                                                               const float* __restrict__ scale_ptr,
                                                               unsigned short* __restrict__ G,
-                                                              int Np, float* __restrict__ dscale) {
+                                                              int Np, float* __restrict__ row_ds) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Nx) return;
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(256) void softce_rows_bwd_kernel(const float* __res
         gr[2 * Np + j] = f2bf(gs - bf2f(hi));
     }
     ds = wave_sum(ds);
-    if (lane == 0 && dscale != nullptr) atomicAdd(dscale, ds);
+    if (lane == 0) row_ds[row] = ds;
 }
 
 // out[c, k * Rp + r] = in[r, seg(k) * W + c] for the three column segments of a [R, 3W] image (seg(k) = 2 bits of `map` each),
@@ -149,6 +165,7 @@ static inline int pad16(int v) { return (v + 15) / 16 * 16; }
 struct LossWs {
     unsigned short *x3, *y3;   // [Nx,3D], [N,3D]
     float *S, *lse, *tsum;     // [Nx,N], [Nx], [Nx]
+    float *rows;               // [Nx]: per-row loss terms (forward), then per-row d(scale) terms (backward)
     unsigned short *G, *GT;    // [Nx,3Np] = [hi|hi|lo],  [N,3Nxp] = [hi^T|lo^T|hi^T]
     unsigned short *xT, *yT;   // [D,3Nxp] = [hi^T|hi^T|lo^T],  [D,3Np] = [hi^T|lo^T|hi^T]
     size_t total;
@@ -169,6 +186,7 @@ static LossWs carve(void* base, int Nx, int N, int D) {
     w.S = (float*)take((size_t)Nx * pad16(N) * 4);              // ld = N16, columns N.. ignored
     w.lse = (float*)take((size_t)Nx * 4);
     w.tsum = (float*)take((size_t)Nx * 4);
+    w.rows = (float*)take((size_t)Nx * 4);
     w.G = (unsigned short*)take((size_t)Nx * 3 * Np * 2);
     w.GT = (unsigned short*)take((size_t)N * 3 * Nxp * 2);
     w.xT = (unsigned short*)take((size_t)D * 3 * Nxp * 2);
@@ -214,8 +232,10 @@ extern "C" int clibd_softce_rows_fwd(const float* x, const float* y, const int64
     ep.split_k = 1;
     if (int e = clibd_gemm_bf16_nt(w.x3, 3 * D, w.y3, 3 * D, Nx, N16, 3 * D, &ep, stream)) return e;
     hipLaunchKernelGGL(softce_rows_fwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, N16, Nx, N, labels, row0, scale,
-                       w.lse, w.tsum, loss_sum);
-    return check_launch("softce_rows_fwd");
+                       w.lse, w.tsum, w.rows);
+    if (int e = check_launch("softce_rows_fwd")) return e;
+    hipLaunchKernelGGL(reduce_rows_add_kernel, dim3(1), dim3(256), 0, st, w.rows, Nx, loss_sum);
+    return check_launch("softce_rows_fwd (loss sum)");
 }
 
 // Must follow clibd_softce_rows_fwd on the same workspace (reuses its similarity matrix and row statistics).
@@ -231,8 +251,12 @@ extern "C" int clibd_softce_rows_bwd(const int64_t* labels, int Nx, int N, int D
     hipStream_t st = (hipStream_t)stream;
     const int Np = pad64(N), Nxp = pad64(Nx);   // multiples of 64: every K segment of the backward GEMMs is whole K-tiles
     hipLaunchKernelGGL(softce_rows_bwd_kernel, dim3((Nx + 3) / 4), dim3(256), 0, st, w.S, pad16(N), Nx, N, labels, row0, w.lse,
-                       w.tsum, weight, weight_scale, scale, w.G, Np, dscale);
+                       w.tsum, weight, weight_scale, scale, w.G, Np, w.rows);
     if (int e = check_launch("softce_rows_bwd")) return e;
+    if (dscale != nullptr) {
+        hipLaunchKernelGGL(reduce_rows_add_kernel, dim3(1), dim3(256), 0, st, w.rows, Nx, dscale);
+        if (int e = check_launch("softce_rows_bwd (dscale sum)")) return e;
+    }
     // operand images, zero padded along the contraction: segment order pairs hi.hi + hi.lo + lo.hi (see the file header)
     if (int e = launch_transpose3(w.G, Nx, Np, N, /*hi, lo, hi*/ 0 | (2 << 2) | (0 << 4), w.GT, Nxp, st)) return e;
     if (int e = launch_transpose3(w.x3, Nx, D, D, /*hi, hi, lo*/ 0 | (1 << 2) | (2 << 4), w.xT, Nxp, st)) return e;

@@ -315,7 +315,8 @@ def gemm_fp8_nt(
 
 def transpose_bf16(x: torch.Tensor, pad_to: int = 64, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[R,C] bf16 -> [C, R_pad] bf16 (zero padded along R to a multiple of `pad_to`).
-    colsum (fp32 [C], accumulates): column sums of x in the same pass (bias gradient beside the weight gradient's dy^T)."""
+    colsum (fp32 [C], accumulates): column sums of x in the same pass (bias gradient beside the weight gradient's dy^T), through a
+    partials workspace and a fixed-order second kernel (clibd_transpose_colsum_bf16_ws: no float atomics, bit-reproducible)."""
     _chk(x, BF16, "x", contiguous=False)
     ld = _rowmajor(x, "x")
     R, Cc = x.shape
@@ -325,7 +326,11 @@ def transpose_bf16(x: torch.Tensor, pad_to: int = 64, colsum: Optional[torch.Ten
         _chk(colsum, F32, "colsum")
         if colsum.numel() != Cc:
             raise ValueError("transpose_bf16: colsum must have C elements")
-        check(_lib.load().clibd_transpose_colsum_bf16(x.data_ptr(), ld, R, Cc, out.data_ptr(), Rp, colsum.data_ptr(), _stream()), "transpose_colsum_bf16")
+        lib = _lib.load()
+        need = int(lib.clibd_transpose_colsum_workspace_bytes(Rp, Cc))
+        ws = torch.empty(((need + 3) // 4,), dtype=F32, device=x.device)
+        check(lib.clibd_transpose_colsum_bf16_ws(x.data_ptr(), ld, R, Cc, out.data_ptr(), Rp, colsum.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()),
+              "transpose_colsum_bf16_ws")
     else:
         check(_lib.load().clibd_transpose_bf16(x.data_ptr(), ld, R, Cc, out.data_ptr(), Rp, _stream()), "transpose_bf16")
     return out

@@ -146,6 +146,12 @@ int clibd_transpose_bf16(const void* in, int ld_in, int R, int C, void* out, int
 /* same, and colsum[c] += sum_r in[r, c] (fp32, accumulates): the bias gradient of a linear layer rides along with the transpose
  * of dy that its weight gradient needs (full fine-tune mode).  Needs C, ld_in, ld_out multiples of 8, 16-byte aligned bases. */
 int clibd_transpose_colsum_bf16(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum, void* stream);
+/* ABI 5 — the same with a partials workspace (clibd_transpose_colsum_workspace_bytes(ld_out, C) bytes): every row block writes its
+ * column sums to the workspace and a second kernel adds them to colsum in row-block order, so the bias gradient repeats bit for bit from
+ * run to run (the form above issues one float atomic per block and column).  The trainable heads of the LoRA step take this form. */
+size_t clibd_transpose_colsum_workspace_bytes(int ld_out, int C);
+int clibd_transpose_colsum_bf16_ws(const void* in, int ld_in, int R, int C, void* out, int ld_out, float* colsum, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* fp32 -> bf16 cast of a contiguous buffer (weights are kept fp32 in the state dict, bf16 shadow copies
  * feed the MFMA path, as torch.autocast does per call in the reference, epoch/train_epoch.py:43). */
@@ -354,6 +360,8 @@ int clibd_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int
  * bwd must follow fwd on the same workspace:  g = weight * (*weight_scale) * dloss_sum/dS;
  *   dx [Nx,D] += scale * g·y,  dy [N,D] += scale * g^T·x  (fp32, ACCUMULATED),  *dscale += sum g∘(x·y^T).
  * D % 64 == 0; any Nx, N.
+ * ABI 5: *loss_sum and *dscale are accumulated from per-row terms (kept in the workspace) by a one-workgroup kernel in a fixed order —
+ * no float atomics on the loss path, so the loss value and d(logit_scale) repeat bit for bit from run to run.
  * ------------------------------------------------------------------------------------------------ */
 size_t clibd_softce_workspace_bytes(int Nx, int N, int D);
 int clibd_softce_rows_fwd(const float* x, const float* y, const int64_t* labels, int Nx, int N, int D, int row0,

@@ -38,7 +38,7 @@ def test_python_binding_covers_every_declared_symbol(lib):
     from clibd_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.load().clibd_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().clibd_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_binding_refuses_a_library_built_from_other_sources(lib, monkeypatch):

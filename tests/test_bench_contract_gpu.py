@@ -18,7 +18,7 @@ def test_bench_prints_exactly_one_json_line(forced):
     env = dict(os.environ, CLIBD_FORCE_COLLECTIVES=forced)
     # (the forced-collectives run skips the host-batch legs; the plain run keeps them: round 5's steady-state / uint8 legs are part of the line)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--per-gpu-batch", "32", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline"] + (["--no-h2d"] if forced == "1" else []), capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--no-cpu-baseline", "--configs4-batch", "32"] + (["--no-h2d"] if forced == "1" else []), capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     if forced == "1" and r.returncode != 0 and "init_process_group" in r.stderr:
         pytest.skip("one-rank RCCL process group unavailable on this box")
     assert r.returncode == 0, r.stderr[-3000:]
@@ -45,8 +45,25 @@ def test_bench_prints_exactly_one_json_line(forced):
     # round 5: the step at the reference's backward numerics rides in the same line; the host-fed legs are steady state + uint8 images
     rn = d["reference_numerics"]
     assert rn["value"] > 0 and rn["numerics"] == {"residual_grad": "fp32", "gelu_grad": "bf16", "attn_bwd": "2phase", "ln_fold": "off", "dgrad": "bf16"}
+    # round 6: BASELINE configs[4] rides in the default line as a side record — bf16 against the recommended fp8 mode at the same batch, with the
+    # fp8 FLOP share and the in-run gradient cosine (here at a toy batch; the driver's line carries per-GPU batch 1024)
+    c4 = d["configs4"]
+    assert "error" not in c4, c4
+    assert c4["per_gpu_batch"] == 32 and c4["bf16"]["ms_per_step"] > 0 and c4["fp8"]["ms_per_step"] > 0 and c4["speedup"] > 0
+    assert 0.05 < c4["fp8"]["fp8_flop_share"] < 0.6                         # the DNA tower's fc1 / fc2 forward + its MLP / projection dgrads
+    assert set(c4["gradient_cosine_vs_bf16"]) == {"train_batch", "fresh_batch"} and all(0.5 < v <= 1.0 for v in c4["gradient_cosine_vs_bf16"].values())
+    num2 = d["config"]["numerics"]
+    assert all(v["forward"] == "bf16" and v["dgrad"] == "bf16" for v in num2.values())   # the side record switched its mode off again
     if forced == "1":
         assert "collectives" in d
+        # round 6: a multi-GPU line is self-diagnosing — per-collective HIP-event times, every rank's own step time, the skew, the group
+        cm = d["collectives_ms"]
+        assert set(cm) == {"all_gather", "reduce_scatter", "all_reduce"} and all(v > 0 for v in cm.values()), cm
+        det = d["collectives_detail"]
+        assert det["all_gather"]["calls_per_step"] == 1 and det["reduce_scatter"]["calls_per_step"] == 1 and det["all_reduce"]["calls_per_step"] == 1
+        assert det["all_gather"]["bytes_per_step"] == (2 * 32 * 768 + 2 * 32) * 4     # packed: two modalities' embeddings + the labels as fp32 slots
+        assert len(d["per_rank_ms"]) == 1 and d["per_rank_ms"][0] > 0 and d["rank_skew_ms"] == 0.0
+        assert d["rccl_ranks"]["world_size"] == 1 and d["rccl_ranks"]["backend"] == "nccl"
     else:
         h = d["h2d_inclusive"]
         assert h["value"] > 0 and h["copy_at_top_of_step"]["value"] > 0 and h["uint8_images"]["value"] > 0
