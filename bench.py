@@ -541,6 +541,8 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
 
     def set_mode(on):
         model.enable_fp8_dgrad(towers="pooled", enabled=on)
+        if with_full:
+            return      # trainable base weights: the 8-bit dgrad only (the fp8 FORWARD needs frozen weights: its weight gradients would want bf16 GEMM inputs)
         if on:
             model.enable_fp8_forward(calibration_inputs=(batch4["image"], batch4["dna"], None), towers="pooled_ffn")
         else:
@@ -583,9 +585,11 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             "per_gpu_batch": b4, "global_batch": world * b4, "steps": nsteps,
             "bf16": {"ms_per_step": ms16, "value": world * b4 / (ms16 * 1e-3), "unit": "paired samples/s"},
             "fp8": {"ms_per_step": ms8, "value": world * b4 / (ms8 * 1e-3), "unit": "paired samples/s",
-                    "mode": "--fp8-forward pooled_ffn --dgrad fp8-pooled: e4m3 operands on fc1 / fc2 of the mean-pooled tower(s) (BarcodeBERT) forward, and on "
-                            "their MLP / projection activation-gradient GEMMs backward (per-row power-of-two scales); the ViT, attention, QKV and every "
-                            "weight gradient stay bf16",
+                    "mode": ("--full-finetune --dgrad fp8-pooled: e4m3 operands on the MLP / projection activation-gradient GEMMs of the mean-pooled tower(s) "
+                             "(BarcodeBERT), weights re-quantised every step; forward, attention, QKV and every weight gradient stay bf16" if with_full else
+                             "--fp8-forward pooled_ffn --dgrad fp8-pooled: e4m3 operands on fc1 / fc2 of the mean-pooled tower(s) (BarcodeBERT) forward, and on "
+                             "their MLP / projection activation-gradient GEMMs backward (per-row power-of-two scales); the ViT, attention, QKV and every "
+                             "weight gradient stay bf16"),
                     "fp8_flop_share": share},
             "speedup": ms16 / ms8,
             "gradient_cosine_vs_bf16": cos,
@@ -924,7 +928,7 @@ def main():
     # build recommends it: fp8 forward on the MLP pair of the mean-pooled towers ("pooled_ffn") + their 8-bit dgrad ("fp8-pooled"), against
     # the bf16 step at the same batch, with the gradient cosine of THIS model (as the steps above left it) on a fresh batch measured in-run.
     cfg4 = None
-    if not args.no_configs4 and not args.fp8_forward and args.dgrad in (None, "bf16") and not args.tri_modal and not args.full_finetune:
+    if not args.no_configs4 and not args.fp8_forward and args.dgrad in (None, "bf16") and not args.tri_modal:
         cfg4 = configs4_record(args, model, trainer, dev, world, rank, dist, timer)
 
     if rank == 0:

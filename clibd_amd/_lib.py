@@ -73,6 +73,8 @@ SIGNATURES = {
                                         C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clibd_layernorm_bwd_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "clibd_layernorm_bwd_fp8_pg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "clibd_layernorm_bwd_pg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, C.c_uint32, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clibd_attention_fwd_drop": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),
     "clibd_attention_bwd_drop": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, C.c_uint32, c_int, c_float, c_void_p]),

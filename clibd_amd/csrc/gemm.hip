@@ -316,7 +316,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, int M, int 
     for (const void* q : ptrs)
         if (q && !aligned16(q)) return set_error(CLIBD_EINVAL, "gemm: epilogue pointers must be 16-byte aligned");
 
-    GemmParams p;
+    GemmParams p{};
     p.A = (const unsigned short*)A; p.W = (const unsigned short*)W;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
     p.tiles_m = (M + BM - 1) / BM;
@@ -400,14 +400,20 @@ extern "C" int clibd_gemm_fp8_dgrad_nt(const void* A, int lda, const void* W, in
     if (ep->act == CLIBD_ACT_MUL_AUX_U8 && (!ep->aux_bf16 || ep->ld_aux % 16 || ep->ld_aux < N))
         return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: MUL_AUX_U8 needs aux (one byte per element) with ld_aux >= N, % 16");
     if (!ep->out_bf16 || !aligned16(ep->out_bf16) || (ep->aux_bf16 && !aligned16(ep->aux_bf16))) return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: out_bf16 / aux alignment");
-    if (ep->out_f32 || ep->out_pre_bf16 || ep->residual_f32 || ep->bias || ep->rank_u || ep->rank_v || ep->row_sums || ep->row_stats || ep->col_sum_w)
+    if (ep->out_f32 || ep->residual_f32 || ep->bias || ep->rank_u || ep->rank_v || ep->row_sums || ep->row_stats || ep->col_sum_w)
         return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: only out_bf16 [+ aux_bf16] epilogues");
+    // ABI 5: out_pre_bf16 on the MUL_AUX forms = a second, bf16 output of the de-scaled value (the weight gradient's operand under full fine-tune)
+    const bool mul_form = ep->act == CLIBD_ACT_MUL_AUX || ep->act == CLIBD_ACT_MUL_AUX_U8;
+    if (ep->out_pre_bf16 && (!mul_form || !a_row_dequant || !aligned16(ep->out_pre_bf16) || (ep->ld_pre & 7) || ep->ld_pre < N))
+        return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: out_pre_bf16 (bf16 copy) comes with MUL_AUX[_U8] and a_row_dequant only; ld_pre >= N, % 8; 16-byte aligned");
     GemmParams p{};
     p.A = (const unsigned short*)A; p.W = (const unsigned short*)W;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
     p.ep = *ep;
     if (p.ep.split_k < 1) p.ep.split_k = 1;
     p.fp8 = 1; p.col_scale = col_scale; p.out_fp8_scale = out_fp8_scale; p.a_row_dequant = a_row_dequant;
+    p.dual_bf16 = (unsigned short*)p.ep.out_pre_bf16; p.ld_dual = p.ep.ld_pre;
+    p.ep.out_pre_bf16 = nullptr; p.ep.ld_pre = 0;
     if (!gemm256_fp8_dgrad_launch(p, (hipStream_t)stream))
         return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: shape / epilogue not supported (M % 4, N % 256, K % 256, K >= 512; forms: -> bf16 | + aux_bf16 -> bf16 "
                                        "(both need a_row_dequant) | x aux (bf16 gelu' or its one-byte code) -> fp8 (needs out_fp8_scale > 0))");

@@ -70,7 +70,10 @@ __device__ __forceinline__ i32x8 cat_frag(bf16x8 lo, bf16x8 hi) {
 //   EPI_BF16 / EPI_ADD_AUX: v = acc * col_scale[n] * a_row_dequant[m]  [+ aux]  -> out_bf16
 //   EPI_MUL_AUX[_U8]      : out := e4m3(acc * col_scale[n] * aux[m,n] * out_fp8_scale) bytes (aux = gelu' as bf16, or as the one-byte code of §4) — the row scale of A passes THROUGH to the
 //                           output (the next dgrad's A operand, dequantised by the same a_row_dequant; 1 / out_fp8_scale rides in its col_scale).
-template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8, bool DG>
+//   DG == 2 (round 6, full fine-tune; MUL_AUX kinds): additionally p.dual_bf16[m,n] = bf16(acc * col_scale[n] * aux[m,n] * a_row_dequant[m]) — the
+//                           true d(fc1 out), which the bf16 weight gradient of fc1 contracts with its input.  The row factors are powers of two
+//                           (clibd_layernorm_bwd_fp8 writes 2^(e - 134)): a lane keeps the four exponents of a row group in ONE register.
+template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8, int DG>
 __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, int skew_ticks, long long* stamps) {
     static_assert(!DG || (FP8 && !LORA && !BIAS && !DIAG), "the 8-bit dgrad forms are fp8, bias-free and adapter-free");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -325,7 +328,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
     PROLOGUE_ISSUE();
     int allow_case = 0;
     const clibd_gemm_epilogue& ep = p.ep;
-    const int stores_case = (ep.out_pre_bf16 ? 1 : 0) + (ep.out_bf16 ? 1 : 0) + (ep.out_f32 ? 2 : 0);  // (16-B stores per row) / 2
+    const int stores_case = (ep.out_pre_bf16 ? 1 : 0) + (ep.out_bf16 ? 1 : 0) + (ep.out_f32 ? 2 : 0) + (DG == 2 ? 1 : 0);  // (16-B stores per row) / 2
 
     // diagnostic time stamps (only when a stamp buffer is installed: clibd_debug_set_gemm_stamps): [wg][tile_i][8]
     int tile_i = 0;
@@ -465,6 +468,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
 #undef EPI_TIED_WAIT
 #undef GLOAD128
         // ---- FP8: dequantise in place, before the (bf16, unscaled) rank update: acc[.., column e] *= col_scale[nb + e]
+        unsigned rdexp[2][2];   // DG == 2 only
         if constexpr (FP8) {
             const float* csp = p.col_scale + n0 + 128 * wm + 8 * erow;
             const f32x4 c0 = *(const f32x4*)csp, c1 = *(const f32x4*)(csp + 4);
@@ -476,6 +480,16 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[hm][t][q >> 1][q & 1] *= c;
                 }
+            if constexpr (DG == 2) {   // the four row exponents of every row group, packed (read here: no store of this tile is in the queue yet)
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f32x4 rd = *(const f32x4*)(p.a_row_dequant + min(mb + 32 * hn + 16 * n, p.M - 4));
+                        rdexp[hn][n] = ((__float_as_uint(rd[0]) >> 23) & 0xffu) | (((__float_as_uint(rd[1]) >> 23) & 0xffu) << 8) |
+                                       (((__float_as_uint(rd[2]) >> 23) & 0xffu) << 16) | (((__float_as_uint(rd[3]) >> 23) & 0xffu) << 24);
+                    }
+            }
             if constexpr (DG && KIND != EPI_MUL_AUX && KIND != EPI_MUL_AUX_U8) {   // the A operand's row scales (M % 4 == 0, host-checked: a group of 4 rows is all in or all out)
 #pragma unroll
                 for (int hn = 0; hn < 2; ++hn)
@@ -607,6 +621,12 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                             store_row8<EPI_GELU_SAVE>(ep, m, nb, v);
                         } else if (DG && (KIND == EPI_MUL_AUX || KIND == EPI_MUL_AUX_U8)) {
                             *(uint2*)((unsigned char*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8fp8(v, p.out_fp8_scale);
+                            if constexpr (DG == 2) {
+                                const float rdf = __uint_as_float(((rdexp[hn][n] >> (8 * r)) & 0xffu) << 23);
+                                float w8[8];
+                                _Pragma("unroll") for (int e = 0; e < 8; ++e) w8[e] = v[e] * rdf;
+                                *(uint4*)(p.dual_bf16 + (size_t)m * p.ld_dual + nb) = pack8bf(w8);
+                            }
                         } else if (epi_aux_kind(KIND)) {
                             *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
                         } else {
@@ -657,11 +677,11 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
 
 template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8>
 __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
-    gemm256_body<KIND, LORA, BIAS, DIAG, FP8, false>(p, ntiles, skew_ticks, stamps);
+    gemm256_body<KIND, LORA, BIAS, DIAG, FP8, 0>(p, ntiles, skew_ticks, stamps);
 }
-template <int KIND>
+template <int KIND, int DG = 1>
 __global__ __launch_bounds__(G256_THREADS) void gemm256_fp8_dgrad_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
-    gemm256_body<KIND, false, false, false, true, true>(p, ntiles, skew_ticks, stamps);
+    gemm256_body<KIND, false, false, false, true, DG>(p, ntiles, skew_ticks, stamps);
 }
 
 // The product library has no mutable state.  The s_memtime stamp buffer and the start-up skew knob of
@@ -775,19 +795,23 @@ bool gemm256_fp8_dgrad_launch(const GemmParams& p, hipStream_t stream) {
     if (p.ep.bias != nullptr || p.ep.rank_u != nullptr || p.ep.drop_thr16 > 0) return false;
     if ((unsigned long long)p.M * p.lda >= (1ull << 32) || (unsigned long long)p.N * p.ldw >= (1ull << 32)) return false;
     const int kind = epilogue_kind(p.ep);
+    const bool dual = p.dual_bf16 != nullptr;
     const void* fn = kind == EPI_BF16 ? (const void*)gemm256_fp8_dgrad_kernel<EPI_BF16>
-                   : kind == EPI_MUL_AUX ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX>
-                   : kind == EPI_MUL_AUX_U8 ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8>
+                   : kind == EPI_MUL_AUX ? (dual ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX, 2> : (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX>)
+                   : kind == EPI_MUL_AUX_U8 ? (dual ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8, 2> : (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8>)
                    : kind == EPI_ADD_AUX ? (const void*)gemm256_fp8_dgrad_kernel<EPI_ADD_AUX> : nullptr;
     if (fn == nullptr) return false;
     const bool mul = kind == EPI_MUL_AUX || kind == EPI_MUL_AUX_U8;
     if ((p.out_fp8_scale > 0.f) != mul) return false;
-    if (!mul && p.a_row_dequant == nullptr) return false;
+    if ((!mul || dual) && p.a_row_dequant == nullptr) return false;
+    if (dual && (!mul || (p.ld_dual & 7) || p.ld_dual < p.N || ((uintptr_t)p.dual_bf16 & 15))) return false;
     static const bool attr_ok = [] {
         bool ok = hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_ADD_AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         return ok;
     }();
     if (!attr_ok) return false;

@@ -27,6 +27,9 @@ struct GemmParams {
     float out_fp8_scale;
     // 8-bit dgrad forms (clibd_gemm_fp8_dgrad_nt): fp32 [M], the reciprocal of the per-row scale the producer of A applied
     const float* a_row_dequant;
+    // 8-bit dgrad under full fine-tune (round 6): the MUL_AUX forms also write the DE-SCALED value as bf16 (the weight gradient's operand)
+    unsigned short* dual_bf16;
+    int ld_dual;
 };
 
 // Inside a wave's 64 output columns, MFMA n-tile t (0..3), MFMA row i (0..15) carries tile-local column

@@ -198,7 +198,12 @@ __device__ __forceinline__ void layernorm_bwd_body(const unsigned short* __restr
     // ROWS adjacent rows per wave and iteration, and EVERY input of a row — the incoming residual gradient included — requested
     // before the first reduction: one memory round trip per iteration instead of two per row.
     for (int row0 = wave_in_grid * ROWS; row0 < M; row0 += nwaves * ROWS) {
-        f32x4 gy[ROWS][NCH], xh[ROWS][NCH], rs[ROWS][NCH];
+        // RS16 (the two-row e4m3 form: launched only with a bf16 incoming stream and no fp32 one): the residual gradient waits for the
+        // reductions as the packed bf16 pairs it arrived in — 2 registers per chunk instead of 4, 12 fewer at H = 768, which is what
+        // the 128-register bound of four waves per SIMD was short of (round 5: 4 spilled; round 6: none)
+        constexpr bool RS16 = F8 && ROWS == 2;
+        f32x4 gy[ROWS][NCH], xh[ROWS][NCH], rs[RS16 ? 1 : ROWS][RS16 ? 1 : NCH];
+        uint2 rsp[RS16 ? ROWS : 1][RS16 ? NCH : 1];
         float rstd[ROWS], m1[ROWS], m2[ROWS];
         bool live[ROWS];
 #pragma unroll
@@ -211,7 +216,8 @@ __device__ __forceinline__ void layernorm_bwd_body(const unsigned short* __restr
             for (int j = 0; j < NCH; ++j) {
                 gy[rr][j] = (f32x4){0, 0, 0, 0};
                 xh[rr][j] = (f32x4){0, 0, 0, 0};
-                rs[rr][j] = (f32x4){0, 0, 0, 0};
+                if constexpr (RS16) rsp[rr][j] = make_uint2(0u, 0u);
+                else rs[rr][j] = (f32x4){0, 0, 0, 0};
                 if (!act[j]) continue;
                 const int c = 4 * (lane + 64 * j);
                 f32x4 d;
@@ -223,11 +229,15 @@ __device__ __forceinline__ void layernorm_bwd_body(const unsigned short* __restr
                     d[2] = bf2f((unsigned short)(pk.y & 0xffff)); d[3] = bf2f((unsigned short)(pk.y >> 16));
                 }
                 const f32x4 xv = *(const f32x4*)(x + row * H + c);
-                if (dres != nullptr) rs[rr][j] = *(const f32x4*)(dres + row * H + c);
-                if (dres_b16 != nullptr) {
-                    const uint2 pk = *(const uint2*)(dres_b16 + row * H + c);
-                    rs[rr][j][0] += bf2f((unsigned short)(pk.x & 0xffff)); rs[rr][j][1] += bf2f((unsigned short)(pk.x >> 16));
-                    rs[rr][j][2] += bf2f((unsigned short)(pk.y & 0xffff)); rs[rr][j][3] += bf2f((unsigned short)(pk.y >> 16));
+                if constexpr (RS16) {
+                    if (dres_b16 != nullptr) rsp[rr][j] = *(const uint2*)(dres_b16 + row * H + c);
+                } else {
+                    if (dres != nullptr) rs[rr][j] = *(const f32x4*)(dres + row * H + c);
+                    if (dres_b16 != nullptr) {
+                        const uint2 pk = *(const uint2*)(dres_b16 + row * H + c);
+                        rs[rr][j][0] += bf2f((unsigned short)(pk.x & 0xffff)); rs[rr][j][1] += bf2f((unsigned short)(pk.x >> 16));
+                        rs[rr][j][2] += bf2f((unsigned short)(pk.y & 0xffff)); rs[rr][j][3] += bf2f((unsigned short)(pk.y >> 16));
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -259,9 +269,16 @@ __device__ __forceinline__ void layernorm_bwd_body(const unsigned short* __restr
             for (int j = 0; j < NCH; ++j) {
                 if (!act[j]) continue;
                 const int c = 4 * (lane + 64 * j);
-                f32x4 o;
+                f32x4 o, rv;
+                if constexpr (RS16) {
+                    const uint2 pk = rsp[rr][j];
+                    rv[0] = bf2f((unsigned short)(pk.x & 0xffff)); rv[1] = bf2f((unsigned short)(pk.x >> 16));
+                    rv[2] = bf2f((unsigned short)(pk.y & 0xffff)); rv[3] = bf2f((unsigned short)(pk.y >> 16));
+                } else {
+                    rv = rs[rr][j];
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rstd[rr] * (gy[rr][j][e] - m1[rr] - xh[rr][j][e] * m2[rr]) + rs[rr][j][e];
+                for (int e = 0; e < 4; ++e) o[e] = rstd[rr] * (gy[rr][j][e] - m1[rr] - xh[rr][j][e] * m2[rr]) + rv[e];
                 if (dx_f32 != nullptr) *(f32x4*)(dx_f32 + row * H + c) = o;
                 if (dx_res_b16 != nullptr) {
                     uint2 pk;
@@ -355,6 +372,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CLIBD_LNB8_
                                                nullptr, dres_b16, dx_res_b16, dx_fp8, row_dequant);
 }
 
+// 8-bit dgrad with TRAINABLE base weights (round 6, full fine-tune): the e4m3 rows for the dgrad, the bf16 copy for the weight gradient and
+// the LayerNorm parameter gradients, one row per wave and iteration (the PG form's grid and float atomics)
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_fp8_pg_kernel(const unsigned short* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+                                                                   const float* __restrict__ x, const float* __restrict__ stats,
+                                                                   const float* __restrict__ gamma, int M, int H, const float* __restrict__ dres,
+                                                                   float* __restrict__ dx_f32, unsigned short* __restrict__ dx_bf16, unsigned drop_seed,
+                                                                   int drop_thr16, float drop_scale, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   const unsigned short* __restrict__ dres_b16, unsigned short* __restrict__ dx_res_b16,
+                                                                   unsigned char* __restrict__ dx_fp8, float* __restrict__ row_dequant) {
+    layernorm_bwd_body<NCH, true, 1, true>(dy_bf16, dy_f32, x, stats, gamma, M, H, dres, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma,
+                                           dbeta, dres_b16, dx_res_b16, dx_fp8, row_dequant);
+}
+
 static inline int ln_grid(int M) {
     int blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;  // 8 blocks x 4 waves per CU: every wave slot of the chip, grid-stride over rows
@@ -435,7 +466,7 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const fl
     if (M <= 0 || H <= 0 || H % 64 != 0 || H > 1024) return set_error(CLIBD_EINVAL, "layernorm_bwd: H must be a multiple of 64, <= 1024");
     if (!dx_f32 && !dx_bf16 && !dx_res_b16 && !dx_fp8) return set_error(CLIBD_EINVAL, "layernorm_bwd: no output");
     if ((dx_fp8 == nullptr) != (row_dequant == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: dx_fp8 / row_dequant must come together");
-    if (dx_fp8 && (dgamma || ((uintptr_t)dx_fp8 & 3) || (H & 3))) return set_error(CLIBD_EINVAL, "layernorm_bwd: the fp8 output takes no parameter gradients; 4-byte alignment");
+    if (dx_fp8 && (((uintptr_t)dx_fp8 & 3) || (H & 3))) return set_error(CLIBD_EINVAL, "layernorm_bwd: the fp8 output needs 4-byte alignment");
     if (dres_f32 && dres_b16) return set_error(CLIBD_EINVAL, "layernorm_bwd: the residual gradient is either fp32 or bf16");
     if (((uintptr_t)dres_b16 & 7) || ((uintptr_t)dx_res_b16 & 7)) return set_error(CLIBD_EINVAL, "layernorm_bwd: alignment");
     if ((dgamma == nullptr) != (dbeta == nullptr)) return set_error(CLIBD_EINVAL, "layernorm_bwd: dgamma/dbeta must come together");
@@ -447,14 +478,18 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* dy_f32, const fl
     // rows per wave and iteration: two pay for the long launches of the bf16 residual-gradient form (M = 403 456: 716-722 -> 652 us;
     // at M = 50 432 one row is the faster form: 97 -> 85-87 us against 91); the fp32 / parameter-gradient forms are indifferent
     // and keep one (profiles/r03_exp_layernorm_rows.log)
-    // the e4m3-row form: two rows (bounded to four waves per SIMD: 128 registers, 4 spilled) for the pre-LN call (incoming bf16 stream: 569 ->
+    // the e4m3-row form: two rows (bounded to four waves per SIMD; round 6: the residual gradient held packed, 118 registers, none spilled) for the pre-LN call (incoming bf16 stream: 569 ->
     // 635 us at M = 403 456, the 11 / 10 byte ratio; one row: 683), one row for the post-LN call, whose masked copy it replaces (591 -> 599 us;
     // two rows: 561 -> 591): tools/bench_ln_bwd_fp8.py, profiles/r05_exp_ln_bwd_fp8_rows.log
     const bool two_rows = !pg && dy_f32 == nullptr && dres_f32 == nullptr && dx_f32 == nullptr && M >= 131072 && (dx_fp8 == nullptr || (nch <= 3 && dres_b16 != nullptr));
 #define LAUNCH_R(N, R)                                                                                         \
     do {                                                                                                       \
-        if (dx_fp8)                                                                                            \
-            hipLaunchKernelGGL((layernorm_bwd_fp8_kernel<N, R>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
+        if (dx_fp8 && pg)                                                                                      \
+            hipLaunchKernelGGL((layernorm_bwd_fp8_pg_kernel<N>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, \
+                               stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma, dbeta, \
+                               (const unsigned short*)dres_b16, (unsigned short*)dx_res_b16, (unsigned char*)dx_fp8, row_dequant); \
+        else if (dx_fp8)                                                                                       \
+            hipLaunchKernelGGL((layernorm_bwd_fp8_kernel<N, (N <= 3 ? R : 1)>), grid, block, 0, st, (const unsigned short*)dy_bf16, dy_f32, x, /* (two rows only up to H = 768: see two_rows) */ \
                                stats, gamma, M, H, dres_f32, dx_f32, (unsigned short*)dx_bf16, drop_seed, drop_thr16, drop_scale, \
                                (const unsigned short*)dres_b16, (unsigned short*)dx_res_b16, (unsigned char*)dx_fp8, row_dequant); \
         else if (pg)                                                                                            \
@@ -518,6 +553,15 @@ extern "C" int clibd_layernorm_bwd_fp8(const void* dy_bf16, const float* dy_f32,
     if (!dx_fp8 || !row_dequant) return set_error(CLIBD_EINVAL, "layernorm_bwd_fp8: null dx_fp8 / row_dequant");
     return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, nullptr,
                               nullptr, stream, dres_bf16, dx_res_bf16, dx_fp8, row_dequant);
+}
+
+extern "C" int clibd_layernorm_bwd_fp8_pg(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
+                                          int M, int H, const float* dres_f32, const void* dres_bf16, float* dx_f32, void* dx_res_bf16,
+                                          void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* dx_fp8, float* row_dequant,
+                                          float* dgamma, float* dbeta, void* stream) {
+    if (!dx_fp8 || !row_dequant || !dgamma || !dbeta) return set_error(CLIBD_EINVAL, "layernorm_bwd_fp8_pg: null dx_fp8 / row_dequant / dgamma / dbeta");
+    return layernorm_bwd_impl(dy_bf16, dy_f32, x, stats, gamma, M, H, dres_f32, dx_f32, dx_bf16, drop_seed, drop_thr16, drop_scale, dgamma,
+                              dbeta, stream, dres_bf16, dx_res_bf16, dx_fp8, row_dequant);
 }
 
 extern "C" int clibd_layernorm_bwd_any(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,

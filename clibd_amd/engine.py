@@ -68,8 +68,11 @@ class NotSupportedYet(NotImplementedError):
 #   input channel, on v_mfma_f32_16x16x128_f8f6f4.  The QKV dgrad (its operand feeds the adapters' bf16 weight gradients), attention and every
 #   weight gradient stay bf16.  Oracle study (full-size towers, tools/fp8_policy_study.py, profiles/r05_exp_fp8_dgrad_study.log): gradient cosine
 #   against the bf16 dgrad 0.9998 on the training batch / 0.9875 on a fresh one with BOTH towers on it (MI355X, trained weights: 0.9998-1.0000 on
-#   the mean-pooled towers, 0.987-0.9998 with the ViT's too; SimpleCLIP.enable_fp8_dgrad selects towers).  Frozen-base (LoRA) mode with the bf16
-#   residual-gradient stream only (gelu' as bf16 or as its one-byte code); a call whose token count is not a multiple of 4 takes the bf16 GEMMs.  DESIGN.md §3.1d.
+#   the mean-pooled towers, 0.987-0.9998 with the ViT's too; SimpleCLIP.enable_fp8_dgrad selects towers).  The bf16 residual-gradient stream only
+#   (gelu' as bf16 or as its one-byte code); a call whose token count is not a multiple of 4 takes the bf16 GEMMs.  Round 6: also with TRAINABLE base
+#   weights (disable_lora, the reference's final recipe) — the e4m3 weight images are re-made every step, the LayerNorm backward writes the e4m3 rows
+#   AND the bf16 copy the weight gradient contracts (clibd_layernorm_bwd_fp8_pg), the fc2 dgrad writes d(fc1 out) as e4m3 AND as bf16; every weight /
+#   bias / LayerNorm gradient is the bf16 path's arithmetic on those copies.  DESIGN.md §3.1d.
 NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"),
                         dgrad=("bf16", "fp8"))
 _NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD", ln_fold="CLIBD_LN_FOLD",
@@ -181,20 +184,24 @@ class TransformerStack:
         self.fp8 = None  # fp8-forward mode: [{site: activation scale}] per layer; see enable_fp8
         self._calib = None
         self.numerics = default_numerics()   # backward arithmetic switches (see NUMERICS_CHOICES above); set_numerics() changes them
+        self._c2, self._c2_age = None, 0   # dgrad = "fp8" under full fine-tune: the per-layer d(fc1 out) scales and how many refreshes old they are
         self.dgrad8_sites = ("mlp", "proj")   # dgrad = "fp8": which of the covered GEMMs take it ("mlp" = the fc2 -> fc1 pair, "proj"); tools/dgrad8_sites_study.py
+
+    DGRAD8_C2_EVERY = 64   # full fine-tune: refreshes (= steps) between two host reads of the fc2 images' l1 norms
 
     def set_numerics(self, **settings):
         before = (self.numerics.get("ln_fold"), self.numerics.get("dgrad"))
         self.numerics.update(check_numerics(settings))
         if (self.numerics.get("ln_fold"), self.numerics.get("dgrad")) != before:
             self._cache_key = None   # the fold's / the 8-bit dgrad's weight images are built with the frozen-weight images, only while the switch is on
+            self._c2 = None
 
     def _dgrad8_ok(self) -> bool:
         """dgrad = "fp8" is on and this stack can take it (see NUMERICS_CHOICES); raises for a configuration that cannot."""
         if self.numerics["dgrad"] != "fp8":
             return False
-        if self.full_mode() or self.numerics["residual_grad"] != "bf16":
-            raise NotSupportedYet("dgrad=fp8 needs frozen base weights (LoRA mode) and residual_grad=bf16")
+        if self.numerics["residual_grad"] != "bf16":
+            raise NotSupportedYet("dgrad=fp8 needs residual_grad=bf16")
         if self.H % 256 or self.H < 512 or self.FF % 256:
             raise NotSupportedYet("dgrad=fp8 needs hidden % 256 == 0, hidden >= 512, intermediate % 256 == 0")
         return True
@@ -303,14 +310,25 @@ class TransformerStack:
                 c.wo_t8 = c.cs_ot = c.w1_t8 = c.cs_1t = c.w2_t8 = c.cs_2t = c.c2 = None
                 self._cache.append(c)
             if self._dgrad8_ok():   # e4m3 images of the transposed weights, once per weight version
+                # Full fine-tune (round 6): the weights move every step, so the images are re-quantised every step with the bf16 images they
+                # are made from.  The per-layer constant c2 needs the l1 norm on the HOST (a kernel argument): it is re-derived every
+                # DGRAD8_C2_EVERY refreshes only, and carries one binade of headroom (c2 / 2) for the growth of l1max in between.
                 dev = self._cache[0].w2_t.device
-                l1 = torch.zeros((len(self._cache),), dtype=F32, device=dev)
+                full = self.full_mode()
+                reuse = full and self._c2 is not None and len(self._c2) == len(self._cache) and self._c2_age < self.DGRAD8_C2_EVERY
+                l1 = None if reuse else torch.zeros((len(self._cache),), dtype=F32, device=dev)
                 for i, c in enumerate(self._cache):
-                    c.w2_t8, c.cs_2t = ops.quantize_rows_fp8_bf16(c.w2_t, 1.0, l1[i:i + 1])
+                    c.w2_t8, c.cs_2t = ops.quantize_rows_fp8_bf16(c.w2_t, 1.0, None if reuse else l1[i:i + 1])
                     c.wo_t8, c.cs_ot = ops.quantize_rows_fp8_bf16(c.wo_t, 1.0)
-                for c, v in zip(self._cache, l1.cpu().tolist()):   # (one synchronisation per weight version)
+                if reuse:
+                    self._c2_age += 1
+                else:
                     # d(fc1 out) = e4m3(acc * col_scale * gelu' * c2): |acc * col_scale| <= 256 * l1max (scaled row maxima < 256), |gelu'| <= 1.13
-                    c.c2 = 2.0 ** math.floor(math.log2(448.0 / (256.0 * 1.13 * max(v, 1e-30))))
+                    self._c2 = [2.0 ** (math.floor(math.log2(448.0 / (256.0 * 1.13 * max(v, 1e-30)))) - (1 if full else 0))
+                                for v in l1.cpu().tolist()]   # (one synchronisation per weight version; per DGRAD8_C2_EVERY steps under full fine-tune)
+                    self._c2_age = 1
+                for c, c2 in zip(self._cache, self._c2):
+                    c.c2 = c2
                     c.w1_t8, c.cs_1t = ops.quantize_rows_fp8_bf16(c.w1_t, c.c2)   # its col_scale carries 1 / c2
         self._cache_key = key
 
@@ -614,7 +632,10 @@ class TransformerStack:
         r16 = self.numerics["residual_grad"] == "bf16"
         # 8-bit dgrad (numerics dgrad = "fp8"): every LayerNorm backward below also writes its output as e4m3 rows + one dequantisation
         # factor per row (new8), which the next dgrad GEMM takes as its A operand; dx8 = that pair for the incoming stream gradient
-        dg8 = (not full) and self._dgrad8_ok() and self._cache[0].w2_t8 is not None and M % 4 == 0 and M * FF < 2 ** 32   # (the fp8 kernel addresses operands with 32-bit byte offsets)
+        # Round 6: also with trainable base weights (full fine-tune, the reference's final recipe: `disable_lora: true`) — the dgrad takes the e4m3
+        # rows, every weight gradient stays bf16 (the LayerNorm backward then writes both copies, and the fc2 dgrad writes d(fc1 out) twice: e4m3
+        # for the fc1 dgrad, bf16 for the fc1 weight gradient).
+        dg8 = self._dgrad8_ok() and self._cache[0].w2_t8 is not None and M % 4 == 0 and M * FF < 2 ** 32   # (the fp8 kernel addresses operands with 32-bit byte offsets)
         new8 = lambda cols: (torch.empty((M, cols), dtype=torch.uint8, device=dev).view(ops.FP8), torch.empty((M,), dtype=F32, device=dev))
         f8kw = lambda pair: dict(dx_fp8=pair[0], row_dequant=pair[1])
         dx8 = None
@@ -663,7 +684,11 @@ class TransformerStack:
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 if dg8 and dx8 is not None:   # d(fc1 out) leaves as e4m3 with the rows' scales x c2; the fc1 dgrad divides both back out
                     dh8 = torch.empty((M, FF), dtype=torch.uint8, device=dev).view(ops.FP8)
-                    ops.gemm_fp8_dgrad_nt(dx8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"]), out_fp8=dh8, out_fp8_scale=c.c2)
+                    if full:   # ... and once more as bf16: the operand of fc1's weight gradient
+                        dh = new(FF, BF16) if dh is None else dh
+                    ops.gemm_fp8_dgrad_nt(dx8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"]), out_fp8=dh8, out_fp8_scale=c.c2,
+                                          a_row_dequant=dx8[1] if full else None, out_bf16_dual=dh if full else None)
+                    wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                     ops.gemm_fp8_dgrad_nt(dh8, c.w1_t8, c.cs_1t, a_row_dequant=dx8[1], out_bf16=dtmp)
                 else:
                     dh = new(FF, BF16) if dh is None else dh
@@ -705,6 +730,12 @@ class TransformerStack:
                 # copy the dense branch's dgrad consumes; the two dgrads that re-join the stream add the residual copy in their epilogue.
                 def ln_back(dy, xs, st, gam, drop_site, pgk):
                     res = new(H, BF16)
+                    if dg8 and full:   # the dgrad takes the e4m3 rows, the weight gradient the (masked) bf16 copy; parameter gradients ride along
+                        q8 = new8(H)
+                        dropped = drop_site is not None and drop_site.thr16 > 0
+                        masked = new(H, BF16) if dropped else None
+                        ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, dx_bf16=masked, drop=drop_site, **pgk, **f8kw(q8))
+                        return res, (masked if dropped else res), q8
                     if dg8:   # the dense branch's dgrad takes the e4m3 rows: the masked bf16 copy is not written at all
                         q8 = new8(H)
                         ops.layernorm_bwd(dy, xs, st, gam, dx_res_bf16=res, drop=drop_site, **f8kw(q8))
@@ -720,7 +751,12 @@ class TransformerStack:
                 dx1 = new(H, BF16)
                 if dg8:
                     dh8 = torch.empty((M, FF), dtype=torch.uint8, device=dev).view(ops.FP8)
-                    ops.gemm_fp8_dgrad_nt(ds2_8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"]), out_fp8=dh8, out_fp8_scale=c.c2)
+                    if full:
+                        wg(ds2_b, rec.get("a"), [L.fc2_w], [L.fc2_b])
+                        dh = new(FF, BF16) if dh is None else dh
+                    ops.gemm_fp8_dgrad_nt(ds2_8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"]), out_fp8=dh8, out_fp8_scale=c.c2,
+                                          a_row_dequant=ds2_8[1] if full else None, out_bf16_dual=dh if full else None)
+                    wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                     ops.gemm_fp8_dgrad_nt(dh8, c.w1_t8, c.cs_1t, a_row_dequant=ds2_8[1], aux=ds2_res, act=ops.ACT_ADD_AUX, out_bf16=dx1)
                 else:
                     dh = new(FF, BF16) if dh is None else dh
@@ -730,6 +766,7 @@ class TransformerStack:
                     ops.gemm_nt(dh, c.w1_t, act=ops.ACT_ADD_AUX, aux=ds2_res, out_bf16=dx1)
                 ds1_res, ds1_b, ds1_8 = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"], pg(L.ln1_w, L.ln1_b))
                 if dg8:
+                    wg(ds1_b, rec.get("o"), [L.proj_w], [L.proj_b])
                     ops.gemm_fp8_dgrad_nt(ds1_8[0], c.wo_t8, c.cs_ot, a_row_dequant=ds1_8[1], out_bf16=dtmp)
                 else:
                     wg(ds1_b, rec.get("o"), [L.proj_w], [L.proj_b])

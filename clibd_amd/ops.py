@@ -203,10 +203,11 @@ def quantize_rows_fp8_bf16(w: torch.Tensor, act_scale: float = 1.0, l1max: Optio
 
 def gemm_fp8_dgrad_nt(a: torch.Tensor, w: torch.Tensor, col_scale: torch.Tensor, *, a_row_dequant: Optional[torch.Tensor] = None,
                       aux: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_bf16: Optional[torch.Tensor] = None,
-                      out_fp8: Optional[torch.Tensor] = None, out_fp8_scale: float = 0.0) -> None:
+                      out_fp8: Optional[torch.Tensor] = None, out_fp8_scale: float = 0.0, out_bf16_dual: Optional[torch.Tensor] = None) -> None:
     """8-bit dgrad (clibd_gemm_fp8_dgrad_nt): a [M,K] e4m3 gradient rows with per-row scales (a_row_dequant [M] = 1 / scale), w [N,K] the
     transposed weight from quantize_rows_fp8_bf16.  Forms: act NONE -> out_bf16 | ACT_ADD_AUX + aux -> out_bf16 (both need a_row_dequant) |
-    ACT_MUL_AUX (bf16 aux) / ACT_MUL_AUX_U8 (one-byte gelu' codes) -> out_fp8 = e4m3(value * out_fp8_scale), which keeps a's row scales."""
+    ACT_MUL_AUX (bf16 aux) / ACT_MUL_AUX_U8 (one-byte gelu' codes) -> out_fp8 = e4m3(value * out_fp8_scale), which keeps a's row scales;
+    out_bf16_dual (full fine-tune; MUL_AUX forms, needs a_row_dequant): also the de-scaled value as bf16, the weight gradient's operand."""
     _chk(a, FP8, "a", contiguous=False)
     _chk(w, FP8, "w", contiguous=False)
     _chk(col_scale, F32, "col_scale")
@@ -234,7 +235,16 @@ def gemm_fp8_dgrad_nt(a: torch.Tensor, w: torch.Tensor, col_scale: torch.Tensor,
         if tuple(out_fp8.shape) != (M, N):
             raise ValueError("gemm_fp8_dgrad_nt: out_fp8 must be [M,N]")
         ep.out_bf16, ep.ld_out_bf16 = out_fp8.data_ptr(), _rowmajor(out_fp8, "out_fp8")
+        if out_bf16_dual is not None:
+            if a_row_dequant is None:
+                raise ValueError("gemm_fp8_dgrad_nt: out_bf16_dual needs a_row_dequant")
+            _chk(out_bf16_dual, BF16, "out_bf16_dual", contiguous=False)
+            if tuple(out_bf16_dual.shape) != (M, N):
+                raise ValueError("gemm_fp8_dgrad_nt: out_bf16_dual must be [M,N]")
+            ep.out_pre_bf16, ep.ld_pre = out_bf16_dual.data_ptr(), _rowmajor(out_bf16_dual, "out_bf16_dual")
     else:
+        if out_bf16_dual is not None:
+            raise ValueError("gemm_fp8_dgrad_nt: out_bf16_dual comes with the MUL_AUX forms only")
         if out_bf16 is None or out_fp8 is not None or a_row_dequant is None:
             raise ValueError("gemm_fp8_dgrad_nt: the bf16-output forms need out_bf16 and a_row_dequant")
         _chk(out_bf16, BF16, "out_bf16", contiguous=False)
@@ -390,8 +400,8 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, 
     _chk(x, F32, "x")
     M, H = x.shape
     if dx_fp8 is not None or row_dequant is not None:
-        if dx_fp8 is None or row_dequant is None or dgamma is not None or dbeta is not None:
-            raise ValueError("layernorm_bwd: dx_fp8 and row_dequant come together, without parameter gradients")
+        if dx_fp8 is None or row_dequant is None or (dgamma is None) != (dbeta is None):
+            raise ValueError("layernorm_bwd: dx_fp8 and row_dequant come together (and dgamma with dbeta)")
         _chk(dx_fp8, FP8, "dx_fp8")
         _chk(row_dequant, F32, "row_dequant")
         if tuple(dx_fp8.shape) != (M, H) or row_dequant.numel() != M:
@@ -408,6 +418,14 @@ def layernorm_bwd(dy, x, stats, gamma, *, dres=None, dx_f32=None, dx_bf16=None, 
         _chk(gamma, F32, "gamma")
         d = drop if (drop is not None and drop.thr16 > 0) else Drop(0.0, 0)
         dyb, dyf = (dy.data_ptr(), None) if dy.dtype == BF16 else (None, dy.data_ptr())
+        if dgamma is not None:   # full fine-tune under the 8-bit dgrad: the parameter gradients ride along (clibd_layernorm_bwd_fp8_pg)
+            _chk(dgamma, F32, "dgamma"); _chk(dbeta, F32, "dbeta")
+            if dgamma.numel() != H or dbeta.numel() != H:
+                raise ValueError("layernorm_bwd: dgamma / dbeta must have H elements")
+            check(_lib.load().clibd_layernorm_bwd_fp8_pg(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres), _p(dres_bf16), _p(dx_f32),
+                                                         _p(dx_res_bf16), _p(dx_bf16), d.seed, d.thr16, d.scale, dx_fp8.data_ptr(), row_dequant.data_ptr(),
+                                                         dgamma.data_ptr(), dbeta.data_ptr(), _stream()), "layernorm_bwd_fp8_pg")
+            return
         check(_lib.load().clibd_layernorm_bwd_fp8(dyb, dyf, x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), M, H, _p(dres), _p(dres_bf16), _p(dx_f32),
                                                   _p(dx_res_bf16), _p(dx_bf16), d.seed, d.thr16, d.scale, dx_fp8.data_ptr(), row_dequant.data_ptr(),
                                                   _stream()), "layernorm_bwd_fp8")

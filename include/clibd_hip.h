@@ -132,7 +132,11 @@ int clibd_quantize_rows_fp8(const float* w, int N, int K, float act_scale, void*
  *                             out_bf16 := e4m3(acc * col_scale[n] * aux[m,n] * out_fp8_scale) BYTES (ld_out_bf16 in bytes; a_row_dequant
  *                             unused): the dgrad through GELU writes the next dgrad's A operand, which keeps A's row scales; out_fp8_scale
  *                             (> 0 exactly for this form) is a power of two <= 448 / (256 * 1.13 * l1max) with l1max from
- *                             clibd_quantize_rows_fp8_bf16, so that no value saturates (|gelu'| <= 1.13, scaled row maxima < 256). */
+ *                             clibd_quantize_rows_fp8_bf16, so that no value saturates (|gelu'| <= 1.13, scaled row maxima < 256).
+ *                             ABI 5: with ep->out_pre_bf16 (+ ld_pre, and a_row_dequant, whose values must be powers of two as
+ *                             clibd_layernorm_bwd_fp8 writes them) the form ALSO writes out_pre_bf16[m,n] = bf16(acc * col_scale[n] * aux[m,n] *
+ *                             a_row_dequant[m]), the true d(fc1 out): under full fine-tuning (trainable base weights) the bf16 weight
+ *                             gradient of fc1 contracts it with the layer input while the next dgrad takes the e4m3 bytes. */
 int clibd_gemm_fp8_dgrad_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* col_scale,
                             const float* a_row_dequant, float out_fp8_scale, const clibd_gemm_epilogue* ep, void* stream);
 /* Operand image of a bf16 matrix (the transposed weight shadow of the bf16 dgrad) with a POWER-OF-TWO scale per row:
@@ -213,6 +217,13 @@ int clibd_layernorm_bwd_fp8(const void* dy_bf16, const float* dy_f32, const floa
                             int M, int H, const float* dres_f32, const void* dres_bf16, float* dx_f32, void* dx_res_bf16,
                             void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* dx_fp8, float* row_dequant,
                             void* stream);
+/* ABI 5 — the same with the LayerNorm parameter gradients (dgamma[c] += sum_rows dy xhat, dbeta[c] += sum_rows dy, as clibd_layernorm_bwd_pg):
+ * the 8-bit dgrad under full fine-tuning (model_config.disable_lora, the reference's final BIOSCAN-1M / 5M recipe): the dgrad takes the e4m3
+ * rows, the bf16 weight gradient takes dx_bf16, both written in this one pass. */
+int clibd_layernorm_bwd_fp8_pg(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,
+                               int M, int H, const float* dres_f32, const void* dres_bf16, float* dx_f32, void* dx_res_bf16,
+                               void* dx_bf16, uint32_t drop_seed, int drop_thr16, float drop_scale, void* dx_fp8, float* row_dequant,
+                               float* dgamma, float* dbeta, void* stream);
 /* full fine-tune mode: the same backward that also accumulates the parameter gradients it has the operands for
  *   dgamma[c] += sum_m dy[m,c] * xhat[m,c],  dbeta[c] += sum_m dy[m,c]     (fp32 [H], caller zeroes once per step). */
 int clibd_layernorm_bwd_pg(const void* dy_bf16, const float* dy_f32, const float* x, const float* stats, const float* gamma,

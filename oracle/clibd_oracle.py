@@ -87,7 +87,7 @@ def dgrad8(on: bool = True):
       d(fc1 out)     : e4m3(value * s_m * c2) with the s_m of the fc2 dgrad's operand rows and the per-layer constant
                        c2 = 2^floor(log2(448 / (256 * 1.13 * l1max))), l1max the largest row l1 norm of the quantised fc2^T image;
       weights        : bf16(W)^T with one power-of-two scale per row (input channel), e4m3; fp32 accumulation.
-    Frozen base weights only (the mode has no 8-bit weight gradient)."""
+    Weight gradients (full fine-tune) stay the bf16 network's: the mode has no 8-bit weight gradient."""
     global _DGRAD8
     old, _DGRAD8 = _DGRAD8, bool(on)
     try:
@@ -251,15 +251,17 @@ class _Dgrad8Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, y, site, pair_id):
-        if weight.requires_grad:
-            raise RuntimeError("dgrad8: the 8-bit dgrad needs frozen base weights")
-        ctx.save_for_backward(weight)
+        # Round 6: trainable base weights (full fine-tune) — the input gradient is still the 8-bit dgrad, the WEIGHT gradient the bf16 network's
+        # (bf16 operands dy^T . x, fp32 accumulation: the kernels hand the weight gradient a bf16 copy of the same fp32 gradient), and the
+        # per-layer constant c2 carries one binade of headroom (engine.TransformerStack.refresh re-derives it every 64 steps only).
+        ctx.trainable = bool(weight.requires_grad)
+        ctx.save_for_backward(weight, x if ctx.trainable else None)
         ctx.site, ctx.pair_id = site, pair_id
         return y.view_as(y)
 
     @staticmethod
     def backward(ctx, dy):
-        (weight,) = ctx.saved_tensors
+        weight, x = ctx.saved_tensors
         rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
         w8, sn = quantize_rows_e4m3_pow2(rb(weight.detach().float()).t().contiguous())   # [in, out]: rows = the dgrad's output channels
         g = dy.float()
@@ -269,9 +271,12 @@ class _Dgrad8Linear(torch.autograd.Function):
             sm = pow2_row_scale(g)
             if ctx.site == "fc2":
                 l1max = float((w8.abs().sum(dim=1, keepdim=True) / sn).max())
-                _DG8_ROWS[ctx.pair_id] = sm * (2.0 ** math.floor(math.log2(448.0 / (256.0 * 1.13 * max(l1max, 1e-30)))))
+                _DG8_ROWS[ctx.pair_id] = sm * (2.0 ** (math.floor(math.log2(448.0 / (256.0 * 1.13 * max(l1max, 1e-30)))) - (1 if ctx.trainable else 0)))
         dx = (e4m3(g * sm) @ (w8 / sn).t()) / sm
-        return dx, None, None, None, None
+        dw = None
+        if ctx.trainable:
+            dw = rb(g).reshape(-1, g.shape[-1]).t() @ rb(x.detach().float()).reshape(-1, x.shape[-1])
+        return dx, dw, None, None, None
 
 
 def olinear(x, weight, bias=None, round_out=True, fp8_scale=None, dgrad=None):

@@ -42,6 +42,12 @@ def test_gemm_fp8_dgrad_exact_on_integers(dev, M, N, K):
     ops.gemm_fp8_dgrad_nt(a8, w8, cs.to(dev), aux=aux.bfloat16().to(dev), act=ops.ACT_MUL_AUX, out_fp8=o8, out_fp8_scale=2.0 ** -6)
     want = (acc * cs.double() * aux.double() * 2.0 ** -6).float().clamp(-448, 448).to(FP8)
     assert torch.equal(o8.cpu().view(torch.uint8), want.view(torch.uint8))
+    # round 6 (full fine-tune): the same form writing ALSO the de-scaled value as bf16 — the operand of the bf16 weight gradient
+    o8b, dual = torch.empty_like(o8), torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_fp8_dgrad_nt(a8, w8, cs.to(dev), aux=aux.bfloat16().to(dev), act=ops.ACT_MUL_AUX, out_fp8=o8b, out_fp8_scale=2.0 ** -6,
+                          a_row_dequant=rd.to(dev), out_bf16_dual=dual)
+    assert torch.equal(o8b.cpu().view(torch.uint8), want.view(torch.uint8))
+    assert torch.equal(dual.cpu(), (acc * cs.double() * aux.double() * rd.double()[:, None]).float().bfloat16())
 
 
 def test_gemm_fp8_dgrad_rejects_unsupported(dev):
@@ -120,6 +126,59 @@ def test_layernorm_bwd_fp8_rows_carry_the_dropout_mask(dev):
     d8b, rdb = torch.empty_like(d8), torch.empty_like(rd)
     ops.layernorm_bwd(dy.to(dev), x.to(dev), stats.to(dev), gamma.to(dev), dx_res_bf16=torch.empty_like(res), drop=drop, dx_fp8=d8b, row_dequant=rdb)
     assert torch.equal(d8b.view(torch.uint8), d8.view(torch.uint8)) and torch.equal(rdb, rd)
+
+
+def test_layernorm_bwd_fp8_two_row_form_equals_the_one_row_form(dev):
+    """M >= 131 072 with a bf16 incoming stream and no fp32 output takes the two-rows-per-wave kernel (round 6: the residual gradient waits
+    for the reductions as packed bf16 pairs — 118 registers, none spilled); asking for dx_f32 as well selects the one-row kernel.  Same
+    arithmetic: e4m3 bytes, row scales and the bf16 copies must be identical, with and without a dropout mask."""
+    from clibd_amd import ops
+
+    M, H = 131072 + 320, 768
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(M, H, generator=g) * 1.5 + 0.3).to(dev)
+    dy = (torch.randn(M, H, generator=g) * 10.0 ** torch.randint(-5, 1, (M, 1), generator=g).float()).bfloat16().to(dev)
+    gamma = (1.0 + 0.2 * torch.randn(H, generator=g)).to(dev)
+    stats = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()], dim=1).contiguous()
+    dres = (torch.randn(M, H, generator=g).to(dev) * dy.float().abs().amax(dim=1, keepdim=True)).bfloat16()
+    for drop in (None, ops.Drop(0.1, 12345)):
+        outs = []
+        for one_row in (False, True):
+            d8 = torch.empty((M, H), dtype=torch.uint8, device=dev).view(FP8)
+            rd = torch.empty((M,), device=dev)
+            res, msk = torch.empty((M, H), dtype=torch.bfloat16, device=dev), torch.empty((M, H), dtype=torch.bfloat16, device=dev)
+            extra = dict(dx_f32=torch.empty((M, H), device=dev)) if one_row else {}
+            ops.layernorm_bwd(dy, x, stats, gamma, dres_bf16=dres, dx_res_bf16=res, dx_bf16=msk, drop=drop, dx_fp8=d8, row_dequant=rd, **extra)
+            outs.append((d8.view(torch.uint8).clone(), rd.clone(), res.clone(), msk.clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert float(outs[0][1].min()) > 0
+
+
+def test_layernorm_bwd_fp8_with_parameter_gradients(dev):
+    """clibd_layernorm_bwd_fp8_pg (8-bit dgrad under full fine-tune): the e4m3 rows / scales / bf16 copies of the plain fp8 call, bit for
+    bit, plus the parameter gradients of the bf16 path's call (float-atomic order only)."""
+    from clibd_amd import ops
+
+    M, H = 4256, 768
+    g = torch.Generator().manual_seed(78)
+    x = (torch.randn(M, H, generator=g) * 1.5 + 0.3).to(dev)
+    dy = (torch.randn(M, H, generator=g) * 1e-3).bfloat16().to(dev)
+    gamma = (1.0 + 0.2 * torch.randn(H, generator=g)).to(dev)
+    stats = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()], dim=1).contiguous()
+    drop = ops.Drop(0.1, 999)
+    new16 = lambda: torch.empty((M, H), dtype=torch.bfloat16, device=dev)
+    d8a, rda, resa, mska = torch.empty((M, H), dtype=torch.uint8, device=dev).view(FP8), torch.empty((M,), device=dev), new16(), new16()
+    ops.layernorm_bwd(dy, x, stats, gamma, dx_res_bf16=resa, dx_bf16=mska, drop=drop, dx_fp8=d8a, row_dequant=rda)
+    d8b, rdb, resb, mskb = torch.empty_like(d8a), torch.empty_like(rda), new16(), new16()
+    dg, db = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    ops.layernorm_bwd(dy, x, stats, gamma, dx_res_bf16=resb, dx_bf16=mskb, drop=drop, dx_fp8=d8b, row_dequant=rdb, dgamma=dg, dbeta=db)
+    assert torch.equal(d8a.view(torch.uint8), d8b.view(torch.uint8)) and torch.equal(rda, rdb) and torch.equal(resa, resb) and torch.equal(mska, mskb)
+    dg2, db2 = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    ops.layernorm_bwd(dy, x, stats, gamma, dx_res_bf16=new16(), dx_bf16=new16(), drop=drop, dgamma=dg2, dbeta=db2)
+    xhat = (x - stats[:, :1]) * stats[:, 1:]
+    assert torch.allclose(dg, (dy.float() * xhat).sum(0), rtol=1e-4, atol=1e-6) and torch.allclose(db, dy.float().sum(0), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(dg, dg2, rtol=1e-5, atol=1e-8) and torch.allclose(db, db2, rtol=1e-5, atol=1e-8)
 
 
 def test_quantize_rows_fp8_bf16_and_its_l1_bound(dev):
@@ -234,7 +293,87 @@ def test_dgrad8_image_tower_matches_oracle(dev):
     _compare(keep(res["fp8"][1]), keep(res["bf16"][1]), ora, "ViT width 768", 0.999, 0.995)
 
 
-def test_dgrad8_needs_the_bf16_stream_and_frozen_weights(dev):
+@pytest.mark.parametrize("train_mode", [False, True], ids=["eval", "train"])
+def test_dgrad8_full_finetune_dna_tower_matches_oracle(dev, train_mode):
+    """Round 6: the 8-bit dgrad with TRAINABLE base weights — `disable_lora: true`, the reference's final BIOSCAN-1M / 5M recipe
+    (config/model_config/for_bioscan_5m/final_experiments/image_dna_seed_42.yaml:20).  BarcodeBERT width (H = 768, FF = 3072, S = 133), 2 layers,
+    batch 16, every parameter trainable: the dgrad GEMMs take e4m3 rows, every weight / bias / LayerNorm gradient stays bf16.  Against the
+    oracle's restatement of the same rule (same masks in train mode) and against the HIP tower's bf16 dgrad, over ALL parameters."""
+    from oracle import clibd_oracle as O
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder
+
+    torch.manual_seed(33)
+    om = O.DNAEncoder(O.BertForMaskedLM(vocab=1027, hidden=768, layers=2, heads=12, ff=3072), 4, 768, lora_layer=[])
+    m = CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072)), r=4, num_classes=768, lora_layer=[])
+    m.load_state_dict(om.state_dict(), strict=True)
+    for mod in (om, m):
+        for p_ in mod.parameters():
+            p_.requires_grad_(True)
+    m = m.to(dev).train(train_mode)
+    assert m.tower().stack.full_mode()
+    B = 16
+    ids = synthetic_batch(B, torch.device("cpu"), seed=12, rank=0, with_text=False)["dna"]
+    cot = torch.randn(B, 768, generator=torch.Generator().manual_seed(7))
+    res, base = {}, 0
+    for mode in ("bf16", "fp8"):
+        m.tower().stack.set_numerics(dgrad=mode)
+        torch.manual_seed(98)
+        base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        torch.manual_seed(98)
+        y = m(ids.to(dev))
+        res[mode] = (y.detach().cpu(), _grads(m.named_parameters(), (y * cot.to(dev)).sum()))
+    m.tower().stack.set_numerics(dgrad="bf16")
+    assert torch.equal(res["bf16"][0], res["fp8"][0])
+    import contextlib
+    with O.precision("bf16"), (O.dropout(0.1, 0.1, base) if train_mode else contextlib.nullcontext()), O.dgrad8(True):
+        yo = om(ids)
+        ora = _grads(om.named_parameters(), (yo * cot).sum())
+    live = {n for n, v in ora.items() if float(v.abs().max()) > 0}
+    keep = lambda g: {n: v for n, v in g.items() if n in live and n in ora}
+    assert any("intermediate.dense.weight" in n for n in live) and any("attention.output.LayerNorm.weight" in n for n in live)
+    g8, g16, go = keep(res["fp8"][1]), keep(res["bf16"][1]), keep(ora)
+    names = sorted(go)
+    f8, f16, o8 = _flat(g8, names), _flat(g16, names), _flat(go, names)
+    big = max(float(go[n].double().norm()) for n in names)
+    per = {n: _cos(g8[n].flatten().double(), go[n].flatten().double()) for n in names if float(go[n].double().norm()) > 1e-2 * big}
+    worst = min(per, key=per.get)
+    print(f"[dgrad8 full fine-tune, {'train' if train_mode else 'eval'}] {len(names)} parameters: cosine vs oracle(dgrad8) {_cos(f8, o8):.5f} (rel {float((f8 - o8).norm() / o8.norm()):.2e}), "
+          f"worst of {len(per)} large parameters {per[worst]:.4f} ({worst}), vs the bf16 dgrad {_cos(f8, f16):.5f}")
+    assert not torch.equal(f8, f16), "the switch did not reach the kernels"
+    assert _cos(f8, o8) > 0.999 and per[worst] > 0.985 and _cos(f8, f16) > 0.995
+
+
+def test_dgrad8_full_finetune_trainer_step(dev):
+    """A Trainer step of a (small-depth, full-width) Image+DNA model with every weight trainable and the 8-bit dgrad on the mean-pooled
+    tower: runs, learns, base weights move, and the per-layer d(fc1 out) scale is re-derived on the host every DGRAD8_C2_EVERY steps only."""
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder, CLIBDImageEncoder, SimpleCLIP, VisionTransformer
+    from clibd_amd.train import Trainer
+
+    torch.manual_seed(35)
+    model = SimpleCLIP(CLIBDImageEncoder(VisionTransformer(embed_dim=768, depth=2, num_heads=12, num_classes=0), r=4, num_classes=768, lora_layer=[]),
+                       CLIBDDNAEncoder(BertForMaskedLM(BertConfigLite(vocab_size=1027, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072)), r=4, num_classes=768, lora_layer=[]), None)
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+    model = model.to(dev).train()
+    model.enable_fp8_dgrad(towers="pooled")
+    st = model.dna_encoder.tower().stack
+    st.DGRAD8_C2_EVERY = 3
+    tr = Trainer(model, lr=1e-4, world_size=1, rank=0, all_gather=True)
+    batch = synthetic_batch(16, dev, seed=13, rank=0, with_text=False)
+    w0 = model.dna_encoder.base_dna_encoder.bert.encoder.layer[0].intermediate.dense.weight.detach().clone()
+    losses, ages = [], []
+    for _ in range(5):
+        losses.append(float(tr.step(batch["image"], batch["dna"], None, batch["labels"])))
+        ages.append(st._c2_age)
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert ages == [1, 2, 3, 1, 2], ages
+    assert not torch.equal(w0, model.dna_encoder.base_dna_encoder.bert.encoder.layer[0].intermediate.dense.weight.detach())
+    assert model.numerics()["dna_encoder"]["dgrad"] == "fp8" and model.numerics()["image_encoder"]["dgrad"] == "bf16"
+
+
+def test_dgrad8_needs_the_bf16_stream_and_supported_widths(dev):
     from clibd_amd.engine import NotSupportedYet
     from clibd_amd.model import BertConfigLite, BertForMaskedLM, CLIBDDNAEncoder
 
