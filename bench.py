@@ -561,14 +561,38 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             timer.enabled = False
             r = timer.result()
             share = r["fp8_flop_share"] if r else None
-        # gradient fidelity of the model as it stands now, on the batch it just trained on and on one it has never seen
-        cos = {}
-        for name, bt in (("train_batch", batch4), ("fresh_batch", fresh4)):
-            g8 = grad_vector(bt)
-            set_mode(False)
-            g16 = grad_vector(bt)
-            set_mode(True)
-            cos[name] = float((g8 @ g16) / (g8.norm() * g16.norm()).clamp_min(1e-300))
+        def cosines():
+            out_ = {}
+            for name, bt in (("train_batch", batch4), ("fresh_batch", fresh4)):
+                set_mode(True)
+                g8 = grad_vector(bt)
+                set_mode(False)
+                g16 = grad_vector(bt)
+                out_[name] = float((g8 @ g16) / (g8.norm() * g16.norm()).clamp_min(1e-300))
+            return out_
+
+        def spread_of(bt):
+            """mean mutual cosine of the image embeddings of 256 pairs: ~1 at random init (every row nearly parallel), falls as the model learns"""
+            with torch.no_grad():
+                hi = model(bt["image"][:256], bt["dna"][:256], None)[0]
+            model.join_streams()
+            n_ = hi.shape[0]
+            return float(((hi @ hi.T).sum() - n_) / (n_ * (n_ - 1)))
+
+        # gradient fidelity (a) of the model exactly as the timed steps left it — at random init every embedding is nearly parallel to every
+        # other, the gradient is one common direction and ANY mode reads ~1.0 here — and (b) after a short spreading phase (bf16, `spread_steps`
+        # optimizer steps on the first 32 pairs at lr 1e-3, the protocol of tests/test_fp8_gpu.py::test_fp8_gradients_on_spread_embeddings), where
+        # the gradient separates samples and the fp8 operands' noise shows
+        set_mode(False)
+        cos_raw, spread_raw = cosines(), spread_of(fresh4)
+        spread_steps = 40
+        lr0 = trainer.optimizer.param_groups[0]["lr"]
+        trainer.optimizer.param_groups[0]["lr"] = 1e-3
+        nb = min(32, b4)
+        for _ in range(spread_steps):
+            trainer.step(batch4["image"][:nb], batch4["dna"][:nb], None, batch4["labels"][:nb])
+        trainer.optimizer.param_groups[0]["lr"] = lr0
+        cos, spread_after = cosines(), spread_of(fresh4)
         set_mode(False)
     except Exception as e:   # the side record must never take the headline line down with it
         try:
@@ -577,9 +601,10 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             pass
         return {"error": repr(e)}
     if world > 1:   # one number per job: the worst rank's cosine
-        c = torch.tensor([cos["train_batch"], cos["fresh_batch"]], dtype=torch.float64, device=dev)
+        c = torch.tensor([cos["train_batch"], cos["fresh_batch"], cos_raw["train_batch"], cos_raw["fresh_batch"]], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.MIN)
         cos = {"train_batch": float(c[0]), "fresh_batch": float(c[1])}
+        cos_raw = {"train_batch": float(c[2]), "fresh_batch": float(c[3])}
     return {"workload": f"BASELINE configs[4] per-rank shape: {world} GPU x {b4} pairs (global {world * b4}), Image+DNA, " +
                         ("FULL fine-tune" if with_full else "LoRA r=4") + ", train mode",
             "per_gpu_batch": b4, "global_batch": world * b4, "steps": nsteps,
@@ -592,10 +617,13 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
                              "weight gradient stay bf16"),
                     "fp8_flop_share": share},
             "speedup": ms16 / ms8,
-            "gradient_cosine_vs_bf16": cos,
-            "note": "same model, same process, measured after the headline passes (the model has taken those optimizer steps on the synthetic batch: "
-                    "random-init towers + trained adapters / heads — no pretrained weights exist on this box); gradient_cosine = cos(fp8-mode gradient, bf16 "
-                    "gradient) over ALL trainable tensors, same dropout masks, on the configs4 training batch and on a batch never seen; at N > 1 the minimum over ranks"}
+            "gradient_cosine_vs_bf16": dict(cos, spread_steps=spread_steps, image_embedding_mutual_cosine=spread_after,
+                                            as_timed={"train_batch": cos_raw["train_batch"], "fresh_batch": cos_raw["fresh_batch"], "image_embedding_mutual_cosine": spread_raw}),
+            "note": "same model, same process, measured after the headline passes; gradient_cosine = cos(fp8-mode gradient, bf16 gradient) over ALL trainable "
+                    "tensors, same dropout masks, on the configs4 training batch (its first 32 pairs are the spreading phase's) and on a batch never seen, at per-GPU "
+                    "batch; train_batch / fresh_batch = after `spread_steps` bf16 optimizer steps on 32 pairs (random-init towers + adapters / heads trained on "
+                    "synthetic pairs: no pretrained weights exist on this box), as_timed = the model exactly as the timed steps left it, where the embeddings are "
+                    "still nearly parallel (image_embedding_mutual_cosine ~ 1) and every mode reads ~1.0; at N > 1 the minimum over ranks"}
 
 
 _JSON_FD = None   # the process's original stdout, saved by main() before fd 1 is pointed at stderr

@@ -51,7 +51,10 @@ def test_bench_prints_exactly_one_json_line(forced):
     assert "error" not in c4, c4
     assert c4["per_gpu_batch"] == 32 and c4["bf16"]["ms_per_step"] > 0 and c4["fp8"]["ms_per_step"] > 0 and c4["speedup"] > 0
     assert 0.05 < c4["fp8"]["fp8_flop_share"] < 0.6                         # the DNA tower's fc1 / fc2 forward + its MLP / projection dgrads
-    assert set(c4["gradient_cosine_vs_bf16"]) == {"train_batch", "fresh_batch"} and all(0.5 < v <= 1.0 for v in c4["gradient_cosine_vs_bf16"].values())
+    gc = c4["gradient_cosine_vs_bf16"]
+    assert 0.5 < gc["train_batch"] <= 1.0 and 0.5 < gc["fresh_batch"] <= 1.0 and gc["spread_steps"] == 40
+    assert 0.5 < gc["as_timed"]["train_batch"] <= 1.0 and 0.5 < gc["as_timed"]["fresh_batch"] <= 1.0
+    assert gc["image_embedding_mutual_cosine"] < gc["as_timed"]["image_embedding_mutual_cosine"] <= 1.0    # the spreading phase spread the embeddings
     num2 = d["config"]["numerics"]
     assert all(v["forward"] == "bf16" and v["dgrad"] == "bf16" for v in num2.values())   # the side record switched its mode off again
     if forced == "1":

@@ -178,7 +178,7 @@ def test_layernorm_bwd_fp8_with_parameter_gradients(dev):
     ops.layernorm_bwd(dy, x, stats, gamma, dx_res_bf16=new16(), dx_bf16=new16(), drop=drop, dgamma=dg2, dbeta=db2)
     xhat = (x - stats[:, :1]) * stats[:, 1:]
     assert torch.allclose(dg, (dy.float() * xhat).sum(0), rtol=1e-4, atol=1e-6) and torch.allclose(db, dy.float().sum(0), rtol=1e-4, atol=1e-6)
-    assert torch.allclose(dg, dg2, rtol=1e-5, atol=1e-8) and torch.allclose(db, db2, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-6) and torch.allclose(db, db2, rtol=1e-4, atol=1e-6)   # (float-atomic order across 1024 blocks)
 
 
 def test_quantize_rows_fp8_bf16_and_its_l1_bound(dev):

@@ -144,7 +144,7 @@ def test_full_size_fp8_forward_close_to_bf16_path(dev):
     i8, d8, l8, g8 = run()
     model.enable_fp8_forward(enabled=False)
     i16b, d16b, l16b, _ = run()
-    assert torch.equal(i16, i16b) and torch.equal(d16, d16b) and abs(l16 - l16b) < 1e-5   # the mode switches off cleanly (the loss is an atomic sum)
+    assert torch.equal(i16, i16b) and torch.equal(d16, d16b) and l16 == l16b   # the mode switches off cleanly (round 6: the loss is a fixed-order sum)
     for a, b in ((i8, i16), (d8, d16)):
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() < 2e-2
@@ -269,7 +269,7 @@ def _named_grads(module, loss):
     return {n: (torch.zeros_like(p) if g is None else g).detach().float().cpu() for (n, p), g in zip(ps.items(), gs)}
 
 
-@pytest.mark.parametrize("calibrated,towers", [(False, "all"), (True, "pooled_mlp"), (True, "pooled_ffn+dgrad8")])
+@pytest.mark.parametrize("calibrated,towers", [(False, "all"), (True, "all"), (True, "pooled"), (True, "pooled_mlp"), (True, "pooled_ffn+dgrad8")])   # (round 6: the calibrated all-tower / all-site cases of round 4 are back)
 def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated, towers):
     """configs[4]'s mode against a CPU statement of the SAME arithmetic (oracle precision("fp8"): e4m3 operands with the towers'
     scales, fp32 accumulation, bf16 backward), ViT-B/16 + BERT-base at batch 16 — no longer HIP against HIP.
@@ -305,7 +305,7 @@ def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated, towers):
     model.enable_fp8_forward(calibration_inputs=(img, dna, None) if calibrated else None, towers=towers)
     _hand_scales_to_oracle(model, om)
     if calibrated:   # per-layer powers of two, not all equal to the static defaults
-        sc = (model.image_encoder if towers == "all" else model.dna_encoder).tower().stack.fp8   # (the calibrated all-tower and all-site "pooled" cases ran until round 5 — measured 0.9955 on the gradient; the two selections here cover calibration)
+        sc = (model.image_encoder if towers == "all" else model.dna_encoder).tower().stack.fp8
         assert any(d != sc[0] for d in sc[1:]) or sc[0] != dict(model.image_encoder.tower().stack.FP8_SCALES)
     with O.precision("fp8"), O.dgrad8(dg8):
         oi, od, _, osc, _ = om(batch["image"], batch["dna"], None)
@@ -366,6 +366,7 @@ def test_fp8_gradients_on_spread_embeddings(dev):
     B = 32
     batch = synthetic_batch(B, dev, seed=3, rank=0, with_text=False)
     fresh = synthetic_batch(B, dev, seed=4, rank=0, with_text=False)
+    fresh_more = [synthetic_batch(B, dev, seed=sd, rank=0, with_text=False) for sd in (5, 6)]   # round 6: two more unseen batches for the modes called training-grade
     tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True)
     crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
 
@@ -405,11 +406,28 @@ def test_fp8_gradients_on_spread_embeddings(dev):
                 out[(tag, name, key)] = (_cosv(torch.cat([g8[n].flatten() for n in names]), torch.cat([g16[n].flatten() for n in names])),
                                          spread, float((e8 - e16).abs().max()), float((d8 - d16).abs().max()))
         model.enable_fp8_forward(enabled=False)
+        # round 6: the modes this build calls TRAINING-GRADE, on two more batches the model has never seen
+        for j, bt in enumerate(fresh_more):
+            model.enable_fp8_forward(enabled=False)
+            _, _, g16 = run(bt)
+            names = sorted(g16)
+            cat = lambda g_: torch.cat([g_[n].flatten() for n in names])
+            for fwd, dg, key in (("pooled_ffn", None, "pooled_ffn"), ("pooled_ffn", "pooled", "pooled_ffn+dgrad8(pooled)"), (None, "pooled", "dgrad8(pooled)"), (None, "all", "dgrad8(all)")):
+                if fwd:
+                    model.enable_fp8_forward(calibration_inputs=(bt["image"], bt["dna"], None), towers=fwd)
+                else:
+                    model.enable_fp8_forward(enabled=False)
+                if dg:
+                    model.enable_fp8_dgrad(towers=dg)
+                _, _, g8 = run(bt)
+                model.enable_fp8_dgrad(enabled=False)
+                extra[(tag, f"fresh{j + 2}", key)] = _cosv(cat(g8), cat(g16))
+        model.enable_fp8_forward(enabled=False)
         sink = {id(p): p.grad for p in tr.optimizer.param_groups[0]["params"]}
         for tw in (model.image_encoder.tower(), model.dna_encoder.tower()):
             tw.grad_sink = sink
 
-    out, losses = {}, []
+    out, losses, extra = {}, [], {}
     for stage, nsteps in (("8 steps", 8), ("40 steps", 32)):
         losses += [float(tr.step(batch["image"], batch["dna"], None, batch["labels"])) for _ in range(nsteps)]
         compare(stage, out)
@@ -419,27 +437,37 @@ def test_fp8_gradients_on_spread_embeddings(dev):
     print(f"[fp8 gradients on trained weights] loss {losses[0]:.3f} -> {losses[7]:.3f} -> {losses[-1]:.3f}")
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
     assert out[("40 steps", "train", "all")][1] < 0.9               # the embeddings did spread
+    for k, c in extra.items():
+        print(f"[fp8 gradients on trained weights] after {k[0]}, {k[1]} batch, towers={k[2]}: cosine(fp8, bf16) {c:.4f}")
+    # Round 6: the 40 training steps are bit-reproducible now (no float atomics on the LoRA path: tests/test_determinism_gpu.py), so every figure
+    # below is the SAME number in every run of this test, and the gates are the claims again:
+    #   TRAINING-GRADE (cosine >= 0.98 against the bf16 gradient, both stages, training batch and every unseen batch):
+    #     pooled_ffn, pooled_ffn + dgrad8(pooled) [configs[4]'s recommended mode], dgrad8(pooled), dgrad8(all);
+    #   NOT training-grade, gated at what they measure (round 4's all-site "pooled": 0.977 on the unseen batch after 40 steps; with the ViT's
+    #   8-bit dgrad on top of an fp8 forward the two errors add: 0.978 / 0.966) — README / DESIGN call them so;
+    #   embedding-grade ("all", "pooled_mlp"): a broken-backward tripwire only.
+    # All of it on random-init towers whose adapters and heads were trained 40 steps on 32 synthetic pairs: no pretrained weights exist here.
+    TRAINING_GRADE = ("pooled_ffn", "pooled_ffn+dgrad8(pooled)", "dgrad8(pooled)", "dgrad8(all)")
     for k, (c, _, de, dd) in out.items():
-        # Gates are regression tripwires, set ~0.01 under the worst value of five MI355X runs (the 40 training steps are chaotic in the float-atomic
-        # order of the loss and temperature gradients: every run trains a slightly different model, and fresh-batch cosines scatter by +-0.005);
-        # the measured ranges — the claims — are in DESIGN.md §3.1d.  The round-4 gate "pooled >= 0.98" read 0.9799 in one of those runs.
         if k[2] == "dgrad8(pooled)":
-            assert c >= 0.999 and de == 0.0 and dd == 0.0, (k, c, de, dd)  # the 8-bit dgrad of the mean-pooled towers: free (measured 0.9998 - 1.0000)
+            assert c >= 0.999 and de == 0.0 and dd == 0.0, (k, c, de, dd)  # the 8-bit dgrad of the mean-pooled towers: free (0.9998 - 1.0000)
         elif k[2] == "dgrad8(all)":
-            assert c >= 0.975 and de == 0.0 and dd == 0.0, (k, c, de, dd)  # + the ViT's: measured 0.9866 - 0.9998
+            assert c >= 0.98 and de == 0.0 and dd == 0.0, (k, c, de, dd)   # + the ViT's: 0.9892 - 0.9990
         elif k[2] in ("pooled_ffn", "pooled_ffn+dgrad8(pooled)"):
-            assert c >= 0.975 and de == 0.0 and dd < 3e-2, (k, c, de, dd)  # fp8 forward on the pooled towers' MLP pair [+ their 8-bit dgrad]: measured 0.9843 - 0.9999
+            assert c >= 0.98 and de == 0.0 and dd < 3e-2, (k, c, de, dd)   # fp8 forward on the pooled towers' MLP pair [+ their 8-bit dgrad]: 0.9896 - 0.9997
         elif k[2] == "pooled_ffn+dgrad8(all)":
-            assert c >= 0.965 and de == 0.0 and dd < 3e-2, (k, c, de, dd)  # +15 %: measured 0.9780 - 0.9997
+            assert c >= 0.97 and de == 0.0 and dd < 3e-2, (k, c, de, dd)   # NOT training-grade: 0.9779 on the unseen batch after 40 steps
         elif k[2] in ("pooled", "pooled+dgrad8(pooled)"):
-            assert c >= 0.97 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # round 4's selection: measured 0.9799 - 0.9998
+            assert c >= 0.97 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # NOT training-grade (round 4's selection): 0.9770 on the unseen batch after 40 steps
         elif k[2] == "pooled+dgrad8(all)":
-            assert c >= 0.96 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # measured 0.9746 - 0.9996: the two errors add
+            assert c >= 0.96 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # NOT training-grade: 0.9655
         else:
             # embedding-grade: the floor round 3's measurement set.  "pooled_mlp" (round 5: + the ViT's MLP pair) sits between the two —
             # the oracle study (profiles/r05_exp_fp8_vit_sites.log) has it at 0.985 on the training batch and 0.82 on a fresh one after
             # 8 steps: it does NOT pass the 0.98 gate on both batches, so it is not the default and not called training-grade
             assert c > 0.15 and de < 0.3, (k, c, de)
+    for k, c in extra.items():
+        assert k[2] in TRAINING_GRADE and c >= 0.98, (k, c)
     for stage in ("8 steps", "40 steps"):
         for name in ("train", "fresh"):
             assert out[(stage, name, "pooled_mlp")][0] >= out[(stage, name, "all")][0] - 0.05, (stage, name, out[(stage, name, "pooled_mlp")][0], out[(stage, name, "all")][0])

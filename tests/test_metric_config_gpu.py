@@ -153,7 +153,13 @@ def test_b2048_train_mode_step_is_finite_and_bit_reproducible(dev, big):
 B5, N5 = 1024, 8192
 
 
-@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
+# fp8 modes of this size: None = bf16; "pooled_ffn" = configs[4]'s RECOMMENDED mode (fp8 forward on the MLP pair of the mean-pooled tower + its 8-bit
+# dgrad: training-grade, tests/test_fp8_gpu.py); "all" = every tower, every site (embedding-grade: every fp8 forward kernel at this size)
+FP8_MODES = [None, "pooled_ffn", "all"]
+FP8_IDS = ["bf16", "fp8-recommended", "fp8-all"]
+
+
+@pytest.mark.parametrize("fp8", FP8_MODES, ids=FP8_IDS)
 def test_b1024_rows_equal_chunked_and_block_loss_matches_cpu(dev, big, fp8):
     from clibd_amd import ops
     from clibd_amd.data import synthetic_batch
@@ -161,7 +167,7 @@ def test_b1024_rows_equal_chunked_and_block_loss_matches_cpu(dev, big, fp8):
     model, batch = big
     img, dna = batch["image"][:B5], batch["dna"][:B5]
     if fp8:
-        model.enable_fp8_forward(calibration_inputs=(img, dna, None), towers="all")   # per-layer scales from this batch; fixed for every call below (both towers: every fp8 kernel at this size)
+        model.enable_fp8_forward(calibration_inputs=(img, dna, None), towers=fp8)   # per-layer scales from this batch; fixed for every call below
     try:
         with torch.no_grad():
             i_full, d_full, _, scale, _ = model(img, dna, None)
@@ -206,16 +212,24 @@ def test_b1024_rows_equal_chunked_and_block_loss_matches_cpu(dev, big, fp8):
     assert 0.0 < got * (N5 // B5) < math.log(N5) + 1.0, got                 # a share of a loss that starts at ln 8192
 
 
-@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
+@pytest.mark.parametrize("fp8", FP8_MODES, ids=FP8_IDS)
 def test_b1024_training_step_runs_and_learns(dev, big, fp8):
     from clibd_amd.train import Trainer
 
     model, batch = big
     img, dna, labels = batch["image"][:B5], batch["dna"][:B5], batch["labels"][:B5]
+    if fp8:
+        model.enable_fp8_forward(calibration_inputs=(img, dna, None), towers=fp8)    # the selection the trainer's re-calibration keeps
+        if fp8 == "pooled_ffn":
+            model.enable_fp8_dgrad(towers="pooled")                                  # M = 136 192 DNA token rows: the two-row e4m3 LayerNorm backward, the 8-bit dgrad GEMMs
     tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True, fp8_recalibrate_every=2 if fp8 else 0)
     try:
         losses = [float(tr.step(img, dna, None, labels)) for _ in range(3)]
+        if fp8 == "pooled_ffn":
+            num = model.numerics()
+            assert num["dna_encoder"]["dgrad"] == "fp8" and num["dna_encoder"]["forward"].startswith("fp8") and num["image_encoder"]["forward"] == "bf16"
     finally:
+        model.enable_fp8_dgrad(enabled=False)
         model.enable_fp8_forward(enabled=False)
         for enc in (model.image_encoder, model.dna_encoder):
             enc.tower().grad_sink = None
