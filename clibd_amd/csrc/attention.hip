@@ -548,8 +548,13 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
 // workgroups per CU, and for four of them to fit the LDS each image is 144 rows instead of S_pad = 160 (IMG): rows 144 .. 159 of the
 // first image then alias rows 0 .. 15 of the second, those of the second a zeroed 2-KiB pad.  Every such row is only ever multiplied
 // by an exact zero (key tile 9 / query tile 9 are skipped: `last_live` is false, `nqt` = 9), so finite bytes are all that is needed.
+// -DCLIBD_ATT_BWD_LONG_WAVES=3 (A/B knob, round 6): the register cap of the long-sequence instantiations (NKT > 10: the ViT's 14 tiles, 222
+// registers at two waves per SIMD) forced to three waves per SIMD = 168 registers, whatever that spills (profiles/r06_exp_attention_vit_waves.log)
+#ifndef CLIBD_ATT_BWD_LONG_WAVES
+#define CLIBD_ATT_BWD_LONG_WAVES 2
+#endif
 template <int NKT, bool PAIR, bool MASK, bool DROP, int NW = ATT_WAVES, int IMG = 16 * NKT>
-__global__ __launch_bounds__(64 * NW, (NKT <= 10 ? 3 : 2)) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(64 * NW, (NKT <= 10 ? 3 : CLIBD_ATT_BWD_LONG_WAVES)) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                                     const unsigned short* __restrict__ dout, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ dqkv, float scale,

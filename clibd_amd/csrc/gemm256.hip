@@ -423,7 +423,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                         const uint2 c8 = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
                         in_aux[4 * n + r] = make_uint4(c8.x, c8.y, 0u, 0u);
                     } else if constexpr (epi_aux_kind(KIND)) {
-                        in_aux[4 * n + r] = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
+                        in_aux[4 * n + r] = load_aux16((const unsigned short*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
                     } else {
                         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)mc * ep.ld_res + nb);
                         in_res[4 * n + r][0] = rs[0];

@@ -404,6 +404,18 @@ __device__ __forceinline__ float row16_sum(float x) {
 }
 
 // the same with the loads
+// The 16-byte aux load of the MUL_AUX / ADD_AUX epilogues (gelu' / a residual-gradient stream: read ONCE, never again).  -DCLIBD_NT_AUX_LOADS
+// (A/B knob, round 6): with the non-temporal hint, so that the stream does not displace the A / W panels six workgroups share in L2.
+__device__ __forceinline__ uint4 load_aux16(const void* p) {
+    typedef unsigned aux_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef CLIBD_NT_AUX_LOADS
+    const aux_u32x4 v = __builtin_nontemporal_load((const aux_u32x4*)p);
+#else
+    const aux_u32x4 v = *(const aux_u32x4*)p;
+#endif
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <int KIND>
 __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
     uint4 ax = make_uint4(0u, 0u, 0u, 0u);
@@ -412,7 +424,7 @@ __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, 
         const uint2 c = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
         ax.x = c.x; ax.y = c.y;
     } else if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
-        ax = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        ax = load_aux16((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
     } else {
         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
         r0 = rs[0];

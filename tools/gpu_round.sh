@@ -17,7 +17,7 @@ if has bench; then
   echo "bench exit $?"; tail -c 1500 "$OUT/bench_b2048.json"
 fi
 if has b256; then
-  timeout 600 python bench.py --per-gpu-batch 256 --steps 20 --warmup 5 --no-cpu-baseline --gemm-breakdown > "$OUT/bench_b256.json" 2> "$OUT/bench_b256.err"
+  timeout 600 python bench.py --per-gpu-batch 256 --steps 20 --warmup 5 --no-cpu-baseline --no-configs4 --gemm-breakdown > "$OUT/bench_b256.json" 2> "$OUT/bench_b256.err"
   echo "b256 exit $?"; tail -c 600 "$OUT/bench_b256.json"
 fi
 if has tri; then
@@ -34,22 +34,22 @@ if has fp8; then   # BASELINE configs[4]: opt-in fp8-forward mode — the traini
 fi
 if has prof; then
   export CLIBD_TOWER_STREAMS=0
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_serial" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics > "$OUT/prof_serial.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_serial" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4 > "$OUT/prof_serial.log" 2>&1
   echo "prof serial exit $?"
   unset CLIBD_TOWER_STREAMS
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_streams" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics > "$OUT/prof_streams.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_streams" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4 > "$OUT/prof_streams.log" 2>&1
   echo "prof streams exit $?"
-  python tools/stamp_stats.py "$OUT/prof_serial" "$OUT/kernel_stats_serial.csv" "CLIBD_TOWER_STREAMS=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics"
-  python tools/stamp_stats.py "$OUT/prof_streams" "$OUT/kernel_stats_two_streams.csv" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics"
+  python tools/stamp_stats.py "$OUT/prof_serial" "$OUT/kernel_stats_serial.csv" "CLIBD_TOWER_STREAMS=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4"
+  python tools/stamp_stats.py "$OUT/prof_streams" "$OUT/kernel_stats_two_streams.csv" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4"
   find "$OUT" -name "*kernel_trace.csv" -size +20M -delete   # keep the stats, drop oversized raw traces
   find "$OUT" -name "*.db" -delete
 fi
 if has pmc; then
   B=${PMC_BATCH:-2048}
-  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics > "$OUT/pmc_fetch.log" 2>&1
-  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics > "$OUT/pmc_write.log" 2>&1
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4 > "$OUT/pmc_fetch.log" 2>&1
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4 > "$OUT/pmc_write.log" 2>&1
   python tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic_b$B.json" $B > "$OUT/pmc_traffic.txt" 2>&1
-  timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics > "$OUT/pmc_mfma.log" 2>&1
+  timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4 > "$OUT/pmc_mfma.log" 2>&1
   python tools/pmc_mfma.py "$OUT/pmc_mfma" "$OUT/pmc_mfma_b$B.json" > "$OUT/pmc_mfma.txt" 2>&1
   find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
   find "$OUT" -name "*.db" -delete
@@ -57,9 +57,9 @@ if has pmc; then
 fi
 if has dram; then   # DRAM share of the L2's memory-side requests per kernel (tools/pmc_dram.py)
   B=${PMC_BATCH:-2048}
-  timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d "$OUT/pmc_dram_rd" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics > "$OUT/pmc_dram_rd.log" 2>&1
+  timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d "$OUT/pmc_dram_rd" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4 > "$OUT/pmc_dram_rd.log" 2>&1
   echo "dram rd exit $?"
-  timeout 900 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d "$OUT/pmc_dram_wr" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics > "$OUT/pmc_dram_wr.log" 2>&1
+  timeout 900 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d "$OUT/pmc_dram_wr" -- python3 bench.py --per-gpu-batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timing --no-h2d --no-ref-numerics --no-configs4 > "$OUT/pmc_dram_wr.log" 2>&1
   echo "dram wr exit $?"
   python tools/pmc_dram.py "$OUT/pmc_dram_rd" "$OUT/pmc_dram_wr" "$OUT/pmc_dram_b$B.json" $B > "$OUT/pmc_dram.txt" 2>&1
   find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
