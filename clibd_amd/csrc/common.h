@@ -218,6 +218,48 @@ __device__ __forceinline__ void geluq_unpack4(unsigned w, float out[4]) {       
     out[3] = fmaf((float)(w >> 24), GELUQ_STEP, GELUQ_LO);
 }
 
+// gelu' as TWELVE bits, "e4m7" (round 6): sign, a 4-bit exponent and bf16's 7 mantissa bits — the bf16 value itself with the exponent re-biased
+// to the sixteen binades gelu' lives in.  e4 = 0 is zero; e4 = 1 .. 15 are the binades [2^-14, 2^-13) .. [1, 2).  Every bf16 value of
+// magnitude in [2^-14, 2) — gelu' lies in [-0.129, 1.129] — survives BIT FOR BIT; smaller magnitudes (|gelu'| < 6.1e-5: pre-activations
+// below about -4.55) become a signed zero.  So this is the bf16 form at 1.5 bytes per element, not a coarser code: the decoded operand of
+// the fc2 dgrad differs from the bf16 form's only where |gelu'| < 2^-14.  Eight adjacent columns = 12 bytes = three dwords per lane and row.
+__device__ __forceinline__ unsigned gelu12_code_bits(unsigned b) {   // b: the bf16 bit pattern of gelu'
+    const unsigned t = b & 0x7fffu;
+    unsigned u = t >= (113u << 7) ? t - (112u << 7) : 0u;
+    u = u > 0x7ffu ? 0x7ffu : u;                       // (|g| >= 2 cannot happen for gelu': saturate instead of wrapping)
+    return ((b >> 4) & 0x800u) | u;
+}
+__device__ __forceinline__ float gelu12_val(unsigned c) {
+    const unsigned u = c & 0x7ffu;
+    const unsigned t = u ? u + (112u << 7) : 0u;
+    return __uint_as_float((((c & 0x800u) << 4) | t) << 16);
+}
+struct __attribute__((packed, aligned(4))) gelu12_row8 { unsigned w0, w1, w2; };
+__device__ __forceinline__ gelu12_row8 gelu12_pack8(const float* g) {
+    unsigned c[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const unsigned pk = pack2bf(g[e], g[e + 1]);       // the bf16 form's rounding, one v_cvt_pk per pair
+        c[e] = gelu12_code_bits(pk & 0xffffu);
+        c[e + 1] = gelu12_code_bits(pk >> 16);
+    }
+    gelu12_row8 r;
+    r.w0 = c[0] | (c[1] << 12) | (c[2] << 24);
+    r.w1 = (c[2] >> 8) | (c[3] << 4) | (c[4] << 16) | (c[5] << 28);
+    r.w2 = (c[5] >> 4) | (c[6] << 8) | (c[7] << 20);
+    return r;
+}
+__device__ __forceinline__ void gelu12_unpack8(unsigned w0, unsigned w1, unsigned w2, float* g) {
+    g[0] = gelu12_val(w0 & 0xfffu);
+    g[1] = gelu12_val((w0 >> 12) & 0xfffu);
+    g[2] = gelu12_val((w0 >> 24) | ((w1 & 0xfu) << 8));
+    g[3] = gelu12_val((w1 >> 4) & 0xfffu);
+    g[4] = gelu12_val((w1 >> 16) & 0xfffu);
+    g[5] = gelu12_val((w1 >> 28) | ((w2 & 0xffu) << 4));
+    g[6] = gelu12_val((w2 >> 8) & 0xfffu);
+    g[7] = gelu12_val(w2 >> 20);
+}
+
 // d/dx gelu(x) = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));

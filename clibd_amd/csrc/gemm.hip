@@ -299,9 +299,15 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, int M, int 
         return set_error(CLIBD_EINVAL, "gemm: GELU_GRAD / MUL_AUX / ADD_AUX need aux_bf16 with ld_aux >= N, % 8");
     if (ep->act == CLIBD_ACT_MUL_AUX_U8 && (!ep->aux_bf16 || ep->ld_aux % 16 || ep->ld_aux < N))
         return set_error(CLIBD_EINVAL, "gemm: MUL_AUX_U8 needs aux (one byte per element) with ld_aux >= N, % 16");
+    const bool e12 = ep->act == CLIBD_ACT_GELU_SAVE_GRAD_E12 || ep->act == CLIBD_ACT_MUL_AUX_E12;
+    if (e12 && (N % 8 != 0)) return set_error(CLIBD_EINVAL, "gemm: the e4m7 gelu' forms need N % 8 == 0");
+    if (ep->act == CLIBD_ACT_MUL_AUX_E12 && (!ep->aux_bf16 || ep->ld_aux % 4 || ep->ld_aux < 3 * (N / 2)))
+        return set_error(CLIBD_EINVAL, "gemm: MUL_AUX_E12 needs aux (1.5 bytes per element) with ld_aux >= 3N/2 bytes, % 4");
+    if (ep->act == CLIBD_ACT_GELU_SAVE_GRAD_E12 && (!ep->out_pre_bf16 || ep->ld_pre % 4 || ep->ld_pre < 3 * (N / 2)))
+        return set_error(CLIBD_EINVAL, "gemm: GELU_SAVE_GRAD_E12 needs out_pre (1.5 bytes per element) with ld_pre >= 3N/2 bytes, % 4");
     if ((ep->act == CLIBD_ACT_GELU_SAVE_GRAD || ep->act == CLIBD_ACT_GELU_SAVE_GRAD_U8) && !ep->out_pre_bf16)
         return set_error(CLIBD_EINVAL, "gemm: GELU_SAVE_GRAD needs out_pre_bf16");
-    if (ep->act < 0 || ep->act > CLIBD_ACT_MUL_AUX_U8) return set_error(CLIBD_EINVAL, "gemm: bad act");
+    if (ep->act < 0 || ep->act > CLIBD_ACT_MUL_AUX_E12) return set_error(CLIBD_EINVAL, "gemm: bad act");
     if (ep->residual_f32 && (ep->ld_res % 4 || ep->ld_res < N)) return set_error(CLIBD_EINVAL, "gemm: ld_res");
     if (ep->out_pre_bf16 && (ep->ld_pre % (ep->act == CLIBD_ACT_GELU_SAVE_GRAD_U8 ? 16 : 8) || ep->ld_pre < N)) return set_error(CLIBD_EINVAL, "gemm: ld_pre");
     if (ep->out_bf16 && (ep->ld_out_bf16 % 8 || ep->ld_out_bf16 < N)) return set_error(CLIBD_EINVAL, "gemm: ld_out_bf16");
@@ -403,7 +409,9 @@ extern "C" int clibd_gemm_fp8_dgrad_nt(const void* A, int lda, const void* W, in
     if (ep->out_f32 || ep->residual_f32 || ep->bias || ep->rank_u || ep->rank_v || ep->row_sums || ep->row_stats || ep->col_sum_w)
         return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: only out_bf16 [+ aux_bf16] epilogues");
     // ABI 5: out_pre_bf16 on the MUL_AUX forms = a second, bf16 output of the de-scaled value (the weight gradient's operand under full fine-tune)
-    const bool mul_form = ep->act == CLIBD_ACT_MUL_AUX || ep->act == CLIBD_ACT_MUL_AUX_U8;
+    const bool mul_form = ep->act == CLIBD_ACT_MUL_AUX || ep->act == CLIBD_ACT_MUL_AUX_U8 || ep->act == CLIBD_ACT_MUL_AUX_E12;
+    if (ep->act == CLIBD_ACT_MUL_AUX_E12 && (!ep->aux_bf16 || ep->ld_aux % 4 || ep->ld_aux < 3 * (N / 2)))
+        return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: MUL_AUX_E12 needs aux (1.5 bytes per element) with ld_aux >= 3N/2 bytes, % 4");
     if (ep->out_pre_bf16 && (!mul_form || !a_row_dequant || !aligned16(ep->out_pre_bf16) || (ep->ld_pre & 7) || ep->ld_pre < N))
         return set_error(CLIBD_EINVAL, "gemm_fp8_dgrad: out_pre_bf16 (bf16 copy) comes with MUL_AUX[_U8] and a_row_dequant only; ld_pre >= N, % 8; 16-byte aligned");
     GemmParams p{};

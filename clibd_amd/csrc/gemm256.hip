@@ -381,8 +381,20 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
         PHASE_TAIL(2, 6); PHASE_TAIL(3, 4); PHASE_TAIL(4, 2); PHASE_TAIL(5, 0); PHASE_TAIL(6, 0); PHASE_TAIL(7, 0);
         if (wm == 0) BARRIER();  // group 0 matches group 1's extra barrier; every LDS read of this tile is complete
         // FP8_MFMA_DRAIN: the fp8 MFMAs are inline asm, so hipcc inserts no wait states between the last of them (8 passes) and the
-        // first VALU read of an accumulator below (dequantisation): 18 are required, give 32
-        if constexpr (FP8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        // first VALU read of an accumulator below: 18 are required, give 32.  The drain is TIED to the accumulators: every
+        // reader after the K loop — the dequantisation by col_scale, the DG row scales, the rank update, the epilogue — takes acc[] from
+        // these statements' outputs, so no refactor of what is loaded when can hoist a read above them (an untied asm with a memory clobber
+        // ordered the reads only through the col_scale load).  Two statements: an asm takes at most 30 operands, the accumulators are 32.
+        if constexpr (FP8) {
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm)
+                asm volatile("s_nop 15\n\ts_nop 15"
+                             : "+v"(acc[hm][0][0][0]), "+v"(acc[hm][0][0][1]), "+v"(acc[hm][0][1][0]), "+v"(acc[hm][0][1][1]),
+                               "+v"(acc[hm][1][0][0]), "+v"(acc[hm][1][0][1]), "+v"(acc[hm][1][1][0]), "+v"(acc[hm][1][1][1]),
+                               "+v"(acc[hm][2][0][0]), "+v"(acc[hm][2][0][1]), "+v"(acc[hm][2][1][0]), "+v"(acc[hm][2][1][1]),
+                               "+v"(acc[hm][3][0][0]), "+v"(acc[hm][3][0][1]), "+v"(acc[hm][3][1][0]), "+v"(acc[hm][3][1][1])
+                             :: "memory");
+        }
         STAMP(4);
         // lane coordinates made opaque per tile: everything the epilogue derives from them (16 row offsets x several
         // leading dimensions) is rebuilt here instead of being hoisted out of the persistent loop into spilled registers
@@ -422,6 +434,8 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                     } else if constexpr (KIND == EPI_MUL_AUX_U8) {
                         const uint2 c8 = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
                         in_aux[4 * n + r] = make_uint4(c8.x, c8.y, 0u, 0u);
+                    } else if constexpr (KIND == EPI_MUL_AUX_12) {
+                        in_aux[4 * n + r] = load_aux12((const unsigned char*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + (nb >> 1) * 3);
                     } else if constexpr (epi_aux_kind(KIND)) {
                         in_aux[4 * n + r] = load_aux16((const unsigned short*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
                     } else {
@@ -490,7 +504,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                                        (((__float_as_uint(rd[2]) >> 23) & 0xffu) << 16) | (((__float_as_uint(rd[3]) >> 23) & 0xffu) << 24);
                     }
             }
-            if constexpr (DG && KIND != EPI_MUL_AUX && KIND != EPI_MUL_AUX_U8) {   // the A operand's row scales (M % 4 == 0, host-checked: a group of 4 rows is all in or all out)
+            if constexpr (DG && !epi_mul_aux_kind(KIND)) {   // the A operand's row scales (M % 4 == 0, host-checked: a group of 4 rows is all in or all out)
 #pragma unroll
                 for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
@@ -619,7 +633,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                             _Pragma("unroll") for (int t = 0; t < 4; ++t) v[4 * hm + t] = acc[hm][t][hn][n][r];
                         if (KIND == EPI_ROWNORM_GELU) {
                             store_row8<EPI_GELU_SAVE>(ep, m, nb, v);
-                        } else if (DG && (KIND == EPI_MUL_AUX || KIND == EPI_MUL_AUX_U8)) {
+                        } else if (DG && epi_mul_aux_kind(KIND)) {
                             *(uint2*)((unsigned char*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8fp8(v, p.out_fp8_scale);
                             if constexpr (DG == 2) {
                                 const float rdf = __uint_as_float(((rdexp[hn][n] >> (8 * r)) & 0xffu) << 23);
@@ -718,6 +732,8 @@ static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
         case EPI_ADD_AUX: return K256(EPI_ADD_AUX);
         case EPI_GELU_SAVE_U8: return K256(EPI_GELU_SAVE_U8);
         case EPI_MUL_AUX_U8: return K256(EPI_MUL_AUX_U8);
+        case EPI_GELU_SAVE_12: return K256(EPI_GELU_SAVE_12);
+        case EPI_MUL_AUX_12: return K256(EPI_MUL_AUX_12);
         case EPI_RES_F32: return K256(EPI_RES_F32);
         case EPI_RES_F32_DROP: return K256(EPI_RES_F32_DROP);
         case EPI_SPLITK_F32: return (const void*)gemm256_bf16_nt_kernel<EPI_SPLITK_F32, false, false, false, false>;
@@ -799,9 +815,10 @@ bool gemm256_fp8_dgrad_launch(const GemmParams& p, hipStream_t stream) {
     const void* fn = kind == EPI_BF16 ? (const void*)gemm256_fp8_dgrad_kernel<EPI_BF16>
                    : kind == EPI_MUL_AUX ? (dual ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX, 2> : (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX>)
                    : kind == EPI_MUL_AUX_U8 ? (dual ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8, 2> : (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8>)
+                   : kind == EPI_MUL_AUX_12 ? (dual ? (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_12, 2> : (const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_12>)
                    : kind == EPI_ADD_AUX ? (const void*)gemm256_fp8_dgrad_kernel<EPI_ADD_AUX> : nullptr;
     if (fn == nullptr) return false;
-    const bool mul = kind == EPI_MUL_AUX || kind == EPI_MUL_AUX_U8;
+    const bool mul = epi_mul_aux_kind(kind);
     if ((p.out_fp8_scale > 0.f) != mul) return false;
     if ((!mul || dual) && p.a_row_dequant == nullptr) return false;
     if (dual && (!mul || (p.ld_dual & 7) || p.ld_dual < p.N || ((uintptr_t)p.dual_bf16 & 15))) return false;
@@ -812,6 +829,8 @@ bool gemm256_fp8_dgrad_launch(const GemmParams& p, hipStream_t stream) {
         ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_ADD_AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_U8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_12>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm256_fp8_dgrad_kernel<EPI_MUL_AUX_12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
         return ok;
     }();
     if (!attr_ok) return false;

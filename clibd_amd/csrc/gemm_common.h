@@ -97,7 +97,13 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
             v[e + 1] *= f1;
         }
     }
-    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8) {
+    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_E12) {
+        float dg[16];
+        gelu_and_grad_rows<16>(v, dg);
+        gelu12_row8* o = (gelu12_row8*)((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + (nb >> 1) * 3);   // 1.5 bytes per column
+        o[0] = gelu12_pack8(dg);
+        o[1] = gelu12_pack8(dg + 8);
+    } else if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8) {
         float dg[16];
         gelu_and_grad_rows<16>(v, dg);
         uint4 c;
@@ -133,6 +139,15 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
             v[2 * e] *= gelu_grad_f(bf2f((unsigned short)(xs[e] & 0xffffu)));
             v[2 * e + 1] *= gelu_grad_f(bf2f((unsigned short)(xs[e] >> 16)));
         }
+    }
+    if (ep.act == CLIBD_ACT_MUL_AUX_E12) {
+        const gelu12_row8* ax = (const gelu12_row8*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + (nb >> 1) * 3);
+        const gelu12_row8 a0 = ax[0], a1 = ax[1];
+        float d[16];
+        gelu12_unpack8(a0.w0, a0.w1, a0.w2, d);
+        gelu12_unpack8(a1.w0, a1.w1, a1.w2, d + 8);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] *= d[e];
     }
     if (ep.act == CLIBD_ACT_MUL_AUX_U8) {
         const uint4 c = *(const uint4*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
@@ -209,9 +224,12 @@ enum : int {
     EPI_MUL_AUX_U8 = 9,    // EPI_MUL_AUX reading those bytes                      (fc2 dgrad x gelu'; opt-in, same switch)
     EPI_RES_F32_COPY = 10,    // EPI_RES_F32 + a bf16 copy of the result + per-slice row sums (LN -> Linear fold, producer: ViT projection)
     EPI_ROWNORM_GELU = 11,    // rstd_m (acc - mean_m s_n) + b'_n -> EPI_GELU_SAVE                  (LN -> Linear fold, consumer: ViT fc1)
-    EPI_NUM_KINDS = 12,
+    EPI_GELU_SAVE_12 = 12,    // EPI_GELU_SAVE with gelu' as the 12-bit e4m7 form of its bf16 value (common.h gelu12_*; numerics gelu_grad="e4m7")
+    EPI_MUL_AUX_12 = 13,      // EPI_MUL_AUX reading that form
+    EPI_NUM_KINDS = 14,
 };
-constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX || kind == EPI_MUL_AUX_U8; }
+constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX || kind == EPI_MUL_AUX_U8 || kind == EPI_MUL_AUX_12; }
+constexpr bool epi_mul_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_MUL_AUX_U8 || kind == EPI_MUL_AUX_12; }
 
 __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.split_k > 1) return EPI_GENERIC;
@@ -226,6 +244,8 @@ __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.act == CLIBD_ACT_ADD_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_ADD_AUX;
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8 && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE_U8;
     if (ep.act == CLIBD_ACT_MUL_AUX_U8 && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX_U8;
+    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_E12 && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE_12;
+    if (ep.act == CLIBD_ACT_MUL_AUX_E12 && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX_12;
     if (ep.act == CLIBD_ACT_NONE && !ep.out_pre_bf16 && ep.residual_f32 && ep.out_f32 && !ep.out_bf16) return drop ? EPI_RES_F32_DROP : EPI_RES_F32;
     return EPI_GENERIC;
 }
@@ -263,6 +283,22 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
         *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
         return;
     }
+    if (KIND == EPI_GELU_SAVE_12) {
+        float dg[8];
+        gelu_and_grad_rows<8>(v, dg);
+        *(gelu12_row8*)((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + (nb >> 1) * 3) = gelu12_pack8(dg);
+        *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
+    if (KIND == EPI_MUL_AUX_12) {
+        const gelu12_row8 a = *(const gelu12_row8*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + (nb >> 1) * 3);
+        float d[8];
+        gelu12_unpack8(a.w0, a.w1, a.w2, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= d[e];
+        *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
     if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
         const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
         const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
@@ -288,7 +324,11 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
         }
     }
     if (KIND == EPI_GENERIC) {
-        if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8) {
+        if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_E12) {
+            float dg[8];
+            gelu_and_grad_rows<8>(v, dg);
+            *(gelu12_row8*)((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + (nb >> 1) * 3) = gelu12_pack8(dg);
+        } else if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8) {
             float dg[8];
             gelu_and_grad_rows<8>(v, dg);
             *(uint2*)((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) =
@@ -312,6 +352,12 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
             geluq_unpack4(c.y, d1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
+        } else if (ep.act == CLIBD_ACT_MUL_AUX_E12) {
+            const gelu12_row8 a = *(const gelu12_row8*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + (nb >> 1) * 3);
+            float d[8];
+            gelu12_unpack8(a.w0, a.w1, a.w2, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= d[e];
         } else if (ep.act == CLIBD_ACT_GELU_GRAD || ep.act == CLIBD_ACT_MUL_AUX || ep.act == CLIBD_ACT_ADD_AUX) {
             const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
             const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};
@@ -364,6 +410,11 @@ __device__ __forceinline__ void fold_row8_in(const clibd_gemm_epilogue& ep, int 
         geluq_unpack4(ax.y, d1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
+    } else if (KIND == EPI_MUL_AUX_12) {   // ax.x, ax.y, ax.z: the row's eight 12-bit values
+        float d[8];
+        gelu12_unpack8(ax.x, ax.y, ax.z, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= d[e];
     } else if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
         const unsigned xs[4] = {ax.x, ax.y, ax.z, ax.w};
 #pragma unroll
@@ -404,16 +455,28 @@ __device__ __forceinline__ float row16_sum(float x) {
 }
 
 // the same with the loads
-// The 16-byte aux load of the MUL_AUX / ADD_AUX epilogues (gelu' / a residual-gradient stream: read ONCE, never again).  -DCLIBD_NT_AUX_LOADS
-// (A/B knob, round 6): with the non-temporal hint, so that the stream does not displace the A / W panels six workgroups share in L2.
+// The 16-byte aux load of the MUL_AUX / ADD_AUX epilogues (gelu' / a residual-gradient stream: read ONCE, never again) carries the non-temporal
+// hint (round 6), so that the stream does not displace the A / W panels the workgroups of an XCD share in L2: FETCH_SIZE of the fc2 dgrad x gelu'
+// launch 6.37 -> 5.76 GB, step -0.14 % in an interleaved same-box A/B (profiles/r06_exp_nt_aux_loads.log).  -DCLIBD_PLAIN_AUX_LOADS builds the A/B partner.
 __device__ __forceinline__ uint4 load_aux16(const void* p) {
     typedef unsigned aux_u32x4 __attribute__((ext_vector_type(4)));
-#ifdef CLIBD_NT_AUX_LOADS
+#ifndef CLIBD_PLAIN_AUX_LOADS
     const aux_u32x4 v = __builtin_nontemporal_load((const aux_u32x4*)p);
 #else
     const aux_u32x4 v = *(const aux_u32x4*)p;
 #endif
     return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// the 12-byte row piece of the e4m7 gelu' form (eight columns), non-temporal like load_aux16
+__device__ __forceinline__ uint4 load_aux12(const void* p) {
+    typedef unsigned aux_u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+#ifndef CLIBD_PLAIN_AUX_LOADS
+    const aux_u32x3 v = __builtin_nontemporal_load((const aux_u32x3*)p);
+#else
+    const aux_u32x3 v = *(const aux_u32x3*)p;
+#endif
+    return make_uint4(v[0], v[1], v[2], 0u);
 }
 
 template <int KIND>
@@ -423,6 +486,8 @@ __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, 
     if (KIND == EPI_MUL_AUX_U8) {
         const uint2 c = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
         ax.x = c.x; ax.y = c.y;
+    } else if (KIND == EPI_MUL_AUX_12) {
+        ax = load_aux12((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + (nb >> 1) * 3);
     } else if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
         ax = load_aux16((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
     } else {

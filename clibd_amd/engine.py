@@ -42,13 +42,19 @@ class NotSupportedYet(NotImplementedError):
 #   independent) is budgeted in DESIGN.md §4.  Full fine-tune mode (disable_lora) follows the same switch since round 4 — its bottom
 #   layer still hands an fp32 gradient to the embedding backward; tests/test_model_gpu.py::test_full_finetune_residual_grad_streams_agree
 #   gates the bf16 stream against the fp32 one on the same model.
-# gelu_grad ("bf16" default | "u8"; env CLIBD_GELU_GRAD).  gelu'(fc1 out) is all the MLP's backward needs (frozen fc1 / fc2 carry no
+# gelu_grad ("e4m7" default since round 6 | "bf16" | "u8"; env CLIBD_GELU_GRAD).  gelu'(fc1 out) is all the MLP's backward needs (frozen fc1 / fc2 carry no
 #   weight gradient that would want the activation), and it lies in [-0.129, 1.129].  "u8" keeps it as ONE BYTE per element
 #   (CLIBD_ACT_GELU_SAVE_GRAD_U8, |error| <= 2.5e-3 everywhere; bf16's half-spacing is 2.0e-3 in [0.5, 1), 3.9e-3 in [1, 2), finer
 #   below 0.5) and the fc2 dgrad multiplies by the decoded byte (CLIBD_ACT_MUL_AUX_U8): 50 GB less per step at b=2048, 285.1 -> 282.5
 #   ms.  Gradient effect at full size: 5e-4 (ViT) / 4e-5 (BERT) relative, invisible against the oracle; on the tiny
 #   fixtures the WORST per-tensor error moves by +-10 % (medians unchanged), which the tightest gate (x1.6 of the reference's own
 #   autocast error) does not always absorb — so the default stays the bf16 form.  The fp8-forward mode always uses bf16.
+#   Round 6: "e4m7" (the DEFAULT) keeps the bf16 value of gelu' in TWELVE bits — sign, 4-bit exponent, bf16's 7 mantissa bits; gelu' lies in
+#   [-0.129, 1.129], sixteen binades [2^-14, 2) cover it — so every bf16 gelu' of magnitude >= 2^-14 = 6.1e-5 is reproduced BIT FOR BIT and smaller ones
+#   (pre-activations below about -4.55) become zero: the fc2 dgrad multiplies by the same operand as the bf16 form, at 1.5 instead of 2 bytes per
+#   element on the fc1 forward's write and the fc2 dgrad's read (CLIBD_ACT_GELU_SAVE_GRAD_E12 / CLIBD_ACT_MUL_AUX_E12; tests/test_ops_gpu.py::
+#   test_gelu_grad_e4m7_is_the_bf16_value, tests/test_model_gpu.py::test_gelu_grad_e4m7_towers_equal_the_bf16_form).  Not a numerics relaxation, hence
+#   also part of bench.py's `reference_numerics`-equivalent set: the reference keeps gelu' nowhere (autograd recomputes it from the bf16 pre-activation).
 # attn_bwd ("2phase" default | "sp"; env CLIBD_ATTN_BWD).  "2phase" = the kernel that derives the softmax statistics itself and
 #   evaluates every score twice; "sp" = single pass (ops.attention_bwd_sp; the training forward then also saves its per-layer output,
 #   the rounding residual of that output and the log-sum-exp: 4 more bytes per element of activation memory per layer).  The
@@ -73,7 +79,7 @@ class NotSupportedYet(NotImplementedError):
 #   weights (disable_lora, the reference's final recipe) — the e4m3 weight images are re-made every step, the LayerNorm backward writes the e4m3 rows
 #   AND the bf16 copy the weight gradient contracts (clibd_layernorm_bwd_fp8_pg), the fc2 dgrad writes d(fc1 out) as e4m3 AND as bf16; every weight /
 #   bias / LayerNorm gradient is the bf16 path's arithmetic on those copies.  DESIGN.md §3.1d.
-NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"),
+NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("e4m7", "bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"),
                         dgrad=("bf16", "fp8"))
 _NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD", ln_fold="CLIBD_LN_FOLD",
                      dgrad="CLIBD_DGRAD")
@@ -97,8 +103,11 @@ def check_numerics(settings: dict) -> dict:
     return settings
 
 
-def _mul_aux_act(h) -> int:
-    return ops.ACT_MUL_AUX_U8 if h.dtype == torch.uint8 else ops.ACT_MUL_AUX
+def _mul_aux_act(h, FF: int) -> int:
+    """the fc2 dgrad's epilogue for the way gelu' was saved: bf16 [M,FF], one byte per element (uint8 [M,FF]) or the 12-bit e4m7 form (uint8 [M,3FF/2])"""
+    if h.dtype == torch.uint8:
+        return ops.ACT_MUL_AUX_E12 if h.shape[1] == 3 * FF // 2 else ops.ACT_MUL_AUX_U8
+    return ops.ACT_MUL_AUX
 
 
 @dataclass
@@ -417,8 +426,14 @@ class TransformerStack:
         a = None if keep else new(FF, AT)           # post-GELU activation (temporary)
         xn2 = new(H, AT) if (self.pre_ln and not keep) else None
         xn8 = new(H, ops.FP8) if (f8s is not None and not mlp_only) else None   # fp8 image of the first LayerNorm's output (temporary)
-        GG = torch.uint8 if (self.numerics["gelu_grad"] == "u8" and f8s is None) else BF16            # storage of gelu'(fc1 out)
-        act_save = ops.ACT_GELU_SAVE_GRAD_U8 if GG == torch.uint8 else ops.ACT_GELU_SAVE_GRAD
+        # storage of gelu'(fc1 out): bf16, one byte, or (round 6, the default) the 12-bit e4m7 form of the bf16 value; the fp8-forward fc1
+        # and the LN -> fc1 fold's consumer epilogue write bf16 only
+        gg = self.numerics["gelu_grad"]
+        if f8s is not None or (self.pre_ln and self.numerics["ln_fold"] == "on"):
+            gg = "bf16"
+        GG = BF16 if gg == "bf16" else torch.uint8
+        HC = 3 * FF // 2 if gg == "e4m7" else FF                                                     # columns of that buffer
+        act_save = {"bf16": ops.ACT_GELU_SAVE_GRAD, "u8": ops.ACT_GELU_SAVE_GRAD_U8, "e4m7": ops.ACT_GELU_SAVE_GRAD_E12}[gg]
         h_tmp = new(FF, BF16) if (f8s is not None and not save) else None       # the fp8 fc1 form always writes gelu'
         t = t0
         sp_ok = save and key_mask is None and f8s is None and S <= 224 and self.numerics["attn_bwd"] == "sp"
@@ -462,7 +477,7 @@ class TransformerStack:
                 st2 = torch.empty((B, 2), dtype=F32, device=dev)
                 xn2c = newB(H, BF16)
                 ops.layernorm_fwd(x1, c.g2, c.be2, self.eps, y_bf16=xn2c, stats=st2)
-                h = newB(FF, GG) if save else None
+                h = newB(HC, GG) if save else None
                 ac = newB(FF, BF16)
                 ops.gemm_nt(xn2c, c.w1, bias=c.b1, act=act_save if save else ops.ACT_GELU, out_pre=h, out_bf16=ac)
                 x2 = newB(H, F32)
@@ -480,7 +495,7 @@ class TransformerStack:
                 qkv = new(3 * H, BF16)
                 x1 = new(H, F32)
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
-                h = new(FF, GG) if save else None        # holds gelu'(fc1 out): all the backward needs
+                h = new(HC, GG) if save else None        # holds gelu'(fc1 out): all the backward needs
                 x2 = new(H, F32)
                 if f8 is not None and mlp_only:   # fp8 on the MLP pair only: the attention half of the block is the bf16 path's
                     ops.layernorm_fwd(x_f32, c.g1, c.be1, self.eps, y_bf16=xn, stats=st1, lora_a=c.a_cat if has_lora else None, t_out=t)
@@ -541,7 +556,7 @@ class TransformerStack:
                 s1 = new(H, F32)
                 x1_f32 = new(H, F32)
                 st1 = torch.empty((M, 2), dtype=F32, device=dev)
-                h = new(FF, GG) if save else None
+                h = new(HC, GG) if save else None
                 s2 = new(H, F32)
                 x2_f32, x2_bf16 = new(H, F32), new(H, BF16)
                 st2 = torch.empty((M, 2), dtype=F32, device=dev)
@@ -653,7 +668,7 @@ class TransformerStack:
                 newB = lambda cols, dt: torch.empty((B, cols), dtype=dt, device=dev)
                 dhc, dtc = newB(FF, BF16), newB(H, BF16)
                 wg(dx_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
-                ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dhc)
+                ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"], FF), aux=rec["h"], out_bf16=dhc)
                 wg(dhc, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                 ops.gemm_nt(dhc, c.w1_t, out_bf16=dtc)
                 dx1_f32, dx1_bf16 = newB(H, F32), newB(H, BF16)
@@ -686,13 +701,13 @@ class TransformerStack:
                     dh8 = torch.empty((M, FF), dtype=torch.uint8, device=dev).view(ops.FP8)
                     if full:   # ... and once more as bf16: the operand of fc1's weight gradient
                         dh = new(FF, BF16) if dh is None else dh
-                    ops.gemm_fp8_dgrad_nt(dx8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"]), out_fp8=dh8, out_fp8_scale=c.c2,
+                    ops.gemm_fp8_dgrad_nt(dx8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"], FF), out_fp8=dh8, out_fp8_scale=c.c2,
                                           a_row_dequant=dx8[1] if full else None, out_bf16_dual=dh if full else None)
                     wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                     ops.gemm_fp8_dgrad_nt(dh8, c.w1_t8, c.cs_1t, a_row_dequant=dx8[1], out_bf16=dtmp)
                 else:
                     dh = new(FF, BF16) if dh is None else dh
-                    ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)      # d(fc1 out)
+                    ops.gemm_nt(dx_bf16, c.w2_t, act=_mul_aux_act(rec["h"], FF), aux=rec["h"], out_bf16=dh)      # d(fc1 out)
                     wg(dh, rec.get("xn2"), [L.fc1_w], [L.fc1_b])
                     ops.gemm_nt(dh, c.w1_t, out_bf16=dtmp)                                               # d(LN2 out)
                 dx18 = new8(H) if (dg8 and "proj" in self.dgrad8_sites) else None
@@ -754,14 +769,14 @@ class TransformerStack:
                     if full:
                         wg(ds2_b, rec.get("a"), [L.fc2_w], [L.fc2_b])
                         dh = new(FF, BF16) if dh is None else dh
-                    ops.gemm_fp8_dgrad_nt(ds2_8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"]), out_fp8=dh8, out_fp8_scale=c.c2,
+                    ops.gemm_fp8_dgrad_nt(ds2_8[0], c.w2_t8, c.cs_2t, aux=rec["h"], act=_mul_aux_act(rec["h"], FF), out_fp8=dh8, out_fp8_scale=c.c2,
                                           a_row_dequant=ds2_8[1] if full else None, out_bf16_dual=dh if full else None)
                     wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                     ops.gemm_fp8_dgrad_nt(dh8, c.w1_t8, c.cs_1t, a_row_dequant=ds2_8[1], aux=ds2_res, act=ops.ACT_ADD_AUX, out_bf16=dx1)
                 else:
                     dh = new(FF, BF16) if dh is None else dh
                     wg(ds2_b, rec.get("a"), [L.fc2_w], [L.fc2_b])
-                    ops.gemm_nt(ds2_b, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)
+                    ops.gemm_nt(ds2_b, c.w2_t, act=_mul_aux_act(rec["h"], FF), aux=rec["h"], out_bf16=dh)
                     wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                     ops.gemm_nt(dh, c.w1_t, act=ops.ACT_ADD_AUX, aux=ds2_res, out_bf16=dx1)
                 ds1_res, ds1_b, ds1_8 = ln_back(dx1, rec["s1"], rec["st1"], c.g1, rec["d_h1"], pg(L.ln1_w, L.ln1_b))
@@ -791,7 +806,7 @@ class TransformerStack:
                 ops.layernorm_bwd(dx_f32, rec["s2"], rec["st2"], c.g2, dx_f32=ds2_f32, dx_bf16=ds2_bf16, drop=rec["d_h2"], **pg(L.ln2_w, L.ln2_b))
                 wg(ds2_bf16, rec.get("a"), [L.fc2_w], [L.fc2_b])
                 dh = new(FF, BF16) if dh is None else dh
-                ops.gemm_nt(ds2_bf16, c.w2_t, act=_mul_aux_act(rec["h"]), aux=rec["h"], out_bf16=dh)
+                ops.gemm_nt(ds2_bf16, c.w2_t, act=_mul_aux_act(rec["h"], FF), aux=rec["h"], out_bf16=dh)
                 wg(dh, rec.get("x1_bf16"), [L.fc1_w], [L.fc1_b])
                 dx1 = new(H, F32)
                 ops.gemm_nt(dh, c.w1_t, residual=ds2_f32, out_f32=dx1)

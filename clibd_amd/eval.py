@@ -92,23 +92,41 @@ def prepare_key_bank(keys_feature: torch.Tensor) -> "ops.KeyBank":
 _bank_cache: dict = {}
 
 
+def clear_key_bank_cache() -> None:
+    """Drop the cached bank (normalised fp32 keys + their bf16 image: ~1.9 GB at 410 k x 768), e.g. before training resumes after an evaluation."""
+    _bank_cache.clear()
+
+
 def _cached_key_bank(keys_feature: torch.Tensor) -> "ops.KeyBank":
-    key = (keys_feature.data_ptr(), tuple(keys_feature.shape), tuple(keys_feature.stride()), keys_feature.dtype, keys_feature._version,
-           str(keys_feature.device))
+    # ADVICE r5: the entry must not outlive the caller's tensor (it would pin ~1.9 GB of device memory until the next call) and a tensor
+    # whose version counter cannot be read (created under torch.inference_mode()) is simply not cached
+    try:
+        version = keys_feature._version
+    except RuntimeError:
+        return prepare_key_bank(keys_feature)
+    key = (keys_feature.data_ptr(), tuple(keys_feature.shape), tuple(keys_feature.stride()), keys_feature.dtype, version, str(keys_feature.device))
     hit = _bank_cache.get("entry")
     if hit is not None and hit[0] == key and hit[1]() is keys_feature:
         return hit[2]
     bank = prepare_key_bank(keys_feature)
     _bank_cache["entry"] = (key, weakref.ref(keys_feature), bank)
+    weakref.finalize(keys_feature, _drop_entry_of, key)    # the bank goes when the caller's tensor does
     return bank
 
 
-def topk_search(query_feature: torch.Tensor, keys_feature, max_k: int = 5, exact: bool = False):
+def _drop_entry_of(key) -> None:
+    hit = _bank_cache.get("entry")
+    if hit is not None and hit[0] == key:
+        _bank_cache.clear()
+
+
+def topk_search(query_feature: torch.Tensor, keys_feature, max_k: int = 5, exact: bool = False, cache: bool = True):
     """(similarities, indices) of IndexFlatIP.search on L2-normalised features.  `keys_feature`: a tensor, or a bank from
     `prepare_key_bank` (re-used across query batches).  Large banks take the pre-filtered search (bf16 approximate scores, exact
     fp32 re-score of every key inside the rigorous error band: indices and similarities identical to the exact kernel's); queries
     it flags — candidate lists full inside the band, e.g. many duplicate keys — are re-run through the exact kernel.  exact=True
-    forces the exact kernel for everything."""
+    forces the exact kernel for everything.  cache=False: the prepared bank of a key TENSOR is not kept (a temporary device copy of host keys
+    could never hit and would only pin memory)."""
     q, _ = ops.l2norm_fwd(query_feature.detach().to(torch.float32).contiguous())
     bank = keys_feature if isinstance(keys_feature, ops.KeyBank) else None
     if bank is None:
@@ -116,7 +134,7 @@ def topk_search(query_feature: torch.Tensor, keys_feature, max_k: int = 5, exact
         if exact or D % 64 != 0 or D > ops.KeyBank.MAX_D or not (4096 <= Nk < ops.KeyBank.MAX_KEYS):
             kf, _ = ops.l2norm_fwd(keys_feature.detach().to(torch.float32).contiguous())
             return ops.topk_ip(q, kf, max_k)
-        bank = _cached_key_bank(keys_feature)
+        bank = _cached_key_bank(keys_feature) if cache else prepare_key_bank(keys_feature)
     if exact:
         return ops.topk_ip(q, bank.keys, max_k)
     sim, idx, ovf = ops.topk_ip_fast(q, bank, max_k)
@@ -137,7 +155,9 @@ def make_prediction(query_feature, keys_feature, keys_label: List[dict], with_si
     qf = torch.as_tensor(np.asarray(query_feature) if not torch.is_tensor(query_feature) else query_feature).to(dev)
     kf = keys_feature if isinstance(keys_feature, ops.KeyBank) else \
         torch.as_tensor(np.asarray(keys_feature) if not torch.is_tensor(keys_feature) else keys_feature).to(dev)
-    sim, idx = topk_search(qf, kf, max_k)
+    # only a tensor the CALLER holds on the device can hit the cache again; host keys (numpy, the reference's convention) become a fresh device copy per call
+    on_device = torch.is_tensor(keys_feature) and keys_feature.device == kf.device if torch.is_tensor(kf) else False
+    sim, idx = topk_search(qf, kf, max_k, cache=on_device)
     idx_h, sim_h = idx.cpu().numpy(), sim.cpu().numpy()
     pred_list = [{level: [keys_label[i][level] for i in row] for level in LEVELS} for row in idx_h]
     out = [pred_list]

@@ -194,7 +194,7 @@ class SimpleCLIP(nn.Module):
 
     def set_numerics(self, **settings):
         """Backward arithmetic switches of every tower (clibd_amd.engine.NUMERICS_CHOICES: residual_grad = "bf16" | "fp32",
-        gelu_grad = "bf16" | "u8", attn_bwd = "2phase" | "sp").  The CLIBD_* environment variables only give the defaults a
+        gelu_grad = "e4m7" | "bf16" | "u8", attn_bwd = "2phase" | "sp", ln_fold, dgrad).  The CLIBD_* environment variables only give the defaults a
         tower is constructed with; this is the explicit form (per model, recorded by bench.py and save_training_state)."""
         for st in self._stacks():
             st.set_numerics(**settings)

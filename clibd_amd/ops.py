@@ -14,6 +14,7 @@ from . import _lib
 from ._lib import GemmEpilogue, check
 
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX, ACT_ADD_AUX, ACT_GELU_SAVE_GRAD_U8, ACT_MUL_AUX_U8 = 0, 1, 2, 3, 4, 5, 6, 7
+ACT_GELU_SAVE_GRAD_E12, ACT_MUL_AUX_E12 = 8, 9   # gelu' as the 12-bit e4m7 form of its bf16 value: uint8 buffers [M, 3N/2] (include/clibd_hip.h)
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
 FP8 = torch.float8_e4m3fn  # OCP e4m3 (gfx950's fp8 MFMA operand format); max finite 448
 
@@ -115,20 +116,20 @@ def gemm_nt(
             raise ValueError("gemm_nt: rank_u must be [M,>=8], rank_v [N,8]")
         ep.rank_u, ep.rank_v, ep.ld_rank_u = rank_u.data_ptr(), rank_v.data_ptr(), _rowmajor(rank_u, "rank_u")
     if aux is not None:
-        _chk(aux, torch.uint8 if act == ACT_MUL_AUX_U8 else BF16, "aux", contiguous=False)   # _U8: gelu' codes, one byte per element
-        if tuple(aux.shape) != (M, N):
-            raise ValueError("gemm_nt: aux must be [M,N]")
+        _chk(aux, torch.uint8 if act in (ACT_MUL_AUX_U8, ACT_MUL_AUX_E12) else BF16, "aux", contiguous=False)   # _U8: gelu' codes, one byte per element; _E12: 1.5 bytes
+        if tuple(aux.shape) != (M, 3 * N // 2 if act == ACT_MUL_AUX_E12 else N):
+            raise ValueError("gemm_nt: aux must be [M,N] ([M,3N/2] bytes for the e4m7 form)")
         ep.aux_bf16, ep.ld_aux = aux.data_ptr(), _rowmajor(aux, "aux")
     if residual is not None:
         _chk(residual, F32, "residual", contiguous=False)
         if tuple(residual.shape) != (M, N):
             raise ValueError("gemm_nt: residual must be [M,N]")
         ep.residual_f32, ep.ld_res = residual.data_ptr(), _rowmajor(residual, "residual")
-    for name, t, dt in (("out_pre", out_pre, torch.uint8 if act == ACT_GELU_SAVE_GRAD_U8 else BF16), ("out_bf16", out_bf16, BF16), ("out_f32", out_f32, F32)):
+    for name, t, dt in (("out_pre", out_pre, torch.uint8 if act in (ACT_GELU_SAVE_GRAD_U8, ACT_GELU_SAVE_GRAD_E12) else BF16), ("out_bf16", out_bf16, BF16), ("out_f32", out_f32, F32)):
         if t is not None:
             _chk(t, dt, name, contiguous=False)
-            if tuple(t.shape) != (M, N):
-                raise ValueError(f"gemm_nt: {name} must be [M,N]")
+            if tuple(t.shape) != (M, 3 * N // 2 if (name == "out_pre" and act == ACT_GELU_SAVE_GRAD_E12) else N):
+                raise ValueError(f"gemm_nt: {name} must be [M,N] ([M,3N/2] bytes for the e4m7 form)")
     if out_pre is not None:
         ep.out_pre_bf16, ep.ld_pre = out_pre.data_ptr(), _rowmajor(out_pre, "out_pre")
     if out_bf16 is not None:
@@ -216,19 +217,19 @@ def gemm_fp8_dgrad_nt(a: torch.Tensor, w: torch.Tensor, col_scale: torch.Tensor,
     N, K2 = w.shape
     if K != K2 or col_scale.numel() != N:
         raise ValueError("gemm_fp8_dgrad_nt: shape mismatch")
-    if act not in (ACT_NONE, ACT_ADD_AUX, ACT_MUL_AUX, ACT_MUL_AUX_U8):
-        raise ValueError("gemm_fp8_dgrad_nt: act must be NONE, ADD_AUX, MUL_AUX or MUL_AUX_U8")
+    if act not in (ACT_NONE, ACT_ADD_AUX, ACT_MUL_AUX, ACT_MUL_AUX_U8, ACT_MUL_AUX_E12):
+        raise ValueError("gemm_fp8_dgrad_nt: act must be NONE, ADD_AUX, MUL_AUX, MUL_AUX_U8 or MUL_AUX_E12")
     if (act == ACT_NONE) != (aux is None):
         raise ValueError("gemm_fp8_dgrad_nt: aux comes with ADD_AUX / MUL_AUX only")
     ep = GemmEpilogue()
     ep.split_k = 1
     ep.act = act
     if aux is not None:
-        _chk(aux, torch.uint8 if act == ACT_MUL_AUX_U8 else BF16, "aux", contiguous=False)
-        if tuple(aux.shape) != (M, N):
-            raise ValueError("gemm_fp8_dgrad_nt: aux must be [M,N]")
+        _chk(aux, torch.uint8 if act in (ACT_MUL_AUX_U8, ACT_MUL_AUX_E12) else BF16, "aux", contiguous=False)
+        if tuple(aux.shape) != (M, 3 * N // 2 if act == ACT_MUL_AUX_E12 else N):
+            raise ValueError("gemm_fp8_dgrad_nt: aux must be [M,N] ([M,3N/2] bytes for the e4m7 form)")
         ep.aux_bf16, ep.ld_aux = aux.data_ptr(), _rowmajor(aux, "aux")
-    if act in (ACT_MUL_AUX, ACT_MUL_AUX_U8):
+    if act in (ACT_MUL_AUX, ACT_MUL_AUX_U8, ACT_MUL_AUX_E12):
         if out_fp8 is None or out_bf16 is not None or not out_fp8_scale > 0:
             raise ValueError("gemm_fp8_dgrad_nt: the MUL_AUX form writes out_fp8 with a positive out_fp8_scale")
         _chk(out_fp8, FP8, "out_fp8", contiguous=False)

@@ -56,13 +56,20 @@ const char* clibd_build_hash(void);
  *                                   out_pre_bf16 / aux_bf16 then point to uint8 [M,N] (ld_pre / ld_aux in bytes, % 16),
  *                                   code = rint((gelu'(x) + 0.1328125) * 255 / 1.265625), decoded as code * 1.265625 / 255 - 0.1328125
  *                                   (gelu' lies in [-0.129, 1.129]; |error| <= 2.5e-3, the spacing of bf16 in [0.5, 1) is 3.9e-3)
+ *   if act == CLIBD_ACT_GELU_SAVE_GRAD_E12 / CLIBD_ACT_MUL_AUX_E12 (ABI 5): the same two forms with gelu' kept as TWELVE bits per element, "e4m7":
+ *                                   sign, 4-bit exponent, bf16's 7 mantissa bits — the bf16 value of gelu' with its exponent re-biased to the binades
+ *                                   [2^-14, 2) (code e4 = biased bf16 exponent - 112, e4 = 0: zero).  Every bf16 gelu' of magnitude >= 2^-14 is kept BIT FOR
+ *                                   BIT (gelu' lies in [-0.129, 1.129]); smaller magnitudes become a signed zero.  out_pre_bf16 / aux_bf16 then point to
+ *                                   bytes [M, 3N/2]: eight adjacent columns = three dwords w0 = c0 | c1 << 12 | c2 << 24, w1 = c2 >> 8 | c3 << 4 | c4 << 16 |
+ *                                   c5 << 28, w2 = c5 >> 4 | c6 << 8 | c7 << 20; ld_pre / ld_aux in BYTES, % 4, >= 3N/2; N % 8 == 0.
  *   if residual_f32:  v += residual_f32[m,n]
  *   out_bf16[m,n] = bf16(v) ; out_f32[m,n] = v   (either or both)
  *   split_k > 1: only out_f32 allowed; partial sums are atomically added into a caller-zeroed out_f32.
  * Constraints: K % 64 == 0, lda/ldw % 8 == 0, N % 16 == 0, all ld_* % 8 == 0, 16-byte aligned pointers.
  * ------------------------------------------------------------------------------------------------ */
 enum { CLIBD_ACT_NONE = 0, CLIBD_ACT_GELU = 1, CLIBD_ACT_GELU_GRAD = 2, CLIBD_ACT_GELU_SAVE_GRAD = 3, CLIBD_ACT_MUL_AUX = 4,
-       CLIBD_ACT_ADD_AUX = 5, CLIBD_ACT_GELU_SAVE_GRAD_U8 = 6, CLIBD_ACT_MUL_AUX_U8 = 7 };
+       CLIBD_ACT_ADD_AUX = 5, CLIBD_ACT_GELU_SAVE_GRAD_U8 = 6, CLIBD_ACT_MUL_AUX_U8 = 7,
+       CLIBD_ACT_GELU_SAVE_GRAD_E12 = 8, CLIBD_ACT_MUL_AUX_E12 = 9 /* ABI 5 */ };
 
 typedef struct clibd_gemm_epilogue {
     const float* bias;          /* [N] fp32 */

@@ -477,7 +477,8 @@ def test_dgrad8_with_the_one_byte_gelu_grad_in_a_tower(dev):
     g = torch.Generator().manual_seed(36)
     img, cot = torch.rand(16, 3, 224, 224, generator=g).to(dev), torch.randn(16, 768, generator=g).to(dev)
     res = {}
-    for key, kw in (("bf16", dict(dgrad="bf16", gelu_grad="bf16")), ("fp8", dict(dgrad="fp8", gelu_grad="bf16")), ("fp8+u8", dict(dgrad="fp8", gelu_grad="u8"))):
+    for key, kw in (("bf16", dict(dgrad="bf16", gelu_grad="bf16")), ("fp8", dict(dgrad="fp8", gelu_grad="bf16")), ("fp8+u8", dict(dgrad="fp8", gelu_grad="u8")),
+                    ("fp8+e4m7", dict(dgrad="fp8", gelu_grad="e4m7"))):
         m.tower().stack.set_numerics(**kw)
         y = m(img)
         res[key] = (y.detach().cpu(), _grads(m.named_parameters(), (y * cot).sum()))
@@ -489,3 +490,5 @@ def test_dgrad8_with_the_one_byte_gelu_grad_in_a_tower(dev):
     c8, c8u = _cos(f["fp8"], f["bf16"]), _cos(f["fp8+u8"], f["bf16"])
     print(f"[dgrad8 + one-byte gelu'] cosine vs the bf16 dgrad: dgrad8 {c8:.6f}, dgrad8 + u8 {c8u:.6f}; between the two {_cos(f['fp8'], f['fp8+u8']):.6f}")
     assert c8u > 0.999 and c8u > c8 - 2e-4
+    # round 6: the twelve-bit form IS the bf16 value (flushed below 2^-14): the 8-bit dgrad's e4m3 operand is the same up to that tail
+    assert float((f["fp8+e4m7"] - f["fp8"]).abs().max()) <= 1e-4 * float(f["fp8"].abs().max()) and _cos(f["fp8+e4m7"], f["fp8"]) > 0.999999

@@ -1016,6 +1016,34 @@ def test_gelu_grad_kept_as_one_byte_in_the_towers(dev, monkeypatch):
         assert_grads(res["u8"][1], go, rel_tol=3e-2, cos_tol=0.999, what="u8 gelu' vs oracle")
 
 
+def test_gelu_grad_e4m7_towers_equal_the_bf16_form(dev):
+    """numerics gelu_grad="e4m7" (round 6, the DEFAULT): gelu' saved as the twelve-bit form of its bf16 value.  Every |gelu'| >= 2^-14 is reproduced
+    bit for bit, so the tower gradients are those of the bf16 form up to the flushed tail (|gelu'| < 6.1e-5, pre-activations below -4.55): here,
+    both tower kinds, LoRA and full fine-tune walks — identical embeddings, gradients within 1e-5 of the largest element (bit-identical in practice)."""
+    gd, gi = load("dna_tiny_golden.pt"), load("image_tiny_golden.pt")
+    for hm, x in ((hip_image(gi, dev), gi["image_u8"].float() / 255.0), (hip_dna(gd, dev), gd["ids"])):
+        assert hm.tower().stack.numerics["gelu_grad"] == "e4m7"
+        for full in (False, True):
+            if full:
+                for p_ in hm.parameters():
+                    p_.requires_grad_(True)
+            g = torch.Generator().manual_seed(6)
+            res = {}
+            for mode in ("bf16", "e4m7"):
+                hm.tower().stack.set_numerics(gelu_grad=mode)
+                y = hm(x.to(dev))
+                if mode == "bf16":
+                    cot = torch.randn(y.shape, generator=g)
+                res[mode] = (y.detach().cpu(), grads_named(hm, (y * cot.to(dev)).sum()))
+            assert torch.equal(res["e4m7"][0], res["bf16"][0])
+            same = 0
+            for n, gb in res["bf16"][1].items():
+                ge = res["e4m7"][1][n]
+                assert float((ge - gb).abs().max()) <= 1e-5 * max(float(gb.abs().max()), 1e-30), (n, full)
+                same += int(torch.equal(ge, gb))
+            print(f"[e4m7 gelu'] {type(hm).__name__} full={full}: {same} of {len(res['bf16'][1])} gradients bit-identical to the bf16 form")
+
+
 @pytest.mark.parametrize("name", ["image", "dna"])
 def test_full_finetune_residual_grad_streams_agree(dev, name):
     """since round 4 the full fine-tune walk (model_config.disable_lora) follows the residual_grad switch too, i.e. by

@@ -1284,3 +1284,110 @@ def test_ln_fold_epilogues(ops, dev):
     assert rel_err(act[rows].float().cpu(), torch.nn.functional.gelu(h_std.to(BF16).float()).cpu()) < 1.2e-2
     with pytest.raises(Exception):   # the fold epilogues exist in the 256x256 kernel only
         ops.gemm_nt(a[:300], wo, bias=bo, residual=res[:300], out_f32=x1[:300], out_bf16=x1b[:300], row_sums=sums[:, :300].contiguous())
+
+
+# ----------------------------------------------------------------------------------------------- gelu' in twelve bits (round 6)
+def decode_e4m7(buf, N):
+    """host statement of the e4m7 layout (include/clibd_hip.h CLIBD_ACT_*_E12): uint8 [M, 3N/2] -> fp32 [M, N]"""
+    M = buf.shape[0]
+    b = buf.cpu().view(M, N // 8, 12).to(torch.int64)
+    w = [b[..., 4 * i] | (b[..., 4 * i + 1] << 8) | (b[..., 4 * i + 2] << 16) | (b[..., 4 * i + 3] << 24) for i in range(3)]
+    c = [w[0] & 0xfff, (w[0] >> 12) & 0xfff, (w[0] >> 24) | ((w[1] & 0xf) << 8), (w[1] >> 4) & 0xfff, (w[1] >> 16) & 0xfff,
+         (w[1] >> 28) | ((w[2] & 0xff) << 4), (w[2] >> 8) & 0xfff, w[2] >> 20]
+    c = torch.stack(c, dim=-1).view(M, N)
+    u = c & 0x7ff
+    t = torch.where(u > 0, u + (112 << 7), torch.zeros_like(u))
+    bits = (((c & 0x800) << 4) | t) << 16
+    return bits.to(torch.int32).view(torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 3072, 768), (300, 256, 128), (2048, 3072, 768)])   # 256x256 kernel (192 tiles) | 128x128 kernel | the class-row block's shape
+def test_gelu_grad_e4m7_is_the_bf16_value(ops, dev, M, N, K):
+    """CLIBD_ACT_GELU_SAVE_GRAD_E12 keeps bf16(gelu') in twelve bits — sign, 4-bit exponent, 7 mantissa bits: decoded, it must EQUAL the bf16 form's
+    gelu' wherever |gelu'| >= 2^-14 and be zero below; the GELU output itself is the bf16 form's bit for bit.  CLIBD_ACT_MUL_AUX_E12 then multiplies by
+    exactly that decoded operand: bit-identical to CLIBD_ACT_MUL_AUX fed the decoded values as bf16.  Pre-activations are spread over +-9 so that
+    the flushed tail (x < -4.55), the zero crossing (x = -0.75) and the saturated side (gelu' -> 1) are all in the sample."""
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.35).to(BF16).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.35).to(BF16).to(dev)
+    bias = (torch.randn(N, generator=g) * 2.0).to(dev)
+    h16, a16 = torch.empty((M, N), dtype=BF16, device=dev), torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a, w, bias=bias, act=ops.ACT_GELU_SAVE_GRAD, out_pre=h16, out_bf16=a16)
+    h12, a12 = torch.empty((M, 3 * N // 2), dtype=torch.uint8, device=dev), torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a, w, bias=bias, act=ops.ACT_GELU_SAVE_GRAD_E12, out_pre=h12, out_bf16=a12)
+    torch.cuda.synchronize()
+    assert torch.equal(a12, a16)
+    want, got = h16.float().cpu(), decode_e4m7(h12, N)
+    big = want.abs() >= 2.0 ** -14
+    assert big.float().mean() > 0.5 and (~big).sum() > 0                 # both regimes are sampled
+    assert torch.equal(got[big], want[big])                             # bit for bit
+    assert float(got[~big].abs().max()) == 0.0                          # flushed: |error| < 2^-14 = 6.1e-5
+    assert float(want.max()) > 1.1 and float(want.min()) < -0.12         # the whole range of gelu' occurs
+    # the fc2 dgrad's operand: the decoded values, bit for bit
+    dy = (torch.randn(M, 256, generator=g) * 0.1).to(BF16).to(dev)
+    wt = (torch.randn(N, 256, generator=g) * 0.1).to(BF16).to(dev)
+    o12, o16 = torch.empty((M, N), dtype=BF16, device=dev), torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(dy, wt, act=ops.ACT_MUL_AUX_E12, aux=h12, out_bf16=o12)
+    ops.gemm_nt(dy, wt, act=ops.ACT_MUL_AUX, aux=got.to(BF16).to(dev), out_bf16=o16)
+    torch.cuda.synchronize()
+    assert torch.equal(o12, o16)
+
+
+def test_gelu_grad_e4m7_covers_every_bf16_value_of_gelu_grad(ops, dev):
+    """Exhaustive over the domain: every bf16 pre-activation x (65 536 bit patterns, non-finite ones excluded) through the kernel's own gelu' —
+    a GEMM with a one-hot operand reproduces x exactly — encoded and decoded: equal to the bf16 form's gelu'(x) whenever that is >= 2^-14 in
+    magnitude, zero otherwise; and NO value of gelu' reaches the code's upper end (|gelu'| < 2)."""
+    bits = torch.arange(65536, dtype=torch.int32)
+    x = (bits << 16).view(torch.float32)
+    x = x[torch.isfinite(x) & (x.abs() < 1e30)]
+    n = x.numel() // 256 * 256
+    x = x[:n].view(-1, 256)                                                # [M, 256] pre-activations
+    M, N = x.shape[0], 256
+    a = x.clone()                                                          # [M, 256] as the A operand (K = 256)
+    w = torch.eye(N)                                                       # out[m, n] = x[m, n] exactly: one non-zero product per output
+    h16, o16 = torch.empty((M, N), dtype=BF16, device=dev), torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a.to(BF16).to(dev), w.to(BF16).to(dev), act=ops.ACT_GELU_SAVE_GRAD, out_pre=h16, out_bf16=o16)
+    h12, o12 = torch.empty((M, 3 * N // 2), dtype=torch.uint8, device=dev), torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a.to(BF16).to(dev), w.to(BF16).to(dev), act=ops.ACT_GELU_SAVE_GRAD_E12, out_pre=h12, out_bf16=o12)
+    torch.cuda.synchronize()
+    want, got = h16.float().cpu(), decode_e4m7(h12, N)
+    ok = torch.isfinite(want)
+    big = ok & (want.abs() >= 2.0 ** -14)
+    assert float(want[ok].abs().max()) < 2.0
+    assert torch.equal(got[big], want[big]) and float(got[ok & ~big].abs().max()) == 0.0
+    assert int(big.sum()) > 20000
+
+
+def test_key_bank_cache_follows_the_callers_tensor(dev):
+    """eval.topk_search keeps ONE prepared bank per device key tensor — and only as long as the caller's tensor lives, never for a
+    temporary device copy of host keys, and not at all for a tensor whose version counter cannot be read."""
+    import gc
+
+    import numpy as np
+
+    from clibd_amd import eval as ev
+
+    g = torch.Generator().manual_seed(3)
+    keys = torch.nn.functional.normalize(torch.randn(4096, 128, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(16, 128, generator=g), dim=1).to(dev)
+    kd = keys.to(dev)
+    ev.clear_key_bank_cache()
+    s1, i1 = ev.topk_search(q, kd, 5)
+    bank = ev._bank_cache["entry"][2]
+    s2, i2 = ev.topk_search(q, kd, 5)
+    assert ev._bank_cache["entry"][2] is bank and torch.equal(i1, i2) and torch.equal(s1, s2)      # hit
+    kd.mul_(1.0)                                                                                  # in-place update: new version, new bank
+    ev.topk_search(q, kd, 5)
+    assert ev._bank_cache["entry"][2] is not bank
+    del kd
+    gc.collect()
+    assert "entry" not in ev._bank_cache                                                           # the bank went with the caller's tensor
+    labels = [{lv: str(j) for lv in ev.LEVELS} for j in range(4096)]
+    ev.make_prediction(q, keys.numpy(), labels)                                                    # host keys: nothing is pinned
+    assert "entry" not in ev._bank_cache
+    with torch.inference_mode():
+        ki = keys.to(dev)
+    s3, i3 = ev.topk_search(q, ki, 5)                                                              # no version counter: works, uncached
+    assert torch.equal(i3, i1) and "entry" not in ev._bank_cache
+    exact = ev.topk_search(q, keys.to(dev), 5, exact=True)
+    assert torch.equal(exact[1], i1)
