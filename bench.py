@@ -916,9 +916,10 @@ def main():
         sync_loop()           # warm-up (pinned staging, allocator)
         t_sync = timed(sync_loop)
         t_pref = prefetch_timed(host)
-        # The dataset holds image BYTES (uint8 HDF5, util/dataset.py:185-195: ToTensor = u8 / 255 on the host): handing those over and
-        # dividing on the device (clibd_patchify_u8, bit-identical patches) moves a quarter of the bytes.  The synthetic fp32 images are
-        # not multiples of 1/255, so this leg runs on its own uint8 batch of the same shape: same kernels, same FLOPs, different pixels.
+        # WHAT-IF leg: the dataset holds image BYTES (uint8 HDF5, util/dataset.py:185-195), but the reference augments on the host AFTER ToTensor
+        # (Resize, RandomResizedCrop, flips, rotation on float tensors), so what it sends is fp32.  IF the pipeline emitted uint8 crops (or ran on
+        # the device), handing those over and dividing on the device (clibd_patchify_u8) would move a quarter of the bytes.  The synthetic fp32
+        # images are not multiples of 1/255, so this leg runs on its own uint8 batch of the same shape: same kernels, same FLOPs, different pixels.
         host8 = dict(host)
         host8["image"] = torch.randint(0, 256, tuple(host["image"].shape), dtype=torch.uint8).pin_memory()
         nbytes8 = nbytes - host["image"].numel() * 4 + host8["image"].numel()
@@ -928,8 +929,10 @@ def main():
                "steps": hsteps, "host_bytes_per_step_per_gpu": nbytes,
                "copy_at_top_of_step": {"value": b * world * hsteps / t_sync, "ms_per_step": t_sync / hsteps * 1e3},
                "uint8_images": {"value": b * world * hsteps / t_pref8, "ms_per_step": t_pref8 / hsteps * 1e3, "host_bytes_per_step_per_gpu": nbytes8,
-                                "note": "the dataset's image bytes handed over as uint8 and divided by 255 on the device (clibd_patchify_u8: "
-                                        "the same patch matrix bit for bit as the reference's host-side ToTensor): a quarter of the PCIe bytes"},
+                                "note": "WHAT-IF leg: uint8 224x224 crops handed over as bytes and divided by 255 on the device (clibd_patchify_u8: bit-identical "
+                                        "to patchify(u8.float() / 255)): a quarter of the PCIe bytes.  Not equivalent to the reference's data path, whose ToTensor is "
+                                        "followed on the host by Resize / RandomResizedCrop / flips / rotation on float tensors (util/dataset.py): it applies only if "
+                                        "the augmentation pipeline emits uint8 crops or runs on the device"},
                "note": "same step with the batch handed over as pinned HOST tensors every step (PCIe-inclusive); `value` here = next batch "
                        "prefetched on a copy stream under the current step (clibd_amd.data.DevicePrefetcher, steady state: the first batch's "
                        "copy is requested before the clock starts), copy_at_top_of_step = the reference's loop shape (synchronous "

@@ -59,19 +59,23 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* _
 // ---- LayerNorm -> Linear fold (round 5) ------------------------------------------------------------------------------------------
 // stats[m] = (mean, rstd) of row m from the per-slice partial sums the producing GEMM's epilogue wrote (clibd_gemm_epilogue.row_sums:
 // [S][M][2] = sum, sum of squares over slice s of the H = 128 S columns): what clibd_layernorm_fwd's `stats` holds, for the consumer GEMM
-// and for the LayerNorm BACKWARD, which is unchanged.  var = E[x^2] - mean^2 in fp32 (slice sums of <= 128 fp32 values; the rows of a
-// pre-LN residual stream have |mean| << sigma: tools/ln_fold_study.py), clamped at 0.
+// and for the LayerNorm BACKWARD, which is unchanged.  The per-slice (sum, sum of squares) are added and differenced in fp64, clamped at 0.
 __global__ __launch_bounds__(256) void rowsum_finalize_kernel(const float* __restrict__ sums, int S, int M, float inv_h, float eps, float* __restrict__ stats) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    float s1 = 0.f, s2 = 0.f;
+    // Round 6: sums and the difference E[x^2] - mean^2 in fp64, so the merge adds no cancellation of its own (in fp32 the subtraction
+    // itself lost (|mean| / sigma)^2 x 6e-8 once more).  What remains is the rounding of the producer's fp32 slice sums: a relative error of
+    // about 1.2e-7 (|mean| / sigma)^2 on the variance — negligible for a pre-LN residual stream (|mean| << sigma), 1 % at |mean| / sigma = 300;
+    // rows beyond that (single-channel outliers of some pretrained ViTs) want the LayerNorm pass (ln_fold stays opt-in, default off).
+    double t = 0.0, q = 0.0;
     for (int j = 0; j < S; ++j) {
         const float2 v = *(const float2*)(sums + ((size_t)j * M + m) * 2);
-        s1 += v.x;
-        s2 += v.y;
+        t += (double)v.x;
+        q += (double)v.y;
     }
-    const float mean = s1 * inv_h;
-    const float var = fmaxf(s2 * inv_h - mean * mean, 0.f);
+    const double mean_d = t * (double)inv_h;
+    const float mean = (float)mean_d;
+    const float var = fmaxf((float)((q - mean_d * t) * (double)inv_h), 0.f);
     *(float2*)(stats + (size_t)m * 2) = make_float2(mean, rsqrtf(var + eps));
 }
 

@@ -324,7 +324,11 @@ int clibd_lora_backward(const void* dqkv, int ld_dqkv, const void* x_bf16, const
 int clibd_patchify(const float* image, int B, void* patches_bf16, void* stream);
 /* The same from the dataset's image BYTES (uint8 [B,3,224,224], 8-byte aligned): value = fp32(u8) / 255 (IEEE division, what the
  * reference's ToTensor computes on the host, util/dataset.py:185-195), so the result equals clibd_patchify(u8.float() / 255) bit
- * for bit while a quarter of the bytes cross PCIe (train_epoch.py:26-32 copies the fp32 tensor every step).  ABI version 3. */
+ * for bit while a quarter of the bytes cross PCIe (train_epoch.py:26-32 copies the fp32 tensor every step).  ABI version 3.
+ * Scope: this is the ARITHMETIC of ToTensor only.  The reference's pipeline continues on the host after ToTensor — Resize(256,
+ * antialias), RandomResizedCrop / CenterCrop(224), flips and rotation on float tensors (util/dataset.py) — so the tensor it sends is not u8 / 255
+ * of any stored byte image; the uint8 path applies when the augmentation pipeline emits uint8 224 x 224 crops (or moves to the device), and is not a
+ * drop-in for the reference's float pipeline. */
 int clibd_patchify_u8(const unsigned char* image, int B, void* patches_bf16, void* stream);
 /* LayerNorm -> Linear fold (ABI 3; see clibd_gemm_epilogue.row_sums / row_stats).  clibd_rowsum_finalize: stats[m] = (mean, rstd) of
  * row m (eps as the LayerNorm's) from the producer GEMM's per-slice sums row_sums[slices][M][2], H = 128 * slices — the `stats` of
