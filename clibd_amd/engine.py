@@ -42,19 +42,23 @@ class NotSupportedYet(NotImplementedError):
 #   independent) is budgeted in DESIGN.md §4.  Full fine-tune mode (disable_lora) follows the same switch since round 4 — its bottom
 #   layer still hands an fp32 gradient to the embedding backward; tests/test_model_gpu.py::test_full_finetune_residual_grad_streams_agree
 #   gates the bf16 stream against the fp32 one on the same model.
-# gelu_grad ("e4m7" default since round 6 | "bf16" | "u8"; env CLIBD_GELU_GRAD).  gelu'(fc1 out) is all the MLP's backward needs (frozen fc1 / fc2 carry no
+# gelu_grad ("bf16" default | "u8" | "e4m7"; env CLIBD_GELU_GRAD).  gelu'(fc1 out) is all the MLP's backward needs (frozen fc1 / fc2 carry no
 #   weight gradient that would want the activation), and it lies in [-0.129, 1.129].  "u8" keeps it as ONE BYTE per element
 #   (CLIBD_ACT_GELU_SAVE_GRAD_U8, |error| <= 2.5e-3 everywhere; bf16's half-spacing is 2.0e-3 in [0.5, 1), 3.9e-3 in [1, 2), finer
 #   below 0.5) and the fc2 dgrad multiplies by the decoded byte (CLIBD_ACT_MUL_AUX_U8): 50 GB less per step at b=2048, 285.1 -> 282.5
 #   ms.  Gradient effect at full size: 5e-4 (ViT) / 4e-5 (BERT) relative, invisible against the oracle; on the tiny
 #   fixtures the WORST per-tensor error moves by +-10 % (medians unchanged), which the tightest gate (x1.6 of the reference's own
 #   autocast error) does not always absorb — so the default stays the bf16 form.  The fp8-forward mode always uses bf16.
-#   Round 6: "e4m7" (the DEFAULT) keeps the bf16 value of gelu' in TWELVE bits — sign, 4-bit exponent, bf16's 7 mantissa bits; gelu' lies in
-#   [-0.129, 1.129], sixteen binades [2^-14, 2) cover it — so every bf16 gelu' of magnitude >= 2^-14 = 6.1e-5 is reproduced BIT FOR BIT and smaller ones
+#   Round 6: "e4m7" keeps the bf16 value of gelu' in TWELVE bits — sign, 4-bit exponent, bf16's 7 mantissa bits; gelu' lies in [-0.129, 1.129],
+#   sixteen binades [2^-14, 2) cover it — so every bf16 gelu' of magnitude >= 2^-14 = 6.1e-5 is reproduced BIT FOR BIT and smaller ones
 #   (pre-activations below about -4.55) become zero: the fc2 dgrad multiplies by the same operand as the bf16 form, at 1.5 instead of 2 bytes per
 #   element on the fc1 forward's write and the fc2 dgrad's read (CLIBD_ACT_GELU_SAVE_GRAD_E12 / CLIBD_ACT_MUL_AUX_E12; tests/test_ops_gpu.py::
-#   test_gelu_grad_e4m7_is_the_bf16_value, tests/test_model_gpu.py::test_gelu_grad_e4m7_towers_equal_the_bf16_form).  Not a numerics relaxation, hence
-#   also part of bench.py's `reference_numerics`-equivalent set: the reference keeps gelu' nowhere (autograd recomputes it from the bf16 pre-activation).
+#   test_gelu_grad_e4m7_is_the_bf16_value, tests/test_model_gpu.py::test_gelu_grad_e4m7_towers_equal_the_bf16_form).  Numerically free — and a measured
+#   NO-GO as the default: the step is 3.0 % SLOWER with it (294.9 against 286.3 ms, three interleaved pairs on one box, profiles/r06_exp_gelu_grad_e4m7.log).
+#   The twelve-bit pack / unpack has no conversion instruction behind it (~100 VALU operations per row of eight columns where the bf16 form takes
+#   four v_cvt_pk and the one-byte form eight v_cvt_pk_u8), and the GEMM's epilogue is exposed time: it roughly doubles the VALU work of the fc1
+#   epilogue, which the 12.5 % fewer output bytes do not buy back; a hand-packed encode (v_pk_sub_u16 clamp on the bf16 pairs, ~32 operations per
+#   row) would still cost more cycles than the bytes save.  Opt-in, for completeness of the byte ladder 2 / 1.5 / 1.
 # attn_bwd ("2phase" default | "sp"; env CLIBD_ATTN_BWD).  "2phase" = the kernel that derives the softmax statistics itself and
 #   evaluates every score twice; "sp" = single pass (ops.attention_bwd_sp; the training forward then also saves its per-layer output,
 #   the rounding residual of that output and the log-sum-exp: 4 more bytes per element of activation memory per layer).  The
@@ -79,7 +83,7 @@ class NotSupportedYet(NotImplementedError):
 #   weights (disable_lora, the reference's final recipe) — the e4m3 weight images are re-made every step, the LayerNorm backward writes the e4m3 rows
 #   AND the bf16 copy the weight gradient contracts (clibd_layernorm_bwd_fp8_pg), the fc2 dgrad writes d(fc1 out) as e4m3 AND as bf16; every weight /
 #   bias / LayerNorm gradient is the bf16 path's arithmetic on those copies.  DESIGN.md §3.1d.
-NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("e4m7", "bf16", "u8"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"),
+NUMERICS_CHOICES = dict(residual_grad=("bf16", "fp32"), gelu_grad=("bf16", "u8", "e4m7"), attn_bwd=("2phase", "sp"), ln_fold=("off", "on"),
                         dgrad=("bf16", "fp8"))
 _NUMERICS_ENV = dict(residual_grad="CLIBD_RESIDUAL_GRAD", gelu_grad="CLIBD_GELU_GRAD", attn_bwd="CLIBD_ATTN_BWD", ln_fold="CLIBD_LN_FOLD",
                      dgrad="CLIBD_DGRAD")
@@ -426,7 +430,7 @@ class TransformerStack:
         a = None if keep else new(FF, AT)           # post-GELU activation (temporary)
         xn2 = new(H, AT) if (self.pre_ln and not keep) else None
         xn8 = new(H, ops.FP8) if (f8s is not None and not mlp_only) else None   # fp8 image of the first LayerNorm's output (temporary)
-        # storage of gelu'(fc1 out): bf16, one byte, or (round 6, the default) the 12-bit e4m7 form of the bf16 value; the fp8-forward fc1
+        # storage of gelu'(fc1 out): bf16 (default), one byte, or (round 6) the 12-bit e4m7 form of the bf16 value; the fp8-forward fc1
         # and the LN -> fc1 fold's consumer epilogue write bf16 only
         gg = self.numerics["gelu_grad"]
         if f8s is not None or (self.pre_ln and self.numerics["ln_fold"] == "on"):

@@ -338,10 +338,10 @@ def test_numerics_switches_are_explicit_settings(monkeypatch, tmp_path):
     monkeypatch.delenv("CLIBD_LN_FOLD", raising=False)
     monkeypatch.delenv("CLIBD_DGRAD", raising=False)
     a = build()
-    assert a.numerics()["image_encoder"] == dict(residual_grad="bf16", gelu_grad="e4m7", attn_bwd="2phase", ln_fold="off", dgrad="bf16", forward="bf16")   # (round 6: gelu' in twelve bits, the bf16 value)
+    assert a.numerics()["image_encoder"] == dict(residual_grad="bf16", gelu_grad="bf16", attn_bwd="2phase", ln_fold="off", dgrad="bf16", forward="bf16")
     monkeypatch.setenv("CLIBD_GELU_GRAD", "u8")
     b = build()                                    # the variable is read at construction ...
-    assert b.numerics()["dna_encoder"]["gelu_grad"] == "u8" and a.numerics()["dna_encoder"]["gelu_grad"] == "e4m7"   # ... not by `a`
+    assert b.numerics()["dna_encoder"]["gelu_grad"] == "u8" and a.numerics()["dna_encoder"]["gelu_grad"] == "bf16"   # ... not by `a`
     a.set_numerics(residual_grad="fp32")           # two models of one process differ
     assert a.numerics()["image_encoder"]["residual_grad"] == "fp32" and b.numerics()["image_encoder"]["residual_grad"] == "bf16"
     with pytest.raises(ValueError):
