@@ -882,7 +882,15 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     q.nk_split = nk;
     q.split_stride = 0;
     q.band = band_env_value() != 0 ? band_env_value() : (q.tiles_n >= G256_WS_MIN_TILES_N ? -G256_WS_GROUP : 4);
-    const int grid = (int)(tiles < num_cus ? tiles : num_cus);
+    int grid = (int)(tiles < num_cus ? tiles : num_cus);
+#ifdef CLIBD_BALANCED_GRID
+    // A/B knob (round 6): the SMALLEST grid that needs the same number of tile rounds (591 tiles: 3 rounds on 256 CUs -> 197 workgroups x 3 tiles
+    // each), so that a launch with a mostly empty last round leaves whole CUs to the other tower's kernel from the start instead of for one round
+    if (tiles > num_cus) {
+        const long long rounds = (tiles + num_cus - 1) / num_cus;
+        grid = (int)((tiles + rounds - 1) / rounds);
+    }
+#endif
     const int kind = epilogue_kind(p.ep);
     int ntiles_i = (int)tiles;
     int skew_arg = skew_env_value();
