@@ -1,0 +1,42 @@
+"""the LayerNorm kernels stream 5.6 TB/s at b = 2048 and 6.4 TB/s at b = 256.  Hypothesis: the b = 256 launch (M = 50 432: x 155 MB + dy 77 MB
++ the bf16 residual stream 77 MB in, 2 x 77 MB out) finds part of its operands in the 256 MB Infinity Cache — the previous kernel has just written them — which the
+b = 2048 launch (8 x the bytes) cannot.  Test: the same backward launch at M = 50 432 on ONE buffer set (re-run back to back: warm) and rotating over EIGHT disjoint
+buffer sets (3.7 GB: every launch meets cold operands), against the M = 403 456 launch.
+    python tools/bench_ln_cache.py"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from clibd_amd import ops
+dev = torch.device("cuda:0"); BF16, F32 = torch.bfloat16, torch.float32
+H = 768
+
+
+def make(M):
+    x = torch.randn(M, H, device=dev)
+    st = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-6).rsqrt()], dim=1).contiguous()
+    return dict(dy=torch.randn(M, H, device=dev).to(BF16), x=x, st=st, dres=torch.randn(M, H, device=dev).to(BF16),
+                out=torch.empty((M, H), dtype=BF16, device=dev))
+
+
+def run(sets, iters):
+    g = torch.ones(H, device=dev)
+    for s in sets:
+        ops.layernorm_bwd(s["dy"], s["x"], s["st"], g, dres_bf16=s["dres"], dx_bf16=s["out"])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        s = sets[i % len(sets)]
+        ops.layernorm_bwd(s["dy"], s["x"], s["st"], g, dres_bf16=s["dres"], dx_bf16=s["out"])
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+for M, nsets in ((50432, 1), (50432, 8), (50432, 16), (403456, 1), (403456, 2)):
+    sets = [make(M) for _ in range(nsets)]
+    ms = run(sets, 64 if M < 100000 else 16)
+    byt = M * H * (2 + 4 + 2 + 2) + M * 8
+    print(f"layernorm_bwd (bf16 stream) M={M:6d} rotating over {nsets:2d} buffer set(s) ({nsets * byt / 1e9:5.2f} GB): {ms * 1e3:7.1f} us = {byt / ms / 1e9:6.2f} TB/s", flush=True)
+    del sets
+    torch.cuda.empty_cache()
