@@ -553,8 +553,16 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
 #ifndef CLIBD_ATT_BWD_LONG_WAVES
 #define CLIBD_ATT_BWD_LONG_WAVES 2
 #endif
+// waves per SIMD the register allocator is held to: three for the short forms (NKT <= 10), two for the long ones — and (round 6) two for the
+// four-wave ten-tile form without a key mask (S in (144, 160]: it spilled 6 registers at the three-wave cap; -DCLIBD_ATT_BWD_S160_WAVES=3 builds the A/B partner)
+#ifndef CLIBD_ATT_BWD_S160_WAVES
+#define CLIBD_ATT_BWD_S160_WAVES 2
+#endif
+constexpr int att_bwd_min_waves(int NKT, bool MASK, int NW) {
+    return NKT > 10 ? CLIBD_ATT_BWD_LONG_WAVES : (NKT == 10 && NW == 4 && !MASK) ? CLIBD_ATT_BWD_S160_WAVES : 3;
+}
 template <int NKT, bool PAIR, bool MASK, bool DROP, int NW = ATT_WAVES, int IMG = 16 * NKT>
-__global__ __launch_bounds__(64 * NW, (NKT <= 10 ? 3 : CLIBD_ATT_BWD_LONG_WAVES)) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(64 * NW, att_bwd_min_waves(NKT, MASK, NW)) void attention_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                                     const unsigned short* __restrict__ dout, int S,
                                                                     int nheads, const int* __restrict__ key_mask,
                                                                     unsigned short* __restrict__ dqkv, float scale,
@@ -1195,6 +1203,12 @@ static int att_check(const void* qkv, int B, int S, int nheads, const char* who)
 
 using namespace clibd;
 
+#ifndef CLIBD_ATT_BWD_S256_DROP_ONE_TILE
+#define CLIBD_ATT_BWD_S256_DROP_ONE_TILE 1
+#endif
+#ifndef CLIBD_ATT_FWD_PERSISTENT_SPILLING
+#define CLIBD_ATT_FWD_PERSISTENT_SPILLING 0
+#endif
 #define ATT_DISPATCH(NKT_EXPR, MACRO) \
     switch (NKT_EXPR) {               \
         case 2: MACRO(2); break;      \
@@ -1232,8 +1246,10 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
     const size_t lds3 = (size_t)2 * 144 * 128 + 16 * 128;   // three-wave form: two 144-row images + the zeroed pad
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
-        if (N >= 12 && total >= 2 * num_cus) {   /* S > 160: at S = 133 only 9 of the 16 waves have a tile and the per-head kernel wins */ \
-            constexpr int NP = N >= 12 ? N : 12;   /* (only the long-sequence forms are instantiated) */             \
+        /* (round 6) the dropout forms of the persistent kernel that spill at its 128-register cap — dropout with a key mask, dropout at sixteen tiles — take the per-head kernel */ \
+        constexpr bool PERSIST_OK = CLIBD_ATT_FWD_PERSISTENT_SPILLING || !(DRP && (MSK || N >= 16));               \
+        if (PERSIST_OK && N >= 12 && total >= 2 * num_cus) {   /* S > 160: at S = 133 only 9 of the 16 waves have a tile and the per-head kernel wins */ \
+            constexpr int NP = (PERSIST_OK && N >= 12) ? N : 12;   /* (only the long-sequence, spill-free forms are instantiated) */             \
             hipFuncSetAttribute((const void*)attention_fwd_persistent_kernel<NP, MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
             hipLaunchKernelGGL((attention_fwd_persistent_kernel<NP, MSK, DRP>), dim3(num_cus), dim3(64 * ATTP_WAVES), ldsp, st, \
                                (const unsigned short*)qkv, S, nheads, total, (const int*)key_mask, (unsigned short*)out, scale, nq, out_seq, \
@@ -1354,8 +1370,10 @@ extern "C" int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B
     }
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
-        hipFuncSetAttribute((const void*)attention_bwd_kernel<N, (N >= 12), MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((attention_bwd_kernel<N, (N >= 12), MSK, DRP>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,       \
+        /* PAIR (two key tiles per wave in phase 2) for the long forms — except (round 6) sixteen tiles with dropout and no mask, which spilled 10 registers at 256 */ \
+        constexpr bool PR = (N >= 12) && !(CLIBD_ATT_BWD_S256_DROP_ONE_TILE && N == 16 && DRP && !MSK);             \
+        hipFuncSetAttribute((const void*)attention_bwd_kernel<N, PR, MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attention_bwd_kernel<N, PR, MSK, DRP>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,       \
                            (const unsigned short*)qkv, (const unsigned short*)dout, S, nheads, (const int*)key_mask, \
                            (unsigned short*)dqkv, scale, nq, dout_seq, drop_seed, drop_thr16, drop_scale);        \
     } while (0)
