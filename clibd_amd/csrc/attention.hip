@@ -553,10 +553,12 @@ __global__ __launch_bounds__(64 * ATTP_WAVES) void attention_fwd_persistent_kern
 #ifndef CLIBD_ATT_BWD_LONG_WAVES
 #define CLIBD_ATT_BWD_LONG_WAVES 2
 #endif
-// waves per SIMD the register allocator is held to: three for the short forms (NKT <= 10), two for the long ones — and (round 6) two for the
-// four-wave ten-tile form without a key mask (S in (144, 160]: it spilled 6 registers at the three-wave cap; -DCLIBD_ATT_BWD_S160_WAVES=3 builds the A/B partner)
+// waves per SIMD the register allocator is held to: three for the short forms (NKT <= 10), two for the long ones.  The four-wave ten-tile form
+// without a key mask (S in (144, 160]) spills 6 registers at the three-wave cap; round 6 measured the spill-free alternative (two waves per SIMD, 170-174
+// registers: -DCLIBD_ATT_BWD_S160_WAVES=2): 177-182 us against 163-164 us per launch at S = 150, b = 256 — the spilling form is 10 % FASTER and stays
+// (profiles/r06_exp_attention_spills.log).
 #ifndef CLIBD_ATT_BWD_S160_WAVES
-#define CLIBD_ATT_BWD_S160_WAVES 2
+#define CLIBD_ATT_BWD_S160_WAVES 3
 #endif
 constexpr int att_bwd_min_waves(int NKT, bool MASK, int NW) {
     return NKT > 10 ? CLIBD_ATT_BWD_LONG_WAVES : (NKT == 10 && NW == 4 && !MASK) ? CLIBD_ATT_BWD_S160_WAVES : 3;
@@ -1204,10 +1206,10 @@ static int att_check(const void* qkv, int B, int S, int nheads, const char* who)
 using namespace clibd;
 
 #ifndef CLIBD_ATT_BWD_S256_DROP_ONE_TILE
-#define CLIBD_ATT_BWD_S256_DROP_ONE_TILE 1
+#define CLIBD_ATT_BWD_S256_DROP_ONE_TILE 0
 #endif
 #ifndef CLIBD_ATT_FWD_PERSISTENT_SPILLING
-#define CLIBD_ATT_FWD_PERSISTENT_SPILLING 0
+#define CLIBD_ATT_FWD_PERSISTENT_SPILLING 1
 #endif
 #define ATT_DISPATCH(NKT_EXPR, MACRO) \
     switch (NKT_EXPR) {               \
@@ -1246,7 +1248,8 @@ static int attention_fwd_impl(const void* qkv, int B, int S, int nheads, const i
     const size_t lds3 = (size_t)2 * 144 * 128 + 16 * 128;   // three-wave form: two 144-row images + the zeroed pad
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
-        /* (round 6) the dropout forms of the persistent kernel that spill at its 128-register cap — dropout with a key mask, dropout at sixteen tiles — take the per-head kernel */ \
+        /* The dropout forms of the persistent kernel that spill 2-10 registers at its 128-register cap (dropout with a key mask, dropout at sixteen tiles) were measured   */ \
+        /* against the spill-free per-head kernel in round 6 (knob = 0): 207 / 242 us persistent against 265-269 / 299 us per head at S = 220 / 250: the persistent forms stay */ \
         constexpr bool PERSIST_OK = CLIBD_ATT_FWD_PERSISTENT_SPILLING || !(DRP && (MSK || N >= 16));               \
         if (PERSIST_OK && N >= 12 && total >= 2 * num_cus) {   /* S > 160: at S = 133 only 9 of the 16 waves have a tile and the per-head kernel wins */ \
             constexpr int NP = (PERSIST_OK && N >= 12) ? N : 12;   /* (only the long-sequence, spill-free forms are instantiated) */             \
@@ -1370,7 +1373,7 @@ extern "C" int clibd_attention_bwd_drop(const void* qkv, const void* dout, int B
     }
 #define LAUNCH_M(N, MSK, DRP)                                                                                     \
     do {                                                                                                          \
-        /* PAIR (two key tiles per wave in phase 2) for the long forms — except (round 6) sixteen tiles with dropout and no mask, which spilled 10 registers at 256 */ \
+        /* PAIR (two key tiles per wave in phase 2) for the long forms.  Sixteen tiles with dropout and no mask spill 10 registers at 256; the one-tile form (knob = 1) spills 4 and runs the same 384 us at S = 250: PAIR kept */ \
         constexpr bool PR = (N >= 12) && !(CLIBD_ATT_BWD_S256_DROP_ONE_TILE && N == 16 && DRP && !MSK);             \
         hipFuncSetAttribute((const void*)attention_bwd_kernel<N, PR, MSK, DRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((attention_bwd_kernel<N, PR, MSK, DRP>), dim3(B * nheads), dim3(ATT_THREADS), lds, st,       \
