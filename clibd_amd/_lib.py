@@ -51,6 +51,8 @@ SIGNATURES = {
     "clibd_abi_version": (c_int, []),
     "clibd_build_hash": (C.c_char_p, []),
     "clibd_gemm_bf16_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
+    "clibd_gemm_tail_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "clibd_gemm_bf16_nt_ws": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p, c_size_t, c_void_p]),
     "clibd_gemm_bf16_nt_khole": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(GemmEpilogue), c_void_p]),
     "clibd_gemm_fp8_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, C.POINTER(GemmEpilogue), c_void_p]),
     "clibd_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void cast_transpose_f32_bf16_kernel(const floa
 using namespace clibd;
 
 static int gemm_impl(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int hole_k0, int hole_len,
-                     const clibd_gemm_epilogue* ep, void* stream) {
+                     const clibd_gemm_epilogue* ep, void* stream, void* tail_ws = nullptr, size_t tail_ws_bytes = 0) {
     if (!A || !W || !ep) return set_error(CLIBD_EINVAL, "gemm: null pointer");
     if (hole_len < 0 || hole_k0 < 0 || hole_k0 % BK || hole_len % BK || hole_k0 + hole_len > K || (hole_len > 0 && hole_len >= K))
         return set_error(CLIBD_EINVAL, "gemm: bad K hole (multiples of 64 inside [0, K))");
@@ -334,6 +334,14 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, int M, int 
     p.splits = 1; p.nk_split = 0; p.split_stride = 0;
     p.hole_kt = hole_len > 0 ? hole_k0 / BK : 0x7fffffff;
     p.hole_nkt = hole_len / BK;
+    if (tail_ws != nullptr) {   // stream-K tail workspace: [256 flag words | fp32 partial tiles]; ignored when the shape has no use for it
+        const size_t need = gemm256_tail_workspace_bytes(M, N, K);
+        if (need > 0) {
+            if (tail_ws_bytes < need || !aligned16(tail_ws)) return set_error(CLIBD_EINVAL, "gemm: tail workspace too small or misaligned (clibd_gemm_tail_workspace_bytes)");
+            p.sk_flags = (unsigned*)tail_ws;
+            p.sk_ws = (float*)((char*)tail_ws + 1024);
+        }
+    }
     // kernel choice (CLIBD_GEMM_KERNEL=1 forces the 128x128 kernel: tuning aid).  A third shape — 256x128x32 tiles, 3-stage
     // ring, two workgroups per CU so epilogues overlap across workgroups — was built and measured: 800 TF at K=768 and
     // 920 TF at K=3072 against 944 / 1300 TF for the 256x256 8-phase kernel, so it was dropped.
@@ -365,6 +373,13 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, int M, int 
 extern "C" int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                                   const clibd_gemm_epilogue* ep, void* stream) {
     return gemm_impl(A, lda, W, ldw, M, N, K, 0, 0, ep, stream);
+}
+
+extern "C" size_t clibd_gemm_tail_workspace_bytes(int M, int N, int K) { return gemm256_tail_workspace_bytes(M, N, K); }
+
+extern "C" int clibd_gemm_bf16_nt_ws(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                                     const clibd_gemm_epilogue* ep, void* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_impl(A, lda, W, ldw, M, N, K, 0, 0, ep, stream, workspace, workspace_bytes);
 }
 
 extern "C" int clibd_gemm_bf16_nt_khole(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int hole_k0, int hole_len,

@@ -43,6 +43,9 @@ constexpr int HALF_BYTES = 128 * T_K * 2;      // 16 KiB
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // 64 KiB
 constexpr int G256_THREADS = 512;
 constexpr int G256_LDS = 2 * STAGE_BYTES;      // 128 KiB
+// stream-K tail workspace (caller-owned, zeroed ONCE by the caller): 256 flag words at a FIXED place in front — every launch leaves them zero again, whatever
+// shape used the buffer last — then the fp32 partial tiles
+constexpr size_t G256_SK_FLAG_BYTES = 1024;
 // tile order (gemm_common.h tile_coords): W-stationary n-groups of 6 column tiles for every launch (round 5: in-step A/B against the m-bands of 4 of
 // rounds 1-4: -0.8 % of the b = 2048 step, -1.3 % at b = 256, -0.7 % in the fp8 modes; profiles/r05_exp_gemm_ws_in_step.log).  The -D knobs build the A/B variants.
 #ifndef CLIBD_WS_MIN_TILES_N
@@ -73,9 +76,11 @@ __device__ __forceinline__ i32x8 cat_frag(bf16x8 lo, bf16x8 hi) {
 //   DG == 2 (round 6, full fine-tune; MUL_AUX kinds): additionally p.dual_bf16[m,n] = bf16(acc * col_scale[n] * aux[m,n] * a_row_dequant[m]) — the
 //                           true d(fc1 out), which the bf16 weight gradient of fc1 contracts with its input.  The row factors are powers of two
 //                           (clibd_layernorm_bwd_fp8 writes 2^(e - 134)): a lane keeps the four exponents of a row group in ONE register.
-template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8, int DG>
+// SK (round 6): the stream-K tail — the last, partial round's tiles cut into K-slices over the idle CUs (GemmParams.sk_*); bf16 kinds only.
+template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8, int DG, bool SK = false>
 __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, int skew_ticks, long long* stamps) {
     static_assert(!DG || (FP8 && !LORA && !BIAS && !DIAG), "the 8-bit dgrad forms are fp8, bias-free and adapter-free");
+    static_assert(!SK || (!FP8 && !DIAG && KIND != EPI_SPLITK_F32), "the stream-K tail exists for the bf16 epilogue kinds");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -89,6 +94,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
     int m0, n0;          // tile being computed
     int nm0 = 0, nn0 = 0;  // tile whose loads are being issued (== m0,n0 until the last issue of the current tile)
     int kb_issue = 0, nk_issue = nk_total, split_issue = 0;  // K-tile base / K-tile count (even, >= 4) / split of that item
+    int part_issue = 0, slot_issue = -1;                     // SK: K-slice and tail slot of that item (slot -1: a whole tile)
 
     // ---- per-lane LDS-DMA sources: half-tile type j (0 P_hm0, 1 Q_hn0, 2 Q_hn1, 3 P_hm1) x this wave's 2 pieces
     const int prow = lane >> 3;
@@ -117,6 +123,18 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
             tile_id = item - split_issue * tiles_out;
             kb_issue = split_issue * p.nk_split;
             nk_issue = min(p.nk_split, nk_total - kb_issue);
+        }
+        if constexpr (SK) {
+            part_issue = 0; slot_issue = -1; kb_issue = 0; nk_issue = nk_total;
+            if (item >= p.sk_first) {   // a K-slice of a tail tile: non-owners (parts 1 ..) first, owners (part 0) last
+                const int j = item - p.sk_first;
+                const int nown = p.sk_tail * (p.sk_parts - 1);
+                if (j < nown) { part_issue = 1 + j / p.sk_tail; slot_issue = j - (part_issue - 1) * p.sk_tail; }
+                else { part_issue = 0; slot_issue = j - nown; }
+                tile_id = p.sk_first + slot_issue;
+                kb_issue = part_issue * p.sk_nk_part;
+                nk_issue = min(p.sk_nk_part, nk_total - kb_issue);
+            }
         }
         tile_coords(tile_id, p.tiles_m, p.tiles_n, p.band, tm, tn);
         nm0 = tm * T_M;
@@ -343,6 +361,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
         n0 = nn0;
         const int nk = nk_issue;         // K-tiles of this work item (== K/64 unless split-K)
         const int split_cur = split_issue;
+        const int part_cur = part_issue, slot_cur = slot_issue;   // SK
         const int next = tile + (int)gridDim.x;  // static round-robin: tile ids of one workgroup stay on one XCD
         const bool has_next = next < ntiles;
         WAIT_HEAD();  // L_0, L_1 of this tile have landed (this wave's pieces)
@@ -396,6 +415,50 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                              :: "memory");
         }
         STAMP(4);
+        if constexpr (SK) {
+            if (slot_cur >= 0) {   // a K-slice of a tail tile (always this workgroup's last item: the tail is one round)
+                const int srow = 64 * wn + 4 * fch, scol = 128 * wm + 8 * frow;   // this lane's 16 rows x 8 columns inside the 256 x 256 tile
+                if (part_cur > 0) {
+                    // non-owner: the fp32 partial tile goes to the workspace, then ONE release increment of the slot's flag
+                    float* outp = p.sk_ws + ((size_t)(part_cur - 1) * (size_t)p.sk_tail + (size_t)slot_cur) * (size_t)(T_M * T_N);
+#pragma unroll
+                    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                f32x4* o = (f32x4*)(outp + (size_t)(srow + 32 * hn + 16 * n + r) * T_N + scol);
+                                o[0] = (f32x4){acc[0][0][hn][n][r], acc[0][1][hn][n][r], acc[0][2][hn][n][r], acc[0][3][hn][n][r]};
+                                o[1] = (f32x4){acc[1][0][hn][n][r], acc[1][1][hn][n][r], acc[1][2][hn][n][r], acc[1][3][hn][n][r]};
+                            }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    BARRIER();                                      // every wave's stores have left for L2
+                    if (tid == 0) __hip_atomic_fetch_add(p.sk_flags + slot_cur, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                // owner: wait for the partners (dispatched before this workgroup: see GemmParams), add their partials in part order
+                if (tid == 0) {
+                    while (__hip_atomic_load(p.sk_flags + slot_cur, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.sk_parts - 1)) __builtin_amdgcn_s_sleep(16);
+                    __hip_atomic_store(p.sk_flags + slot_cur, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
+                }
+                BARRIER();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                for (int q = 1; q < p.sk_parts; ++q) {
+                    const float* inp = p.sk_ws + ((size_t)(q - 1) * (size_t)p.sk_tail + (size_t)slot_cur) * (size_t)(T_M * T_N);
+#pragma unroll
+                    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const f32x4* o = (const f32x4*)(inp + (size_t)(srow + 32 * hn + 16 * n + r) * T_N + scol);
+                                const f32x4 a0 = o[0], a1 = o[1];
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) { acc[0][t][hn][n][r] += a0[t]; acc[1][t][hn][n][r] += a1[t]; }
+                            }
+                }
+            }
+        }
         // lane coordinates made opaque per tile: everything the epilogue derives from them (16 row offsets x several
         // leading dimensions) is rebuilt here instead of being hoisted out of the persistent loop into spilled registers
         int erow = frow, egrp = fch;
@@ -693,6 +756,21 @@ template <int KIND, bool LORA, bool BIAS, bool DIAG, bool FP8>
 __global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
     gemm256_body<KIND, LORA, BIAS, DIAG, FP8, 0>(p, ntiles, skew_ticks, stamps);
 }
+template <int KIND, bool LORA, bool BIAS>
+__global__ __launch_bounds__(G256_THREADS) void gemm256_bf16_nt_sk_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
+    gemm256_body<KIND, LORA, BIAS, false, false, 0, true>(p, ntiles, skew_ticks, stamps);
+}
+// the stream-K tail is instantiated for the kinds whose launches have long contractions and few column tiles (N = 768, K = 2304 / 3072: fc2 forward,
+// fc1 dgrad, QKV dgrad of both tower kinds)
+static const void* kernel_ptr_sk(int kind, bool lora, bool bias) {
+    switch (kind) {
+        case EPI_BF16: return bias ? nullptr : lora ? (const void*)gemm256_bf16_nt_sk_kernel<EPI_BF16, true, false> : (const void*)gemm256_bf16_nt_sk_kernel<EPI_BF16, false, false>;
+        case EPI_ADD_AUX: return bias ? nullptr : lora ? (const void*)gemm256_bf16_nt_sk_kernel<EPI_ADD_AUX, true, false> : (const void*)gemm256_bf16_nt_sk_kernel<EPI_ADD_AUX, false, false>;
+        case EPI_RES_F32: return (bias && !lora) ? (const void*)gemm256_bf16_nt_sk_kernel<EPI_RES_F32, false, true> : nullptr;
+        case EPI_RES_F32_DROP: return (bias && !lora) ? (const void*)gemm256_bf16_nt_sk_kernel<EPI_RES_F32_DROP, false, true> : nullptr;
+        default: return nullptr;
+    }
+}
 template <int KIND, int DG = 1>
 __global__ __launch_bounds__(G256_THREADS) void gemm256_fp8_dgrad_kernel(GemmParams p, int ntiles, int skew_ticks, long long* stamps) {
     gemm256_body<KIND, false, false, false, true, DG>(p, ntiles, skew_ticks, stamps);
@@ -903,8 +981,42 @@ bool gemm256_try_launch(const GemmParams& p, hipStream_t stream) {
     if (kind < 0) return false;                                   // an inconsistent fold epilogue (gemm_impl reports it)
     const void* fn = kernel_ptr(kind, lora, p.ep.bias != nullptr, diag);
     if (fn == nullptr) return false;
+    // Stream-K tail (round 6): with a workspace from the caller (clibd_gemm_bf16_nt_ws), a launch whose last round is at most half full and whose
+    // contraction is long cuts that round's tiles into K-slices over the idle CUs
+    q.sk_parts = 0;
+    if (p.sk_ws != nullptr && p.sk_flags != nullptr && !diag) {
+        const SkPlan sk = plan_stream_k_tail(tiles, num_cus, nk);
+        const void* fsk = sk.parts >= 2 ? kernel_ptr_sk(kind, lora, p.ep.bias != nullptr) : nullptr;
+        if (fsk != nullptr) {
+            static const bool sk_attr_ok = [] {
+                bool ok = true;
+                for (int k = 0; k < EPI_NUM_KINDS; ++k)
+                    for (int v = 0; v < 4; ++v) {
+                        const void* f = kernel_ptr_sk(k, (v & 1) != 0, (v & 2) != 0);
+                        if (f != nullptr) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) == hipSuccess;
+                    }
+                return ok;
+            }();
+            if (sk_attr_ok) {
+                q.sk_parts = sk.parts; q.sk_tail = sk.tail; q.sk_first = sk.first; q.sk_nk_part = sk.nk_part;
+                ntiles_i = sk.first + sk.tail * sk.parts;                      // work items: whole tiles, then the tail's slices
+                const int gsk = ntiles_i < num_cus ? ntiles_i : num_cus;
+                if (hipLaunchKernel(fsk, dim3((unsigned)gsk), dim3(G256_THREADS), args, G256_LDS, stream) != hipSuccess) return false;
+                return true;
+            }
+        }
+    }
     if (hipLaunchKernel(fn, dim3((unsigned)grid), dim3(G256_THREADS), args, G256_LDS, stream) != hipSuccess) return false;
     return true;
+}
+
+size_t gemm256_tail_workspace_bytes(int M, int N, int K) {
+    if (M < 1024 || N <= 0 || K <= 0 || N % T_N != 0 || K % T_K != 0) return 0;
+    const long long tiles = (long long)((M + T_M - 1) / T_M) * (N / T_N);
+    if (tiles < 128) return 0;
+    const SkPlan sk = plan_stream_k_tail(tiles, device_cus(), K / T_K);
+    if (sk.parts < 2) return 0;
+    return G256_SK_FLAG_BYTES + (size_t)sk.tail * (size_t)(sk.parts - 1) * (size_t)(T_M * T_N) * sizeof(float);
 }
 
 // Split-K with a partials workspace: partials[s] (fp32 [M, N], row stride N) = A[:, ks] . W[:, ks]^T for K-slice s.

@@ -30,7 +30,38 @@ struct GemmParams {
     // 8-bit dgrad under full fine-tune (round 6): the MUL_AUX forms also write the DE-SCALED value as bf16 (the weight gradient's operand)
     unsigned short* dual_bf16;
     int ld_dual;
+    // Stream-K tail (round 6, gemm256 SK instantiations; clibd_gemm_bf16_nt_ws): the tiles of the LAST, partial round of the persistent grid are cut
+    // into sk_parts K-slices, one work item each.  Work items sk_first .. sk_first + sk_tail * sk_parts - 1 are those slices, non-owners first
+    // (slot j % sk_tail, part 1 + j / sk_tail), owners (part 0) last: a workgroup's id is also its dispatch order, so an owner's partners are
+    // always dispatched before it.  Part q covers K-tiles [q * sk_nk_part, min((q + 1) * sk_nk_part, K / 64)); parts >= 1 store their fp32 partial
+    // tile to sk_ws[((q - 1) * sk_tail + slot) * 65536] and add 1 to sk_flags[slot]; part 0 waits for sk_parts - 1, adds the partials in part
+    // order (fixed order: deterministic), clears the flag and runs the tile's epilogue.  sk_parts == 0: off.
+    int sk_parts, sk_tail, sk_first, sk_nk_part;
+    float* sk_ws;
+    unsigned* sk_flags;
 };
+
+// Host-side plan of the stream-K tail: (parts, tail tiles, first tail item, K-tiles per part); parts == 0 when the launch has no use for it
+// (no partial round, a partial round that is more than half full, or K too short for the slices to pay for their partial stores).
+struct SkPlan { int parts, tail, first, nk_part; };
+inline SkPlan plan_stream_k_tail(long long tiles, int num_cus, int nk) {
+    SkPlan s{0, 0, 0, 0};
+    if (tiles <= 0 || num_cus <= 0 || nk < 24 || (nk & 1)) return s;     // K >= 1536: below that a slice's partial store costs what it saves
+    const long long full = (tiles / num_cus) * num_cus;
+    const int tail = (int)(tiles - full);
+    if (tail == 0 || 2 * tail > num_cus) return s;
+    int P = num_cus / tail;
+    if (P > 4) P = 4;                                                    // (bounds the owner's merge and the workspace: tail * (P - 1) * 256 KiB <= 48 MiB)
+    for (; P >= 2; --P) {
+        int nkp = (nk + P - 1) / P;
+        nkp += nkp & 1;
+        if (nkp < 4) nkp = 4;
+        const int parts = (nk + nkp - 1) / nkp;
+        const int last = nk - (parts - 1) * nkp;
+        if (parts >= 2 && last >= 4 && (long long)parts * tail <= num_cus) { s.parts = parts; s.tail = tail; s.first = (int)full; s.nk_part = nkp; return s; }
+    }
+    return s;
+}
 
 // Inside a wave's 64 output columns, MFMA n-tile t (0..3), MFMA row i (0..15) carries tile-local column
 // 16*(i>>2) + 4*t + (i&3): lane group g = lane>>4 then owns the 16 CONTIGUOUS columns 16g .. 16g+15 (e = 4t + reg).
@@ -523,6 +554,8 @@ inline int plan_k_slices(int nk, int tiles, int num_cus, int* nks_out) {
 
 // host side (gemm256.hip): returns true when the 256x256 kernel took the launch
 bool gemm256_try_launch(const GemmParams& p, hipStream_t stream);
+// bytes of the stream-K tail workspace a launch of this shape can use (0: none): partial tiles + flags
+size_t gemm256_tail_workspace_bytes(int M, int N, int K);
 // fp8 operands (p.fp8, p.col_scale set; K / lda / ldw in bytes): true when launched
 bool gemm256_fp8_launch(const GemmParams& p, hipStream_t stream);
 bool gemm256_fp8_dgrad_launch(const GemmParams& p, hipStream_t stream);

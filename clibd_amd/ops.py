@@ -6,6 +6,7 @@ operands on the host, takes raw pointers and enqueues hand-written gfx950 kernel
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -66,6 +67,11 @@ def derive_seed(base: int, layer: int, site: int) -> int:
     x = (x * 0x846CA68B) & 0xFFFFFFFF
     x ^= x >> 16
     return x
+
+
+_STREAMK = os.environ.get("CLIBD_GEMM_STREAMK", "1") != "0"
+_TAIL_WS_BYTES = 48 * 1024 * 1024 + 1024
+_tail_ws: dict = {}
 
 
 def gemm_nt(
@@ -151,7 +157,20 @@ def gemm_nt(
         check(_lib.load().clibd_gemm_bf16_nt_khole(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, int(k_hole[0]), int(k_hole[1]), C.byref(ep),
                                                    _stream()), "gemm_bf16_nt_khole")
         return
-    check(_lib.load().clibd_gemm_bf16_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, C.byref(ep), _stream()), "gemm_bf16_nt")
+    lib = _lib.load()
+    # Stream-K tail (round 6): launches whose last tile round is at most half full and whose contraction is long take a per-(device, stream) workspace
+    # (zeroed once; 48 MiB + 1 KiB covers every shape) and cut that round's tiles into K-slices over the idle CUs.  CLIBD_GEMM_STREAMK=0 turns it off.
+    if _STREAMK and split_k == 1 and M >= 1024:
+        need = int(lib.clibd_gemm_tail_workspace_bytes(M, N, K))
+        if need > 0:
+            key = (a.device, torch.cuda.current_stream(a.device).cuda_stream)
+            ws = _tail_ws.get(key)
+            if ws is None or ws.numel() < need:
+                ws = torch.zeros((max(need, _TAIL_WS_BYTES),), dtype=torch.uint8, device=a.device)
+                _tail_ws[key] = ws
+            check(lib.clibd_gemm_bf16_nt_ws(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, C.byref(ep), ws.data_ptr(), ws.numel(), _stream()), "gemm_bf16_nt_ws")
+            return
+    check(lib.clibd_gemm_bf16_nt(a.data_ptr(), lda, w.data_ptr(), ldw, M, N, K, C.byref(ep), _stream()), "gemm_bf16_nt")
 
 
 def rowsum_finalize(row_sums: torch.Tensor, eps: float, stats: torch.Tensor) -> None:

@@ -104,6 +104,15 @@ typedef struct clibd_gemm_epilogue {
 
 int clibd_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                        const clibd_gemm_epilogue* ep, void* stream);
+/* ABI 5 — the same with a STREAM-K TAIL workspace.  The 256x256 kernel runs one persistent workgroup per CU; a launch whose last tile round is at most
+ * half full (591 tiles on 256 CUs: 79 in the third round) and whose contraction is long (K >= 1536) cuts that round's tiles into 2-4 K-slices, one per
+ * otherwise idle CU: slices 1.. store fp32 partial tiles to the workspace and raise a flag, slice 0 waits, adds them in a fixed order and runs the
+ * epilogue.  Results are deterministic; rows of those tiles differ from the plain launch's by fp32 summation order only.  workspace:
+ * clibd_gemm_tail_workspace_bytes(M, N, K) bytes (0: this shape has no use for it; <= 48 MiB + 1 KiB), 16-byte aligned, whose first 1 KiB the caller
+ * zeroes ONCE (every launch leaves it zero); one workspace per stream.  NULL workspace, or a kind without the form: the plain launch. */
+size_t clibd_gemm_tail_workspace_bytes(int M, int N, int K);
+int clibd_gemm_bf16_nt_ws(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                          const clibd_gemm_epilogue* ep, void* workspace, size_t workspace_bytes, void* stream);
 /* Same product with the K range [hole_k0, hole_k0 + hole_len) of BOTH operands skipped (multiples of 64; 128x128 kernel):
  * for an A whose column segment meets all-zero weights — the adapters' dt projection reads the q and v segments of dqkv
  * and never touches the k segment (a third of the bytes of a latency/HBM-bound skinny product). */

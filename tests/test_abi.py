@@ -72,6 +72,12 @@ def test_host_side_validation_needs_no_gpu(lib):
     assert b"null" in L.clibd_last_error()
     assert L.clibd_attention_fwd(ctypes.c_void_p(16), 1, 300, 1, None, ctypes.c_void_p(16), 300, 300, None) == -1
     assert L.clibd_softce_workspace_bytes(32, 32, 768) > 32 * 32 * 4
+    # round 6: the stream-K tail plan (256 CUs assumed without a device): 591 tiles = 2 rounds + 79 -> 3 K-slices; 399 tiles (tail 143) and K = 768: none
+    assert L.clibd_gemm_tail_workspace_bytes(50432, 768, 3072) == 1024 + 79 * 2 * 256 * 256 * 4
+    assert L.clibd_gemm_tail_workspace_bytes(50432, 768, 2304) == 1024 + 79 * 2 * 256 * 256 * 4
+    assert L.clibd_gemm_tail_workspace_bytes(34048, 768, 3072) == 0 and L.clibd_gemm_tail_workspace_bytes(50432, 3072, 768) == 0
+    assert L.clibd_gemm_tail_workspace_bytes(403456, 768, 3072) == 1024 + 120 * 1 * 256 * 256 * 4      # the metric's batch: 4 728 tiles = 18 rounds + 120 -> 2 slices
+    assert L.clibd_gemm_tail_workspace_bytes(403456, 768, 3072) <= 48 * 1024 * 1024 + 1024
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -1391,3 +1391,59 @@ def test_key_bank_cache_follows_the_callers_tensor(dev):
     assert torch.equal(i3, i1) and "entry" not in ev._bank_cache
     exact = ev.topk_search(q, keys.to(dev), 5, exact=True)
     assert torch.equal(exact[1], i1)
+
+
+# ----------------------------------------------------------------------------------------------- stream-K tail of the 256x256 GEMM (round 6)
+@pytest.mark.parametrize("M,N,K,parts,tail", [(50432, 768, 3072, 3, 79), (50432, 768, 2304, 3, 79), (43776, 768, 3072, 4, 1), (50400, 768, 3072, 3, 79),
+                                              (22528, 768, 1536, 4, 8)])
+def test_gemm_stream_k_tail_is_exact_and_deterministic(ops, dev, M, N, K, parts, tail):
+    """clibd_gemm_bf16_nt_ws: the last, partial tile round cut into K-slices over the idle CUs (per-rank shapes of the 8-GPU configuration: 591 tiles =
+    2 full rounds + 79 tiles -> 3 slices each).  Integer operands make every product and partial sum exact in fp32, so every epilogue kind that has the
+    form must equal the plain launch BIT FOR BIT (and the fp64 statement where there is one): plain bf16 output, + adapters' rank update, + bf16 aux,
+    bias + fp32 residual, bias -> dropout -> + fp32 residual; ragged M; the flags are back at zero; two runs give the same bits."""
+    from clibd_amd import _lib
+
+    lib = _lib.load()
+    if torch.cuda.get_device_properties(dev).multi_processor_count != 256:
+        pytest.skip("the plan under test is the 256-CU one")
+    need = int(lib.clibd_gemm_tail_workspace_bytes(M, N, K))
+    assert need == 1024 + tail * (parts - 1) * 256 * 256 * 4, need
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randint(-2, 3, (M, K), generator=g).to(BF16).to(dev)
+    w = torch.randint(-2, 3, (N, K), generator=g).to(BF16).to(dev)
+    bias = torch.randint(-4, 5, (N,), generator=g).float().to(dev)
+    res = torch.randint(-8, 9, (M, N), generator=g).float().to(dev)
+    aux = torch.randint(-4, 5, (M, N), generator=g).to(BF16).to(dev)
+    u = torch.zeros((M, 8)); u[:, :4] = torch.randint(-1, 2, (M, 4), generator=g).float(); u[:, 4:] = torch.randint(-1, 2, (M, 4), generator=g).float()
+    v = torch.randint(-1, 2, (N, 8), generator=g).float()
+    u, v = u.to(BF16).to(dev), v.to(BF16).to(dev)
+    drop = ops.Drop(0.1, 4242)
+
+    def run_all():
+        o = {}
+        o["bf16"] = torch.empty((M, N), dtype=BF16, device=dev); ops.gemm_nt(a, w, out_bf16=o["bf16"])
+        o["lora"] = torch.empty((M, N), dtype=BF16, device=dev); ops.gemm_nt(a, w, rank_u=u, rank_v=v, out_bf16=o["lora"])
+        o["add"] = torch.empty((M, N), dtype=BF16, device=dev); ops.gemm_nt(a, w, act=ops.ACT_ADD_AUX, aux=aux, out_bf16=o["add"])
+        o["res"] = torch.empty((M, N), dtype=F32, device=dev); ops.gemm_nt(a, w, bias=bias, residual=res, out_f32=o["res"])
+        o["drop"] = torch.empty((M, N), dtype=F32, device=dev); ops.gemm_nt(a, w, bias=bias, residual=res, out_f32=o["drop"], drop=drop)
+        torch.cuda.synchronize()
+        return o
+
+    assert ops._STREAMK
+    sk1 = run_all()
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    assert key in ops._tail_ws and int(ops._tail_ws[key][:1024].to(torch.int32).sum()) == 0      # every flag is back at zero
+    sk2 = run_all()
+    ops._STREAMK = False
+    try:
+        plain = run_all()
+    finally:
+        ops._STREAMK = True
+    for k in sk1:
+        assert torch.equal(sk1[k], sk2[k]), k
+        assert torch.equal(sk1[k], plain[k]), k
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 700, M)])       # the tail tiles are the LAST tiles of the XCD-ordered walk: check both ends in fp64
+    acc = a[rows.to(dev)].double() @ w.double().T
+    assert torch.equal(sk1["bf16"][rows.to(dev)].double(), acc.float().to(BF16).double())
+    assert torch.equal(sk1["res"][rows.to(dev)].double(), acc + bias.double() + res[rows.to(dev)].double())
+    assert torch.equal(sk1["lora"][rows.to(dev)].double(), (acc + u[rows.to(dev)].double() @ v.double().T).float().to(BF16).double())
