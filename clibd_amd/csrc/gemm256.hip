@@ -420,6 +420,10 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                 const int srow = 64 * wn + 4 * fch, scol = 128 * wm + 8 * frow;   // this lane's 16 rows x 8 columns inside the 256 x 256 tile
                 if (part_cur > 0) {
                     // non-owner: the fp32 partial tile goes to the workspace, then ONE release increment of the slot's flag
+                    // The partials travel with the sc0 sc1 bits (write-through / read-around the per-XCD L2, which is not coherent with the other seven): a
+                    // release / acquire pair at agent scope would write back and invalidate a whole L2 per slice — measured: the first form of this tail,
+                    // built on __ATOMIC_RELEASE / __ATOMIC_ACQUIRE, was 2.4 % SLOWER in-step at b = 256.  Here: coherent stores, vmcnt(0), barrier, ONE
+                    // relaxed agent-scope increment; the owner spins on a relaxed agent-scope load and reads the partials with coherent loads.
                     float* outp = p.sk_ws + ((size_t)(part_cur - 1) * (size_t)p.sk_tail + (size_t)slot_cur) * (size_t)(T_M * T_N);
 #pragma unroll
                     for (int hn = 0; hn < 2; ++hn)
@@ -427,35 +431,40 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                         for (int n = 0; n < 2; ++n)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                f32x4* o = (f32x4*)(outp + (size_t)(srow + 32 * hn + 16 * n + r) * T_N + scol);
-                                o[0] = (f32x4){acc[0][0][hn][n][r], acc[0][1][hn][n][r], acc[0][2][hn][n][r], acc[0][3][hn][n][r]};
-                                o[1] = (f32x4){acc[1][0][hn][n][r], acc[1][1][hn][n][r], acc[1][2][hn][n][r], acc[1][3][hn][n][r]};
+                                float* o = outp + (size_t)(srow + 32 * hn + 16 * n + r) * T_N + scol;
+                                const f32x4 v0 = (f32x4){acc[0][0][hn][n][r], acc[0][1][hn][n][r], acc[0][2][hn][n][r], acc[0][3][hn][n][r]};
+                                const f32x4 v1 = (f32x4){acc[1][0][hn][n][r], acc[1][1][hn][n][r], acc[1][2][hn][n][r], acc[1][3][hn][n][r]};
+                                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" :: "v"(o), "v"(v0), "v"(v1) : "memory");
                             }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    BARRIER();                                      // every wave's stores have left for L2
-                    if (tid == 0) __hip_atomic_fetch_add(p.sk_flags + slot_cur, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    BARRIER();                                      // every wave's stores are acknowledged at the coherence point
+                    if (tid == 0) __hip_atomic_fetch_add(p.sk_flags + slot_cur, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 // owner: wait for the partners (dispatched before this workgroup: see GemmParams), add their partials in part order
                 if (tid == 0) {
-                    while (__hip_atomic_load(p.sk_flags + slot_cur, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.sk_parts - 1)) __builtin_amdgcn_s_sleep(16);
+                    while (__hip_atomic_load(p.sk_flags + slot_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.sk_parts - 1)) __builtin_amdgcn_s_sleep(16);
                     __hip_atomic_store(p.sk_flags + slot_cur, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
                 }
                 BARRIER();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 for (int q = 1; q < p.sk_parts; ++q) {
                     const float* inp = p.sk_ws + ((size_t)(q - 1) * (size_t)p.sk_tail + (size_t)slot_cur) * (size_t)(T_M * T_N);
 #pragma unroll
                     for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
-                        for (int n = 0; n < 2; ++n)
+                        for (int n = 0; n < 2; ++n) {
+                            f32x4 t0[4], t1[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const f32x4* o = (const f32x4*)(inp + (size_t)(srow + 32 * hn + 16 * n + r) * T_N + scol);
-                                const f32x4 a0 = o[0], a1 = o[1];
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) { acc[0][t][hn][n][r] += a0[t]; acc[1][t][hn][n][r] += a1[t]; }
+                                const float* o = inp + (size_t)(srow + 32 * hn + 16 * n + r) * T_N + scol;
+                                asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1" : "=&v"(t0[r]), "=&v"(t1[r]) : "v"(o) : "memory");
                             }
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0[0]), "+v"(t0[1]), "+v"(t0[2]), "+v"(t0[3]), "+v"(t1[0]), "+v"(t1[1]), "+v"(t1[2]), "+v"(t1[3]));
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) { acc[0][t][hn][n][r] += t0[r][t]; acc[1][t][hn][n][r] += t1[r][t]; }
+                        }
                 }
             }
         }
