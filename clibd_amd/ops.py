@@ -69,7 +69,8 @@ def derive_seed(base: int, layer: int, site: int) -> int:
     return x
 
 
-_STREAMK = os.environ.get("CLIBD_GEMM_STREAMK", "1") != "0"
+# Measured in-step (profiles/r06_exp_gemm_stream_k_tail.log): 1.8-2.4 % SLOWER at per-GPU batch 256, 0.4-0.7 % slower at 2048 -> off by default (CLIBD_GEMM_STREAMK=1 turns it on)
+_STREAMK = os.environ.get("CLIBD_GEMM_STREAMK", "0") == "1"
 _TAIL_WS_BYTES = 48 * 1024 * 1024 + 1024
 _tail_ws: dict = {}
 
@@ -159,7 +160,7 @@ def gemm_nt(
         return
     lib = _lib.load()
     # Stream-K tail (round 6): launches whose last tile round is at most half full and whose contraction is long take a per-(device, stream) workspace
-    # (zeroed once; 48 MiB + 1 KiB covers every shape) and cut that round's tiles into K-slices over the idle CUs.  CLIBD_GEMM_STREAMK=0 turns it off.
+    # (zeroed once; 48 MiB + 1 KiB covers every shape) and cut that round's tiles into K-slices over the idle CUs.  Opt-in: see _STREAMK.
     if _STREAMK and split_k == 1 and M >= 1024:
         need = int(lib.clibd_gemm_tail_workspace_bytes(M, N, K))
         if need > 0:

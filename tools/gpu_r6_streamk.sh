@@ -3,7 +3,7 @@
 # 512, 1024 and the metric's 2048.
 set -u
 OUT=gpurun_out/${1:-r6sk}; mkdir -p "$OUT"
-for B in 256 2048 512 1024; do
+for B in ${SK_BATCHES:-256 2048 512 1024}; do
   echo "== per-GPU batch $B ==" >> "$OUT/streamk_ab.log"
   for v in 1 0 1 0 1 0; do
     ST=10; [ $B -le 512 ] && ST=20
