@@ -380,8 +380,28 @@ def test_dgrad8_rule_row_scales_l1_bound_and_sites():
     with O.precision("bf16"):   # outside the mode the same call is the bf16 dgrad (here also exact)
         (dx16,) = torch.autograd.grad((O.olinear(x, w, None, round_out=False, dgrad=("proj", None)) * dy).sum(), x)
     assert torch.equal(dx16, dy @ w)
-    with O.precision("bf16"), O.dgrad8(True), pytest.raises(RuntimeError, match="frozen"):
-        O.olinear(x, w.clone().requires_grad_(True), None, dgrad=("proj", None))
+    # round 6: TRAINABLE base weights (full fine-tune) — the input gradient is still the 8-bit dgrad, the weight gradient the bf16 network's
+    # dy^T x on bf16-rounded operands (here exact: integers x e4m3-representable values of x rounded to bf16)
+    wt = w.clone().requires_grad_(True)
+    with O.precision("bf16"), O.dgrad8(True):
+        yt = O.olinear(x, wt, None, round_out=False, dgrad=("proj", None))
+        dxt, dwt = torch.autograd.grad((yt * dy).sum(), (x, wt))
+    assert torch.equal(dxt, dy @ w)
+    assert torch.equal(dwt, dy.t() @ x.detach().to(torch.bfloat16).float())
+    # ... and the per-layer constant of d(fc1 out) carries one binade of headroom then (c2 / 2: engine.TransformerStack.refresh re-derives it every 64 steps only)
+    w2 = torch.randint(-3, 4, (32, 8), generator=g).float() * 0.125          # fc2: [out 32, in 8]
+    h0, dy2 = torch.randn(6, 8, generator=g), torch.randint(-7, 8, (6, 32), generator=g).float()
+    rows = {}
+    for trainable in (False, True):
+        O._DG8_ROWS.clear()
+        w2p = w2.clone().requires_grad_(trainable)
+        h = h0.clone().requires_grad_(True)
+        with O.precision("bf16"), O.dgrad8(True):
+            y2 = O.olinear(h, w2p, None, round_out=False, dgrad=("fc2", w2p))
+            torch.autograd.grad((y2 * dy2).sum(), h)
+        (rows[trainable],) = O._DG8_ROWS.values()      # s_m * c2, left for the fc1 dgrad that follows
+    O._DG8_ROWS.clear()
+    assert torch.equal(rows[True], rows[False] * 0.5) and torch.equal(torch.log2(rows[False]) % 1.0, torch.zeros_like(rows[False]))
     # towers: forward identical, gradients within the mode's noise, fp32 precision ignores the switch
     torch.manual_seed(0)
     enc = O.ImageEncoder(O.VisionTransformer(img_size=32, dim=128, depth=3, heads=2, num_classes=0), 4, 64)
