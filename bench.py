@@ -556,6 +556,7 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
         ms8 = timed_steps()
         share = None
         if timer is not None and not args.no_gemm_timing:
+            kept = (timer.events, timer.flops, timer.flops_fp8, timer.shapes, timer.bytes)     # the headline's per-launch records (--gemm-breakdown prints them later)
             timer.events, timer.flops, timer.flops_fp8, timer.shapes, timer.bytes = [], 0.0, 0.0, [], 0.0
             timer.enabled = True
             trainer.step(batch4["image"], batch4["dna"], None, batch4["labels"])
@@ -563,6 +564,7 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             timer.enabled = False
             r = timer.result()
             share = r["fp8_flop_share"] if r else None
+            timer.events, timer.flops, timer.flops_fp8, timer.shapes, timer.bytes = kept
         def cosines():
             out_ = {}
             for name, bt in (("train_batch", batch4), ("fresh_batch", fresh4)):
