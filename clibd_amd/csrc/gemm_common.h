@@ -277,6 +277,7 @@ __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.act == CLIBD_ACT_MUL_AUX_U8 && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX_U8;
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_E12 && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE_12;
     if (ep.act == CLIBD_ACT_MUL_AUX_E12 && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX_12;
+    if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_E12 || ep.act == CLIBD_ACT_MUL_AUX_E12) return -1;   // any other combination: the 128x128 kernel (the 256x256 kernel declines kind < 0)
     if (ep.act == CLIBD_ACT_NONE && !ep.out_pre_bf16 && ep.residual_f32 && ep.out_f32 && !ep.out_bf16) return drop ? EPI_RES_F32_DROP : EPI_RES_F32;
     return EPI_GENERIC;
 }
@@ -355,11 +356,9 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
         }
     }
     if (KIND == EPI_GENERIC) {
-        if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_E12) {
-            float dg[8];
-            gelu_and_grad_rows<8>(v, dg);
-            *(gelu12_row8*)((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + (nb >> 1) * 3) = gelu12_pack8(dg);
-        } else if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8) {
+        // (the e4m7 forms have no GENERIC path in the 256x256 kernel: with them the generic epilogue's accumulators went to 528 bytes of scratch per lane
+        //  and every generic launch — patch embedding, heads, the whole no-grad forward — ran 3 x slower; epilogue_kind() sends their odd combinations to the 128x128 kernel)
+        if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8) {
             float dg[8];
             gelu_and_grad_rows<8>(v, dg);
             *(uint2*)((unsigned char*)ep.out_pre_bf16 + (size_t)m * ep.ld_pre + nb) =
@@ -383,12 +382,6 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
             geluq_unpack4(c.y, d1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
-        } else if (ep.act == CLIBD_ACT_MUL_AUX_E12) {
-            const gelu12_row8 a = *(const gelu12_row8*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + (nb >> 1) * 3);
-            float d[8];
-            gelu12_unpack8(a.w0, a.w1, a.w2, d);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= d[e];
         } else if (ep.act == CLIBD_ACT_GELU_GRAD || ep.act == CLIBD_ACT_MUL_AUX || ep.act == CLIBD_ACT_ADD_AUX) {
             const uint4 x0 = *(const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
             const unsigned xs[4] = {x0.x, x0.y, x0.z, x0.w};

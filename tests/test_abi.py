@@ -1,6 +1,7 @@
 """CPU checks of the drop-in boundary: the C-ABI library builds, loads, and exports exactly what
 include/clibd_hip.h declares (no compute calls here: there is no GPU on the authoring box)."""
 import ctypes
+import os
 import re
 from pathlib import Path
 
@@ -103,3 +104,31 @@ def test_gemm256_asynchronous_operands_are_not_touched_before_their_wait():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main() == 0
+
+
+def test_gemm256_kernels_use_no_scratch():
+    """Tripwire (round 6): every instantiation of the 256x256 GEMM keeps its 128 accumulators in registers.  A generic-epilogue branch that took a
+    local array by pointer once demoted them to 528 bytes of scratch per lane — no 'VGPRs Spill' in the report, no test failing, and every generic
+    launch (patch embedding, heads, the whole no-grad forward) 3 x slower.  hipcc cross-compiles without a GPU: ~1 minute."""
+    import re
+    import subprocess
+
+    from clibd_amd import build
+
+    src = build.CSRC / "gemm256.hip"
+    r = subprocess.run([build._hipcc(), f"--offload-arch={build.ARCH}", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-c", str(src),
+                        "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name, seen, bad = None, 0, []
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark:\s+(Function Name|ScratchSize \[bytes/lane\]):\s*(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "Function Name":
+            name = m.group(2)
+        elif name and "gemm256" in name:
+            seen += 1
+            if int(m.group(2)) != 0:
+                bad.append((name, int(m.group(2))))
+    assert seen >= 40, seen
+    assert not bad, bad
