@@ -509,7 +509,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, int ntiles, in
                     } else if constexpr (KIND == EPI_MUL_AUX_12) {
                         in_aux[4 * n + r] = load_aux12((const unsigned char*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + (nb >> 1) * 3);
                     } else if constexpr (epi_aux_kind(KIND)) {
-                        in_aux[4 * n + r] = load_aux16((const unsigned short*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
+                        in_aux[4 * n + r] = load_aux16<epi_aux_nt(KIND)>((const unsigned short*)ep.aux_bf16 + (size_t)mc * ep.ld_aux + nb);
                     } else {
                         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)mc * ep.ld_res + nb);
                         in_res[4 * n + r][0] = rs[0];

@@ -482,15 +482,21 @@ __device__ __forceinline__ float row16_sum(float x) {
 // The 16-byte aux load of the MUL_AUX / ADD_AUX epilogues (gelu' / a residual-gradient stream: read ONCE, never again) carries the non-temporal
 // hint (round 6), so that the stream does not displace the A / W panels the workgroups of an XCD share in L2: FETCH_SIZE of the fc2 dgrad x gelu'
 // launch 6.37 -> 5.76 GB, step -0.14 % in an interleaved same-box A/B (profiles/r06_exp_nt_aux_loads.log).  -DCLIBD_PLAIN_AUX_LOADS builds the A/B partner.
+// NT = false: the ADD_AUX stream (a residual gradient the preceding LayerNorm backward has just written: per-kernel times put the hint at +3 % there).
+template <bool NT>
 __device__ __forceinline__ uint4 load_aux16(const void* p) {
     typedef unsigned aux_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CLIBD_PLAIN_AUX_LOADS
-    const aux_u32x4 v = __builtin_nontemporal_load((const aux_u32x4*)p);
+    const aux_u32x4 v = NT ? __builtin_nontemporal_load((const aux_u32x4*)p) : *(const aux_u32x4*)p;
 #else
     const aux_u32x4 v = *(const aux_u32x4*)p;
 #endif
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
+#ifndef CLIBD_NT_ADD_AUX
+#define CLIBD_NT_ADD_AUX 0
+#endif
+constexpr bool epi_aux_nt(int kind) { return kind != EPI_ADD_AUX || CLIBD_NT_ADD_AUX; }
 
 // the 12-byte row piece of the e4m7 gelu' form (eight columns), non-temporal like load_aux16
 __device__ __forceinline__ uint4 load_aux12(const void* p) {
@@ -513,7 +519,7 @@ __device__ __forceinline__ void fold_row8(const clibd_gemm_epilogue& ep, int m, 
     } else if (KIND == EPI_MUL_AUX_12) {
         ax = load_aux12((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + (nb >> 1) * 3);
     } else if (KIND == EPI_MUL_AUX || KIND == EPI_ADD_AUX) {
-        ax = load_aux16((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
+        ax = load_aux16<epi_aux_nt(KIND)>((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
     } else {
         const f32x4* rs = (const f32x4*)(ep.residual_f32 + (size_t)m * ep.ld_res + nb);
         r0 = rs[0];
