@@ -106,29 +106,44 @@ def test_gemm256_asynchronous_operands_are_not_touched_before_their_wait():
     assert mod.main() == 0
 
 
-def test_gemm256_kernels_use_no_scratch():
-    """Tripwire (round 6): every instantiation of the 256x256 GEMM keeps its 128 accumulators in registers.  A generic-epilogue branch that took a
-    local array by pointer once demoted them to 528 bytes of scratch per lane — no 'VGPRs Spill' in the report, no test failing, and every generic
-    launch (patch embedding, heads, the whole no-grad forward) 3 x slower.  hipcc cross-compiles without a GPU: ~1 minute."""
-    import re
+def test_hot_kernels_use_no_scratch():
+    """Tripwire (round 6): every kernel of the hot units keeps its working set in registers.  A generic-epilogue branch that took a local array by
+    pointer once demoted the 256x256 GEMM's 128 accumulators to 528 bytes of scratch per lane — no 'VGPRs Spill' in the compiler's report, no test
+    failing, and every generic launch (patch embedding, heads, the whole no-grad forward) 3 x slower.  hipcc cross-compiles without a GPU; the
+    units compile in parallel (~75 s).  Allowed: the six attention instantiations whose 2-10 spilled registers were measured faster than their
+    spill-free alternatives (profiles/r06_exp_attention_spills.log), none of them on the metric's path."""
+    import concurrent.futures as cf
     import subprocess
 
     from clibd_amd import build
 
-    src = build.CSRC / "gemm256.hip"
-    r = subprocess.run([build._hipcc(), f"--offload-arch={build.ARCH}", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-c", str(src),
-                        "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    name, seen, bad = None, 0, []
-    for line in r.stderr.splitlines():
-        m = re.search(r"remark:\s+(Function Name|ScratchSize \[bytes/lane\]):\s*(\S+)", line)
-        if not m:
-            continue
-        if m.group(1) == "Function Name":
-            name = m.group(2)
-        elif name and "gemm256" in name:
-            seen += 1
-            if int(m.group(2)) != 0:
-                bad.append((name, int(m.group(2))))
-    assert seen >= 40, seen
+    allowed = {   # mangled-name fragment -> scratch bytes per lane it may use
+        "attention_fwd_persistent_kernelILi14ELb1ELb1E": 20, "attention_fwd_persistent_kernelILi16ELb1ELb1E": 44, "attention_fwd_persistent_kernelILi16ELb0ELb1E": 12,
+        "attention_bwd_kernelILi10ELb0ELb0ELb1ELi4ELi160E": 28, "attention_bwd_kernelILi10ELb0ELb0ELb0ELi4ELi160E": 28, "attention_bwd_kernelILi16ELb1ELb0ELb1ELi4ELi256E": 44,
+    }
+
+    def report(unit):
+        r = subprocess.run([build._hipcc(), f"--offload-arch={build.ARCH}", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-c",
+                            str(build.CSRC / f"{unit}.hip"), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out, name = [], None
+        for line in r.stderr.splitlines():
+            m = re.search(r"remark:\s+(Function Name|ScratchSize \[bytes/lane\]):\s*(\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "Function Name":
+                name = m.group(2)
+            elif name:
+                out.append((name, int(m.group(2))))
+        return out
+
+    units = ["gemm256", "attention", "layernorm", "lora", "gemm", "gemm256_tn", "loss"]
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        rows = [r for res in ex.map(report, units) for r in res]
+    assert sum(1 for n, _ in rows if "gemm256" in n) >= 40 and len(rows) >= 120, len(rows)
+    bad = []
+    for name, scratch in rows:
+        cap = max([v for k, v in allowed.items() if k in name] or [0])
+        if scratch > cap:
+            bad.append((name, scratch, cap))
     assert not bad, bad
