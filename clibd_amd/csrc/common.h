@@ -196,6 +196,16 @@ __device__ __forceinline__ void gelu_and_grad_rows(float* v, float* dg) {
         dg[e] = d[0]; dg[e + 1] = d[1];
     }
 }
+// v[0..N) -> gelu(v), pairwise on the packed form (no bf16 rounding of the argument: CLIBD_ACT_GELU's contract); the unused gelu' folds away
+template <int N>
+__device__ __forceinline__ void gelu_rows(float* v) {
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+        f32x2 y, d;
+        gelu_and_grad_x2((f32x2){v[e], v[e + 1]}, y, d);
+        v[e] = y[0]; v[e + 1] = y[1];
+    }
+}
 // gelu'(x) lies in [-0.1290, 1.1290]: kept for the backward as ONE BYTE, code = rint((g' - LO) / STEP) over [LO, LO + 255 STEP]
 // (|error| <= STEP / 2 = 2.5e-3; bf16's SPACING is 3.9e-3 in [0.5, 1) and 7.8e-3 in [1, 2), i.e. a rounding error of at most half of
 // that: 2.0e-3 / 3.9e-3 — the figures engine.py quotes).  CLIBD_ACT_GELU_SAVE_GRAD_U8 writes

@@ -159,8 +159,7 @@ __device__ __forceinline__ void store_row16(const clibd_gemm_epilogue& ep, int m
         for (int e = 0; e < 16; ++e) v[e] = bfround(v[e]);
     }
     if (ep.act == CLIBD_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+        gelu_rows<16>(v);
     } else if (ep.act == CLIBD_ACT_GELU_GRAD) {
         const uint4* ax = (const uint4*)((const unsigned short*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
         const uint4 x0 = ax[0], x1 = ax[1];
@@ -257,7 +256,8 @@ enum : int {
     EPI_ROWNORM_GELU = 11,    // rstd_m (acc - mean_m s_n) + b'_n -> EPI_GELU_SAVE                  (LN -> Linear fold, consumer: ViT fc1)
     EPI_GELU_SAVE_12 = 12,    // EPI_GELU_SAVE with gelu' as the 12-bit e4m7 form of its bf16 value (common.h gelu12_*; numerics gelu_grad="e4m7")
     EPI_MUL_AUX_12 = 13,      // EPI_MUL_AUX reading that form
-    EPI_NUM_KINDS = 14,
+    EPI_GELU = 14,            // [bias] -> gelu -> out_bf16: fc1 of the NO-GRAD forward (eval: no gelu' to save); round 6 — it ran on the generic kind before
+    EPI_NUM_KINDS = 15,
 };
 constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX || kind == EPI_MUL_AUX_U8 || kind == EPI_MUL_AUX_12; }
 constexpr bool epi_mul_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_MUL_AUX_U8 || kind == EPI_MUL_AUX_12; }
@@ -271,6 +271,7 @@ __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
         return (ep.act == CLIBD_ACT_GELU_SAVE_GRAD && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && !ep.rank_u && ep.bias && ep.col_sum_w) ? EPI_ROWNORM_GELU : -1;
     if (ep.act == CLIBD_ACT_NONE && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_BF16;
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE;
+    if (ep.act == CLIBD_ACT_GELU && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU;
     if (ep.act == CLIBD_ACT_MUL_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX;
     if (ep.act == CLIBD_ACT_ADD_AUX && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_ADD_AUX;
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_U8 && !drop && ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16) return EPI_GELU_SAVE_U8;
@@ -287,6 +288,11 @@ __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
 template <int KIND>
 __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
     if (KIND == EPI_BF16) {
+        *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
+    if (KIND == EPI_GELU) {   // the generic form's arithmetic (gelu of the fp32 value, no bf16 rounding of the pre-activation), on packed pairs
+        gelu_rows<8>(v);
         *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
         return;
     }
@@ -373,8 +379,7 @@ __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m,
             for (int e = 0; e < 8; ++e) v[e] = bfround(v[e]);
         }
         if (ep.act == CLIBD_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            gelu_rows<8>(v);
         } else if (ep.act == CLIBD_ACT_MUL_AUX_U8) {
             const uint2 c = *(const uint2*)((const unsigned char*)ep.aux_bf16 + (size_t)m * ep.ld_aux + nb);
             float d0[4], d1[4];
