@@ -816,6 +816,7 @@ static const void* kernel_ptr(int kind, bool lora, bool bias, bool diag) {
         case EPI_BF16: return K256(EPI_BF16);
         case EPI_GELU_SAVE: return K256(EPI_GELU_SAVE);
         case EPI_GELU: return K256(EPI_GELU);
+        case EPI_F32: return K256(EPI_F32);
         case EPI_MUL_AUX: return K256(EPI_MUL_AUX);
         case EPI_ADD_AUX: return K256(EPI_ADD_AUX);
         case EPI_GELU_SAVE_U8: return K256(EPI_GELU_SAVE_U8);

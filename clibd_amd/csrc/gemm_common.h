@@ -257,7 +257,8 @@ enum : int {
     EPI_GELU_SAVE_12 = 12,    // EPI_GELU_SAVE with gelu' as the 12-bit e4m7 form of its bf16 value (common.h gelu12_*; numerics gelu_grad="e4m7")
     EPI_MUL_AUX_12 = 13,      // EPI_MUL_AUX reading that form
     EPI_GELU = 14,            // [bias] -> gelu -> out_bf16: fc1 of the NO-GRAD forward (eval: no gelu' to save); round 6 — it ran on the generic kind before
-    EPI_NUM_KINDS = 15,
+    EPI_F32 = 15,             // [bias] -> out_f32: patch embedding, the MLM head's dgrad into the fp32 residual-gradient entry (generic kind before round 6)
+    EPI_NUM_KINDS = 16,
 };
 constexpr bool epi_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_ADD_AUX || kind == EPI_MUL_AUX_U8 || kind == EPI_MUL_AUX_12; }
 constexpr bool epi_mul_aux_kind(int kind) { return kind == EPI_MUL_AUX || kind == EPI_MUL_AUX_U8 || kind == EPI_MUL_AUX_12; }
@@ -280,6 +281,7 @@ __host__ __device__ inline int epilogue_kind(const clibd_gemm_epilogue& ep) {
     if (ep.act == CLIBD_ACT_MUL_AUX_E12 && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && !ep.out_f32 && ep.out_bf16 && ep.aux_bf16) return EPI_MUL_AUX_12;
     if (ep.act == CLIBD_ACT_GELU_SAVE_GRAD_E12 || ep.act == CLIBD_ACT_MUL_AUX_E12) return -1;   // any other combination: the 128x128 kernel (the 256x256 kernel declines kind < 0)
     if (ep.act == CLIBD_ACT_NONE && !ep.out_pre_bf16 && ep.residual_f32 && ep.out_f32 && !ep.out_bf16) return drop ? EPI_RES_F32_DROP : EPI_RES_F32;
+    if (ep.act == CLIBD_ACT_NONE && !drop && !ep.out_pre_bf16 && !ep.residual_f32 && ep.out_f32 && !ep.out_bf16) return EPI_F32;
     return EPI_GENERIC;
 }
 
@@ -289,6 +291,12 @@ template <int KIND>
 __device__ __forceinline__ void store_row8(const clibd_gemm_epilogue& ep, int m, int nb, float v[8]) {
     if (KIND == EPI_BF16) {
         *(uint4*)((unsigned short*)ep.out_bf16 + (size_t)m * ep.ld_out_bf16 + nb) = pack8bf(v);
+        return;
+    }
+    if (KIND == EPI_F32) {
+        f32x4* o = (f32x4*)(ep.out_f32 + (size_t)m * ep.ld_out_f32 + nb);
+        o[0] = (f32x4){v[0], v[1], v[2], v[3]};
+        o[1] = (f32x4){v[4], v[5], v[6], v[7]};
         return;
     }
     if (KIND == EPI_GELU) {   // the generic form's arithmetic (gelu of the fp32 value, no bf16 rounding of the pre-activation), on packed pairs

@@ -1448,3 +1448,29 @@ def test_gemm_stream_k_tail_is_exact_and_deterministic(ops, dev, M, N, K, parts,
     assert torch.equal(sk1["bf16"][rows.to(dev)].double(), acc.float().to(BF16).double())
     assert torch.equal(sk1["res"][rows.to(dev)].double(), acc + bias.double() + res[rows.to(dev)].double())
     assert torch.equal(sk1["lora"][rows.to(dev)].double(), (acc + u[rows.to(dev)].double() @ v.double().T).float().to(BF16).double())
+
+
+def test_gemm256_f32_and_nograd_gelu_kinds(ops, dev):
+    """Round 6: two epilogue forms that ran on the generic kind of the 256x256 kernel have their own instantiations — [bias ->] fp32 output (patch
+    embedding, the MLM head's dgrad) and bias -> GELU -> bf16 (fc1 of the no-grad forward).  Exact on integers / equal to the 128x128 kernel's GELU."""
+    M, N, K = 4096, 3072, 768            # 192 tiles: the 256x256 kernel
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    ref = a.double() @ w.double().T
+    out = torch.empty((M, N), dtype=F32, device=dev)
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), bias=bias.to(dev), out_f32=out)
+    assert torch.equal(out.cpu().double(), ref + bias.double())
+    ops.gemm_nt(a.to(dev, BF16), w.to(dev, BF16), out_f32=out)
+    assert torch.equal(out.cpu().double(), ref)
+    # GELU form against torch on the exact pre-activation, and against the 128x128 kernel (same arithmetic on a shape the 256x256 kernel declines)
+    a2, w2 = (a * 0.0625).to(dev, BF16), (w * 0.0625).to(dev, BF16)
+    b2 = (bias * 0.25).to(dev)
+    o16 = torch.empty((M, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a2, w2, bias=b2, act=ops.ACT_GELU, out_bf16=o16)
+    pre = (ref * 0.0625 * 0.0625 + bias.double() * 0.25).float()
+    assert rel_err(o16.float().cpu(), gelu(pre)) < 3e-3
+    small = torch.empty((512, N), dtype=BF16, device=dev)
+    ops.gemm_nt(a2[:512], w2, bias=b2, act=ops.ACT_GELU, out_bf16=small)       # M < 1024: the 128x128 kernel
+    assert torch.equal(small, o16[:512])
