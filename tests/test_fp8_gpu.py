@@ -454,11 +454,11 @@ def test_fp8_gradients_on_spread_embeddings(dev):
         elif k[2] == "dgrad8(all)":
             assert c >= 0.98 and de == 0.0 and dd == 0.0, (k, c, de, dd)   # + the ViT's: 0.9892 - 0.9990
         elif k[2] in ("pooled_ffn", "pooled_ffn+dgrad8(pooled)"):
-            assert c >= 0.98 and de == 0.0 and dd < 3e-2, (k, c, de, dd)   # fp8 forward on the pooled towers' MLP pair [+ their 8-bit dgrad]: 0.9896 - 0.9997
+            assert c >= 0.98 and de == 0.0 and dd < 3e-2, (k, c, de, dd)   # fp8 forward on the pooled towers' MLP pair [+ their 8-bit dgrad]: 0.9896 - 0.9999 over two trees' trajectories (profiles/r06_fp8_fidelity_final_tree.log)
         elif k[2] == "pooled_ffn+dgrad8(all)":
             assert c >= 0.97 and de == 0.0 and dd < 3e-2, (k, c, de, dd)   # NOT training-grade: 0.9779 on the unseen batch after 40 steps
         elif k[2] in ("pooled", "pooled+dgrad8(pooled)"):
-            assert c >= 0.97 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # NOT training-grade (round 4's selection): 0.9770 on the unseen batch after 40 steps
+            assert c >= 0.97 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # NOT training-grade (round 4's selection): 0.9770 / 0.9837 on the unseen batch after 40 steps (two trees)
         elif k[2] == "pooled+dgrad8(all)":
             assert c >= 0.96 and de == 0.0 and dd < 6e-2, (k, c, de, dd)   # NOT training-grade: 0.9655
         else:
