@@ -542,7 +542,12 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
                 tw.grad_sink = sk
 
     def set_mode(on):
-        model.enable_fp8_dgrad(towers="pooled", enabled=on)
+        """False: bf16.  True: the recommended mode.  "dgrad_all": bf16 forward, 8-bit dgrad on BOTH towers (the fastest mode that holds the 0.98 gate)."""
+        if on == "dgrad_all":
+            model.enable_fp8_forward(enabled=False)
+            model.enable_fp8_dgrad(towers="all", enabled=True)
+            return
+        model.enable_fp8_dgrad(towers="pooled", enabled=bool(on))
         if with_full:
             return      # trainable base weights: the 8-bit dgrad only (the fp8 FORWARD needs frozen weights: its weight gradients would want bf16 GEMM inputs)
         if on:
@@ -550,10 +555,17 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
         else:
             model.enable_fp8_forward(enabled=False)
 
+    second = not with_full      # the ViT's 8-bit dgrad exists for frozen base weights only
+
     try:
         ms16 = timed_steps()
         set_mode(True)
         ms8 = timed_steps()
+        ms8b = None
+        if second:
+            set_mode("dgrad_all")
+            ms8b = timed_steps()
+            set_mode(True)
         share = None
         if timer is not None and not args.no_gemm_timing:
             kept = (timer.events, timer.flops, timer.flops_fp8, timer.shapes, timer.bytes)     # the headline's per-launch records (--gemm-breakdown prints them later)
@@ -570,9 +582,14 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             for name, bt in (("train_batch", batch4), ("fresh_batch", fresh4)):
                 set_mode(True)
                 g8 = grad_vector(bt)
+                if second:
+                    set_mode("dgrad_all")
+                    g8b = grad_vector(bt)
                 set_mode(False)
                 g16 = grad_vector(bt)
                 out_[name] = float((g8 @ g16) / (g8.norm() * g16.norm()).clamp_min(1e-300))
+                if second:
+                    out_["dgrad_all_" + name] = float((g8b @ g16) / (g8b.norm() * g16.norm()).clamp_min(1e-300))
             return out_
 
         def spread_of(bt):
@@ -621,10 +638,11 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             pass
         return {"error": repr(e)}
     if world > 1:   # one number per job: the worst rank's cosine
-        c = torch.tensor([cos["train_batch"], cos["fresh_batch"], cos_raw["train_batch"], cos_raw["fresh_batch"]], dtype=torch.float64, device=dev)
+        keys = ["train_batch", "fresh_batch"] + (["dgrad_all_train_batch", "dgrad_all_fresh_batch"] if second else [])
+        c = torch.tensor([cos[k] for k in keys] + [cos_raw[k] for k in keys], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.MIN)
-        cos = {"train_batch": float(c[0]), "fresh_batch": float(c[1])}
-        cos_raw = {"train_batch": float(c[2]), "fresh_batch": float(c[3])}
+        cos = {k: float(c[i]) for i, k in enumerate(keys)}
+        cos_raw = {k: float(c[len(keys) + i]) for i, k in enumerate(keys)}
     return {"workload": f"BASELINE configs[4] per-rank shape: {world} GPU x {b4} pairs (global {world * b4}), Image+DNA, " +
                         ("FULL fine-tune" if with_full else "LoRA r=4") + ", train mode",
             "per_gpu_batch": b4, "global_batch": world * b4, "steps": nsteps,
@@ -637,7 +655,14 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
                              "weight gradient stay bf16"),
                     "fp8_flop_share": share},
             "speedup": ms16 / ms8,
-            "gradient_cosine_vs_bf16": dict(cos, spread_steps=spread_steps, image_embedding_mutual_cosine=spread_after,
+            **({"fp8_dgrad_all": {"ms_per_step": ms8b, "value": world * b4 / (ms8b * 1e-3), "unit": "paired samples/s", "speedup": ms16 / ms8b,
+                                  "mode": "--dgrad fp8 (bf16 forward): e4m3 operands on the MLP / projection activation-gradient GEMMs of BOTH towers (per-row power-of-two "
+                                          "scales); every forward GEMM, attention, QKV and every weight gradient stay bf16 — the fastest mode whose gradient holds the 0.98 gate "
+                                          "(tests/test_fp8_gpu.py: dgrad8(all))",
+                                  "gradient_cosine_vs_bf16": {"train_batch": cos["dgrad_all_train_batch"], "fresh_batch": cos["dgrad_all_fresh_batch"],
+                                                              "as_timed": {"train_batch": cos_raw["dgrad_all_train_batch"], "fresh_batch": cos_raw["dgrad_all_fresh_batch"]}}}}
+               if second else {}),
+            "gradient_cosine_vs_bf16": dict({k: v for k, v in cos.items() if not k.startswith("dgrad_all_")}, spread_steps=spread_steps, image_embedding_mutual_cosine=spread_after,
                                             as_timed={"train_batch": cos_raw["train_batch"], "fresh_batch": cos_raw["fresh_batch"], "image_embedding_mutual_cosine": spread_raw}),
             "note": "same model, same process, measured after the headline passes; gradient_cosine = cos(fp8-mode gradient, bf16 gradient) over ALL trainable "
                     "tensors, same dropout masks, on the configs4 training batch (its first 32 pairs are the spreading phase's) and on a batch never seen, at per-GPU "

@@ -55,6 +55,10 @@ def test_bench_prints_exactly_one_json_line(forced):
     assert 0.5 < gc["train_batch"] <= 1.0 and 0.5 < gc["fresh_batch"] <= 1.0 and gc["spread_steps"] == 40
     assert 0.5 < gc["as_timed"]["train_batch"] <= 1.0 and 0.5 < gc["as_timed"]["fresh_batch"] <= 1.0
     assert gc["image_embedding_mutual_cosine"] < gc["as_timed"]["image_embedding_mutual_cosine"] <= 1.0    # the spreading phase spread the embeddings
+    # ... and the fastest mode that holds the 0.98 gate: bf16 forward with the 8-bit dgrad on both towers
+    da = c4["fp8_dgrad_all"]
+    assert da["ms_per_step"] > 0 and da["speedup"] > 0 and "--dgrad fp8" in da["mode"]
+    assert 0.5 < da["gradient_cosine_vs_bf16"]["train_batch"] <= 1.0 and 0.5 < da["gradient_cosine_vs_bf16"]["fresh_batch"] <= 1.0
     num2 = d["config"]["numerics"]
     assert all(v["forward"] == "bf16" and v["dgrad"] == "bf16" for v in num2.values())   # the side record switched its mode off again
     if forced == "1":
