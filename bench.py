@@ -547,6 +547,10 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             model.enable_fp8_forward(enabled=False)
             model.enable_fp8_dgrad(towers="all", enabled=True)
             return
+        if on == "ffn_dgrad_all":        # the recommended forward selection with the 8-bit dgrad on both towers: the fastest combination measured
+            model.enable_fp8_dgrad(towers="all", enabled=True)
+            model.enable_fp8_forward(calibration_inputs=(batch4["image"], batch4["dna"], None), towers="pooled_ffn")
+            return
         model.enable_fp8_dgrad(towers="pooled", enabled=bool(on))
         if with_full:
             return      # trainable base weights: the 8-bit dgrad only (the fp8 FORWARD needs frozen weights: its weight gradients would want bf16 GEMM inputs)
@@ -561,10 +565,12 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
         ms16 = timed_steps()
         set_mode(True)
         ms8 = timed_steps()
-        ms8b = None
+        ms8b = ms8c = None
         if second:
             set_mode("dgrad_all")
             ms8b = timed_steps()
+            set_mode("ffn_dgrad_all")
+            ms8c = timed_steps()
             set_mode(True)
         share = None
         if timer is not None and not args.no_gemm_timing:
@@ -585,11 +591,14 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
                 if second:
                     set_mode("dgrad_all")
                     g8b = grad_vector(bt)
+                    set_mode("ffn_dgrad_all")
+                    g8c = grad_vector(bt)
                 set_mode(False)
                 g16 = grad_vector(bt)
                 out_[name] = float((g8 @ g16) / (g8.norm() * g16.norm()).clamp_min(1e-300))
                 if second:
                     out_["dgrad_all_" + name] = float((g8b @ g16) / (g8b.norm() * g16.norm()).clamp_min(1e-300))
+                    out_["ffn_dgrad_all_" + name] = float((g8c @ g16) / (g8c.norm() * g16.norm()).clamp_min(1e-300))
             return out_
 
         def spread_of(bt):
@@ -638,7 +647,7 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             pass
         return {"error": repr(e)}
     if world > 1:   # one number per job: the worst rank's cosine
-        keys = ["train_batch", "fresh_batch"] + (["dgrad_all_train_batch", "dgrad_all_fresh_batch"] if second else [])
+        keys = ["train_batch", "fresh_batch"] + (["dgrad_all_train_batch", "dgrad_all_fresh_batch", "ffn_dgrad_all_train_batch", "ffn_dgrad_all_fresh_batch"] if second else [])
         c = torch.tensor([cos[k] for k in keys] + [cos_raw[k] for k in keys], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.MIN)
         cos = {k: float(c[i]) for i, k in enumerate(keys)}
@@ -660,9 +669,13 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
                                           "scales); every forward GEMM, attention, QKV and every weight gradient stay bf16 — the fastest mode whose gradient holds the 0.98 gate "
                                           "(tests/test_fp8_gpu.py: dgrad8(all))",
                                   "gradient_cosine_vs_bf16": {"train_batch": cos["dgrad_all_train_batch"], "fresh_batch": cos["dgrad_all_fresh_batch"],
-                                                              "as_timed": {"train_batch": cos_raw["dgrad_all_train_batch"], "fresh_batch": cos_raw["dgrad_all_fresh_batch"]}}}}
+                                                              "as_timed": {"train_batch": cos_raw["dgrad_all_train_batch"], "fresh_batch": cos_raw["dgrad_all_fresh_batch"]}}},
+                "fp8_ffn_dgrad_all": {"ms_per_step": ms8c, "value": world * b4 / (ms8c * 1e-3), "unit": "paired samples/s", "speedup": ms16 / ms8c,
+                                      "mode": "--fp8-forward pooled_ffn --dgrad fp8: the recommended forward selection with the 8-bit dgrad on both towers",
+                                      "gradient_cosine_vs_bf16": {"train_batch": cos["ffn_dgrad_all_train_batch"], "fresh_batch": cos["ffn_dgrad_all_fresh_batch"],
+                                                                  "as_timed": {"train_batch": cos_raw["ffn_dgrad_all_train_batch"], "fresh_batch": cos_raw["ffn_dgrad_all_fresh_batch"]}}}}
                if second else {}),
-            "gradient_cosine_vs_bf16": dict({k: v for k, v in cos.items() if not k.startswith("dgrad_all_")}, spread_steps=spread_steps, image_embedding_mutual_cosine=spread_after,
+            "gradient_cosine_vs_bf16": dict({k: v for k, v in cos.items() if not k.startswith(("dgrad_all_", "ffn_dgrad_all_"))}, spread_steps=spread_steps, image_embedding_mutual_cosine=spread_after,
                                             as_timed={"train_batch": cos_raw["train_batch"], "fresh_batch": cos_raw["fresh_batch"], "image_embedding_mutual_cosine": spread_raw}),
             "note": "same model, same process, measured after the headline passes; gradient_cosine = cos(fp8-mode gradient, bf16 gradient) over ALL trainable "
                     "tensors, same dropout masks, on the configs4 training batch (its first 32 pairs are the spreading phase's) and on a batch never seen, at per-GPU "

@@ -473,6 +473,58 @@ def test_fp8_gradients_on_spread_embeddings(dev):
             assert out[(stage, name, "pooled_mlp")][0] >= out[(stage, name, "all")][0] - 0.05, (stage, name, out[(stage, name, "pooled_mlp")][0], out[(stage, name, "all")][0])
 
 
+def test_fp8_gradient_fidelity_against_the_batch_size(dev):
+    """Round 6: what the gradient cosine of each configs[4] mode is AT configs[4]'s batch.  The 8-bit dgrad rounds every gradient row on its own
+    (per-row power-of-two scales, round to nearest): its error is independent from row to row and averages out over the batch the parameter
+    gradient sums over; the fp8 FORWARD moves a sample's embedding, which the loss sees coherently — that error does not average.  So the 32-pair
+    protocol of the test above is the pessimistic end for every mode with an 8-bit dgrad: on an unseen batch of 512 pairs (same trained adapters)
+    dgrad8(all) reads >= 0.995 and pooled_ffn + dgrad8(all) — 0.978-0.980 at 32 pairs, "not training-grade" there — passes 0.98.  bench.py's
+    `configs4` record measures the same three modes in-run at per-GPU batch 1024 (+7.7 % at 0.9885, +9.2 % at 0.9988, +13.5 % at 0.9874)."""
+    from clibd_amd.data import synthetic_batch
+    from clibd_amd.model import ClipLoss
+    from clibd_amd.train import Trainer
+
+    model = _full_size_pair(dev)
+    batch = synthetic_batch(32, dev, seed=3, rank=0, with_text=False)
+    tr = Trainer(model, lr=1e-3, world_size=1, rank=0, all_gather=True)
+    crit = ClipLoss(local_loss=False, gather_with_grad=True, rank=0, world_size=1, criterion=torch.nn.CrossEntropyLoss())
+    losses = [float(tr.step(batch["image"], batch["dna"], None, batch["labels"])) for _ in range(40)]
+    assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
+    for tw in (model.image_encoder.tower(), model.dna_encoder.tower()):
+        tw.grad_sink = None
+
+    def grads(bt):
+        torch.manual_seed(77)            # the same dropout masks in every mode
+        hi, hd, _, scale, _ = model(bt["image"], bt["dna"], None)
+        g = _named_grads(model, crit(hi, hd, None, bt["labels"], scale))
+        model.join_streams()
+        torch.cuda.synchronize()
+        names = sorted(g)
+        return torch.cat([g[n].flatten().double() for n in names])
+
+    MODES = (("pooled_ffn", "pooled", "pooled_ffn+dgrad8(pooled)"), (None, "all", "dgrad8(all)"), ("pooled_ffn", "all", "pooled_ffn+dgrad8(all)"))
+    res = {}
+    for B in (32, 128, 512):
+        bt = synthetic_batch(B, dev, seed=11, rank=0, with_text=False)      # never seen by the 40 steps
+        model.enable_fp8_forward(enabled=False)
+        model.enable_fp8_dgrad(enabled=False)
+        g16 = grads(bt)
+        for fwd, dg, key in MODES:
+            if fwd:
+                model.enable_fp8_forward(calibration_inputs=(bt["image"], bt["dna"], None), towers=fwd)
+            else:
+                model.enable_fp8_forward(enabled=False)
+            model.enable_fp8_dgrad(towers=dg)
+            res[(B, key)] = _cosv(grads(bt), g16)
+            model.enable_fp8_dgrad(enabled=False)
+            print(f"[fp8 fidelity vs batch] unseen batch of {B:4d} pairs, {key}: cosine(fp8, bf16) {res[(B, key)]:.4f}")
+    model.enable_fp8_forward(enabled=False)
+    assert res[(512, "dgrad8(all)")] >= 0.995 and res[(512, "dgrad8(all)")] > res[(32, "dgrad8(all)")], res     # the dgrad's error averages out over the batch
+    assert res[(512, "pooled_ffn+dgrad8(all)")] >= 0.98, res                                                     # training-grade at a realistic batch
+    assert res[(512, "pooled_ffn+dgrad8(pooled)")] >= 0.98, res
+    assert res[(512, "dgrad8(all)")] > res[(512, "pooled_ffn+dgrad8(pooled)")], res                              # at that batch the forward's error is the larger one
+
+
 def test_fp8_pooled_selection_covers_the_text_tower(dev):
     """Tri-modal model (BASELINE configs[3] + configs[4]): the default fp8 selection puts BarcodeBERT AND BERT-small (H = 512, key
     mask, mean over 20 positions: the other token-averaging head) on fp8 operands and leaves the ViT alone.  Embeddings stay within the
