@@ -478,7 +478,8 @@ def test_fp8_gradient_fidelity_against_the_batch_size(dev):
     (per-row power-of-two scales, round to nearest): its error is independent from row to row and averages out over the batch the parameter
     gradient sums over; the fp8 FORWARD moves a sample's embedding, which the loss sees coherently — that error does not average.  So the 32-pair
     protocol of the test above is the pessimistic end for every mode with an 8-bit dgrad: on an unseen batch of 512 pairs (same trained adapters)
-    dgrad8(all) reads >= 0.995 and pooled_ffn + dgrad8(all) — 0.978-0.980 at 32 pairs, "not training-grade" there — passes 0.98.  bench.py's
+    dgrad8(all) reads 0.9981 (0.9889 at 32 pairs, 0.9925 at 128) and pooled_ffn + dgrad8(all) — 0.978-0.983 at 32 pairs, "not training-grade" there —
+    0.9954 (profiles/r06_fp8_fidelity_vs_batch.log).  bench.py's
     `configs4` record measures the same three modes in-run at per-GPU batch 1024 (+7.7 % at 0.9885, +9.2 % at 0.9988, +13.5 % at 0.9874)."""
     from clibd_amd.data import synthetic_batch
     from clibd_amd.model import ClipLoss
