@@ -652,7 +652,14 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
         dist.all_reduce(c, op=dist.ReduceOp.MIN)
         cos = {k: float(c[i]) for i, k in enumerate(keys)}
         cos_raw = {k: float(c[len(keys) + i]) for i, k in enumerate(keys)}
-    return {"workload": f"BASELINE configs[4] per-rank shape: {world} GPU x {b4} pairs (global {world * b4}), Image+DNA, " +
+    # the fastest of the measured modes whose in-run cosine (the lower of training / unseen batch) holds the 0.98 gate
+    cands = [("fp8", ms8, min(cos["train_batch"], cos["fresh_batch"]))]
+    if second:
+        cands += [("fp8_dgrad_all", ms8b, min(cos["dgrad_all_train_batch"], cos["dgrad_all_fresh_batch"])),
+                  ("fp8_ffn_dgrad_all", ms8c, min(cos["ffn_dgrad_all_train_batch"], cos["ffn_dgrad_all_fresh_batch"]))]
+    ok = [c_ for c_ in cands if c_[2] >= 0.98]
+    best = min(ok, key=lambda c_: c_[1]) if ok else None
+    rec = {"workload": f"BASELINE configs[4] per-rank shape: {world} GPU x {b4} pairs (global {world * b4}), Image+DNA, " +
                         ("FULL fine-tune" if with_full else "LoRA r=4") + ", train mode",
             "per_gpu_batch": b4, "global_batch": world * b4, "steps": nsteps,
             "bf16": {"ms_per_step": ms16, "value": world * b4 / (ms16 * 1e-3), "unit": "paired samples/s"},
@@ -683,6 +690,8 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
                     "and every mode reads ~1.0; train_batch / fresh_batch = the same towers with adapters / heads / temperature re-initialised and trained for "
                     "`spread_steps` bf16 AdamW steps (lr 1e-3) on 32 pairs, the protocol of tests/test_fp8_gpu.py (random-init towers, synthetic pairs: no pretrained "
                     "weights exist on this box); at N > 1 the minimum over ranks"}
+    rec["fastest_at_cosine_0.98"] = ({"record": best[0], "speedup": ms16 / best[1], "gradient_cosine_vs_bf16_min": best[2]} if best else None)
+    return rec
 
 
 _JSON_FD = None   # the process's original stdout, saved by main() before fd 1 is pointed at stderr

@@ -61,6 +61,7 @@ def test_bench_prints_exactly_one_json_line(forced):
     assert 0.5 < da["gradient_cosine_vs_bf16"]["train_batch"] <= 1.0 and 0.5 < da["gradient_cosine_vs_bf16"]["fresh_batch"] <= 1.0
     dc = c4["fp8_ffn_dgrad_all"]
     assert dc["ms_per_step"] > 0 and dc["speedup"] > 0 and 0.5 < dc["gradient_cosine_vs_bf16"]["fresh_batch"] <= 1.0
+    assert "fastest_at_cosine_0.98" in c4 and (c4["fastest_at_cosine_0.98"] is None or c4["fastest_at_cosine_0.98"]["record"] in ("fp8", "fp8_dgrad_all", "fp8_ffn_dgrad_all"))
     num2 = d["config"]["numerics"]
     assert all(v["forward"] == "bf16" and v["dgrad"] == "bf16" for v in num2.values())   # the side record switched its mode off again
     if forced == "1":
