@@ -559,7 +559,8 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
         else:
             model.enable_fp8_forward(enabled=False)
 
-    second = not with_full      # the ViT's 8-bit dgrad exists for frozen base weights only
+    second = True               # the 8-bit dgrad on BOTH towers: runs with frozen and with trainable base weights (tests/test_dgrad8_gpu.py, both towers)
+    third = not with_full       # + the fp8 forward: frozen base weights only
 
     try:
         ms16 = timed_steps()
@@ -569,8 +570,9 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
         if second:
             set_mode("dgrad_all")
             ms8b = timed_steps()
-            set_mode("ffn_dgrad_all")
-            ms8c = timed_steps()
+            if third:
+                set_mode("ffn_dgrad_all")
+                ms8c = timed_steps()
             set_mode(True)
         share = None
         if timer is not None and not args.no_gemm_timing:
@@ -591,13 +593,15 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
                 if second:
                     set_mode("dgrad_all")
                     g8b = grad_vector(bt)
-                    set_mode("ffn_dgrad_all")
-                    g8c = grad_vector(bt)
+                    if third:
+                        set_mode("ffn_dgrad_all")
+                        g8c = grad_vector(bt)
                 set_mode(False)
                 g16 = grad_vector(bt)
                 out_[name] = float((g8 @ g16) / (g8.norm() * g16.norm()).clamp_min(1e-300))
                 if second:
                     out_["dgrad_all_" + name] = float((g8b @ g16) / (g8b.norm() * g16.norm()).clamp_min(1e-300))
+                if third:
                     out_["ffn_dgrad_all_" + name] = float((g8c @ g16) / (g8c.norm() * g16.norm()).clamp_min(1e-300))
             return out_
 
@@ -647,7 +651,7 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
             pass
         return {"error": repr(e)}
     if world > 1:   # one number per job: the worst rank's cosine
-        keys = ["train_batch", "fresh_batch"] + (["dgrad_all_train_batch", "dgrad_all_fresh_batch", "ffn_dgrad_all_train_batch", "ffn_dgrad_all_fresh_batch"] if second else [])
+        keys = ["train_batch", "fresh_batch"] + (["dgrad_all_train_batch", "dgrad_all_fresh_batch"] if second else []) + (["ffn_dgrad_all_train_batch", "ffn_dgrad_all_fresh_batch"] if third else [])
         c = torch.tensor([cos[k] for k in keys] + [cos_raw[k] for k in keys], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.MIN)
         cos = {k: float(c[i]) for i, k in enumerate(keys)}
@@ -655,8 +659,9 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
     # the fastest of the measured modes whose in-run cosine (the lower of training / unseen batch) holds the 0.98 gate
     cands = [("fp8", ms8, min(cos["train_batch"], cos["fresh_batch"]))]
     if second:
-        cands += [("fp8_dgrad_all", ms8b, min(cos["dgrad_all_train_batch"], cos["dgrad_all_fresh_batch"])),
-                  ("fp8_ffn_dgrad_all", ms8c, min(cos["ffn_dgrad_all_train_batch"], cos["ffn_dgrad_all_fresh_batch"]))]
+        cands += [("fp8_dgrad_all", ms8b, min(cos["dgrad_all_train_batch"], cos["dgrad_all_fresh_batch"]))]
+    if third:
+        cands += [("fp8_ffn_dgrad_all", ms8c, min(cos["ffn_dgrad_all_train_batch"], cos["ffn_dgrad_all_fresh_batch"]))]
     ok = [c_ for c_ in cands if c_[2] >= 0.98]
     best = min(ok, key=lambda c_: c_[1]) if ok else None
     rec = {"workload": f"BASELINE configs[4] per-rank shape: {world} GPU x {b4} pairs (global {world * b4}), Image+DNA, " +
@@ -672,16 +677,17 @@ def configs4_record(args, model, trainer, dev, world, rank, dist, timer):
                     "fp8_flop_share": share},
             "speedup": ms16 / ms8,
             **({"fp8_dgrad_all": {"ms_per_step": ms8b, "value": world * b4 / (ms8b * 1e-3), "unit": "paired samples/s", "speedup": ms16 / ms8b,
-                                  "mode": "--dgrad fp8 (bf16 forward): e4m3 operands on the MLP / projection activation-gradient GEMMs of BOTH towers (per-row power-of-two "
+                                  "mode": ("--full-finetune " if with_full else "") + "--dgrad fp8 (bf16 forward): e4m3 operands on the MLP / projection activation-gradient GEMMs of BOTH towers (per-row power-of-two "
                                           "scales); every forward GEMM, attention, QKV and every weight gradient stay bf16 — the fastest mode whose gradient holds the 0.98 gate "
                                           "(tests/test_fp8_gpu.py: dgrad8(all))",
                                   "gradient_cosine_vs_bf16": {"train_batch": cos["dgrad_all_train_batch"], "fresh_batch": cos["dgrad_all_fresh_batch"],
-                                                              "as_timed": {"train_batch": cos_raw["dgrad_all_train_batch"], "fresh_batch": cos_raw["dgrad_all_fresh_batch"]}}},
-                "fp8_ffn_dgrad_all": {"ms_per_step": ms8c, "value": world * b4 / (ms8c * 1e-3), "unit": "paired samples/s", "speedup": ms16 / ms8c,
+                                                              "as_timed": {"train_batch": cos_raw["dgrad_all_train_batch"], "fresh_batch": cos_raw["dgrad_all_fresh_batch"]}}}}
+               if second else {}),
+            **({"fp8_ffn_dgrad_all": {"ms_per_step": ms8c, "value": world * b4 / (ms8c * 1e-3), "unit": "paired samples/s", "speedup": ms16 / ms8c,
                                       "mode": "--fp8-forward pooled_ffn --dgrad fp8: the recommended forward selection with the 8-bit dgrad on both towers",
                                       "gradient_cosine_vs_bf16": {"train_batch": cos["ffn_dgrad_all_train_batch"], "fresh_batch": cos["ffn_dgrad_all_fresh_batch"],
                                                                   "as_timed": {"train_batch": cos_raw["ffn_dgrad_all_train_batch"], "fresh_batch": cos_raw["ffn_dgrad_all_fresh_batch"]}}}}
-               if second else {}),
+               if third else {}),
             "gradient_cosine_vs_bf16": dict({k: v for k, v in cos.items() if not k.startswith(("dgrad_all_", "ffn_dgrad_all_"))}, spread_steps=spread_steps, image_embedding_mutual_cosine=spread_after,
                                             as_timed={"train_batch": cos_raw["train_batch"], "fresh_batch": cos_raw["fresh_batch"], "image_embedding_mutual_cosine": spread_raw}),
             "note": "same model, same process, measured after the headline passes; gradient_cosine = cos(fp8-mode gradient, bf16 gradient) over ALL trainable "
