@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--dgrad", choices=["bf16", "fp8", "fp8-pooled"], default=None,
                     help="numerics switch dgrad (BASELINE configs[4]): fp8 = the MLP / projection activation-gradient GEMMs of every tower on e4m3 operands with per-row scales; "
                          "fp8-pooled = of the mean-pooled towers only (BarcodeBERT, BERT-small).  Not the headline config")
-    ap.add_argument("--no-configs4", action="store_true", help="skip the BASELINE configs[4] side record (per-GPU batch 1024: bf16 vs pooled_ffn fp8 forward + fp8-pooled dgrad)")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the BASELINE configs[4] side record (per-GPU batch 1024: bf16 vs three fp8 modes — pooled_ffn forward + fp8-pooled dgrad, 8-bit dgrad on both towers, both — with in-run gradient cosines)")
     ap.add_argument("--configs4-batch", type=int, default=1024, help="per-GPU batch of the configs[4] side record (BIOSCAN-5M-shaped run: 1024)")
     ap.add_argument("--full-finetune", action="store_true", help="model_config.disable_lora: every encoder weight trainable (not the headline config)")
     ap.add_argument("--eval", action="store_true", help="eval path (SURVEY §8f-2, not the headline metric): no-grad embedding forward + K10 top-k search")
