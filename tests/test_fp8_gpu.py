@@ -294,11 +294,13 @@ def test_fp8_forward_matches_the_fp8_oracle(dev, calibrated, towers):
     from clibd_amd.model import ClipLoss
 
     model, om = _oracle_pair(dev)
-    B = 16
-    batch = synthetic_batch(B, torch.device("cpu"), seed=5, rank=0, with_text=False)
-    labels = torch.arange(B) % 11
-    img, dna = batch["image"].to(dev), batch["dna"].to(dev)
     dg8 = towers.endswith("+dgrad8")
+    # batch 16 for the static-scale case and for configs[4]'s whole mode; the three calibrated selections (restored in round 6) at batch 8: the CPU side of
+    # this test is a full-size fp8-emulated forward + backward, ~1.5 s per sample on the GPU box's host share, and the suite has a time limit
+    B = 16 if (not calibrated or dg8) else 8
+    batch = synthetic_batch(B, torch.device("cpu"), seed=5, rank=0, with_text=False)
+    labels = torch.arange(B) % (11 if B == 16 else 5)
+    img, dna = batch["image"].to(dev), batch["dna"].to(dev)
     towers = towers.split("+")[0]
     if dg8:
         model.enable_fp8_dgrad(towers="all")
